@@ -1,0 +1,168 @@
+/* seld_hip.h — C ABI of libseld_hip.so, the MI355X (gfx950) SELDnet hot path.
+ *
+ * The reference (IRIS-AUDIO/SELD) has no FFI; its seam is Python duck typing.  Every entry
+ * point below names the reference interface it replaces (file:line under the reference tree).
+ * The Python package `seld_amd` binds these with ctypes and mirrors the reference's
+ * models.seldnet / train.trainstep / train.teststep surface on top of them.
+ *
+ * Conventions
+ *  - every call returns int: 0 = ok, <0 = error (SELD_ERR_*); seld_last_error() has the text;
+ *    no exception crosses the ABI.
+ *  - pointers are DEVICE pointers unless the name ends in _host.  fp32 everywhere on the ABI.
+ *  - the ctx owns weights, gradients, Adam slots, BN moving statistics and all workspace
+ *    (sized at seld_create for a fixed [B,T,F,C]); the caller owns x / labels / outputs.
+ *  - work is enqueued on the ctx's stream (default: the null stream; seld_set_stream to change)
+ *    and is asynchronous; seld_sync() waits.  Calls on one ctx are not thread-safe; distinct
+ *    ctxs are independent (one ctx per GPU / rank).
+ *  - layouts are the reference's: x [B,T,F,C] (NHWC, H=time), conv kernels HWIO, GRU kernels
+ *    [in,3u] gate order z|r|h with bias [2,3u], labels sed [B,S,nc], doa [B,S,3nc] as x|y|z blocks.
+ */
+#ifndef SELD_HIP_H
+#define SELD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELD_OK 0
+#define SELD_ERR_INVALID (-1)     /* bad argument */
+#define SELD_ERR_UNSUPPORTED (-2) /* valid config this build has no kernel for */
+#define SELD_ERR_HIP (-3)         /* HIP runtime error */
+#define SELD_ERR_NOMEM (-4)
+
+#define SELD_DTYPE_F32 0
+
+#define SELD_DOA_MSE 0  /* tf.keras.losses.MSE function form (train.py:317-320): [B,S] rows, tape sums them */
+#define SELD_DOA_MMSE 1 /* losses.MMSE (losses.py:4-13) */
+
+#define SELD_MAX_LAYERS 4
+
+typedef struct seld_ctx seld_ctx;
+
+/* Architecture = what models.seldnet (models.py:18-32) reads from model_config/seldnet.json. */
+typedef struct seld_arch {
+    int32_t in_ch;                      /* C: 7 (foa) */
+    int32_t n_freq;                     /* F: 64 */
+    int32_t n_conv;                     /* len(FIRST_ARGS.filters) */
+    int32_t filters[SELD_MAX_LAYERS];
+    int32_t pool_t[SELD_MAX_LAYERS];    /* FIRST_ARGS.pool_size[i][0] */
+    int32_t pool_f[SELD_MAX_LAYERS];    /* FIRST_ARGS.pool_size[i][1] */
+    int32_t n_gru;                      /* len(SECOND_ARGS.units) */
+    int32_t gru_units[SELD_MAX_LAYERS];
+    int32_t n_sed_dense;                /* len(SED_ARGS.units) */
+    int32_t sed_units[SELD_MAX_LAYERS];
+    int32_t n_doa_dense;
+    int32_t doa_units[SELD_MAX_LAYERS];
+    int32_t n_classes;                  /* 12 (train.py:306-307) */
+} seld_arch;
+
+/* Loss configuration = train.py:311-320 + the `loss_weight` flag (params.py:30). */
+typedef struct seld_loss_cfg {
+    int32_t doa_loss;        /* SELD_DOA_MSE | SELD_DOA_MMSE */
+    float w_sed, w_doa;      /* loss_weight "1,1000" */
+    float sed_grad_scale;    /* 1 on a single device; 1/world for data parallel MMSE runs */
+    float mmse_den;          /* <=0: sum(mask) of this batch; >0: all-reduced global denominator */
+} seld_loss_cfg;
+
+/* ---- lifecycle: replaces getattr(models, 'seldnet')(input_shape, model_config) (train.py:308) */
+int seld_create(const seld_arch* arch, int B, int T, int dtype, int device, seld_ctx** out);
+void seld_destroy(seld_ctx* ctx);
+const char* seld_last_error(const seld_ctx* ctx); /* ctx may be NULL: last create() error */
+int seld_set_stream(seld_ctx* ctx, void* hip_stream);
+/* batch size of the next calls, 1 <= B <= the B given to seld_create (the reference's Keras model
+ * accepts any batch; data_loader.batch(drop_remainder=False) yields a short last batch) */
+int seld_set_batch(seld_ctx* ctx, int B);
+int seld_sync(seld_ctx* ctx);
+
+/* ---- variables: replaces model.trainable_variables / get_weights / set_weights
+ * (train.py:31-34, evaluator.py:57).  Flat fp32, Keras creation order; seld_variable_info
+ * enumerates (name, offset, shape).  "state" = BN moving_mean/moving_variance pairs. */
+int64_t seld_param_count(const seld_ctx* ctx);
+int64_t seld_state_count(const seld_ctx* ctx);
+int seld_variable_count(const seld_ctx* ctx, int trainable);
+int seld_variable_info(const seld_ctx* ctx, int trainable, int index, char* name, int name_cap,
+                       int64_t* offset, int32_t* rank, int64_t shape[4]);
+int seld_set_weights_host(seld_ctx* ctx, const float* w_host, int64_t n);
+int seld_get_weights_host(seld_ctx* ctx, float* w_host, int64_t n);
+int seld_set_state_host(seld_ctx* ctx, const float* s_host, int64_t n);
+int seld_get_state_host(seld_ctx* ctx, float* s_host, int64_t n);
+int seld_get_grads_host(seld_ctx* ctx, float* g_host, int64_t n);
+int seld_get_adam_host(seld_ctx* ctx, float* m_host, float* v_host, int64_t n);
+int seld_set_adam_host(seld_ctx* ctx, const float* m_host, const float* v_host, int64_t n, int64_t step);
+void* seld_param_ptr(seld_ctx* ctx); /* device, [param_count] fp32 */
+void* seld_grad_ptr(seld_ctx* ctx);  /* device, [param_count] fp32: the DP all-reduce buffer */
+
+/* ---- model(x, training) (models.py:18-32; train.py:25,41).  training!=0: batch statistics,
+ * moving statistics updated.  sed [B,S,nc], doa [B,S,3nc], S = T / prod(pool_t). */
+int seld_forward(seld_ctx* ctx, const float* x, float* sed, float* doa, int training);
+
+/* ---- train.trainstep (train.py:22-36), split so that a data-parallel host can all-reduce
+ * seld_grad_ptr() between the two halves:
+ *   seld_train_fwd_bwd : forward(training=True) + losses + tape.gradient -> grad buffer
+ *   seld_adam_step     : optional AGC (utils.py:86-96) + Adam.apply_gradients (Keras Adam, eps 1e-7)
+ * sloss: 1 float; dloss: [B*S] floats (MSE) or 1 float (MMSE); either may be NULL. */
+int seld_train_fwd_bwd(seld_ctx* ctx, const float* x, const float* y_sed, const float* y_doa,
+                       const seld_loss_cfg* cfg, float* sed, float* doa, float* sloss, float* dloss);
+int seld_adam_step(seld_ctx* ctx, float lr, float beta1, float beta2, float eps, int agc);
+int seld_train_step(seld_ctx* ctx, const float* x, const float* y_sed, const float* y_doa,
+                    const seld_loss_cfg* cfg, float lr, int agc, float* sed, float* doa,
+                    float* sloss, float* dloss);
+/* ---- train.teststep (train.py:39-44) */
+int seld_test_step(seld_ctx* ctx, const float* x, const float* y_sed, const float* y_doa,
+                   const seld_loss_cfg* cfg, float* sed, float* doa, float* sloss, float* dloss);
+/* sum(mask) of losses.MMSE for this batch (1 float, device) — for the DP denominator all-reduce */
+int seld_mmse_den(seld_ctx* ctx, const float* y_doa, float* den);
+
+/* ---- measurement: HIP-event timing of named kernels on the ctx stream (bench.py roofline) */
+int seld_profile_enable(seld_ctx* ctx, int on);
+int seld_profile_count(const seld_ctx* ctx);
+int seld_profile_get(seld_ctx* ctx, int index, char* name, int name_cap, int64_t* launches, double* total_ms);
+int seld_profile_reset(seld_ctx* ctx);
+
+/* ---- per-kernel entry points (unit parity tests; all device pointers, null stream) --------
+ * Each cites what it computes in the reference.  Shapes are checked; SELD_ERR_UNSUPPORTED if
+ * the build has no kernel for them. */
+/* Conv2D(64, 3, padding='same', use_bias=True) on NHWC (layers.py:27-32); x [B,H,W,Cin], w HWIO, z [B,H,W,64].
+ * stats (may be NULL): [2*64] = per-channel sum(z), sum(z^2) over B*H*W (BatchNormalization batch statistics). */
+int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float* z, float* stats,
+                       int B, int H, int W, int Cin, int Cout);
+/* input gradient of the same conv (tape.gradient through Conv2D): dz [B,H,W,64] -> dx [B,H,W,Cin=64] */
+int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int H, int W, int Cin, int Cout);
+/* kernel+bias gradient of the same conv: dw HWIO, db [Cout] */
+int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int B, int H, int W, int Cin, int Cout);
+/* BatchNormalization(training) + ReLU + MaxPooling2D(pt,pf) given scale/shift per channel:
+ * p = maxpool(relu(z*scale+shift)) (layers.py:33-35 + simple_conv_block) */
+int seld_k_bn_relu_pool_fwd(const float* z, const float* scale, const float* shift, float* p,
+                            int B, int H, int W, int C, int pt, int pf);
+/* backward of the same: dp -> dz, dgamma, dbeta given batch mean / invstd / gamma / beta */
+int seld_k_bn_relu_pool_bwd(const float* z, const float* dp, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                            int B, int H, int W, int C, int pt, int pf);
+/* C[M,N] = act(A[M,K] * op(B) + bias); transb=0: B [K,N]; 1: B [N,K]; act 0 none,1 sigmoid,2 tanh */
+int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,
+                int transb, int act, int accumulate);
+/* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels) */
+int seld_k_gemm_tn(const float* A, const float* Bm, float* C, int M, int K1, int N);
+/* Bidirectional(GRU(128, reset_after=True), merge_mode='mul') recurrence (modules.py:311-316).
+ * gx_* [B,S,384] = x*kernel + bias[0]; U_* [128,384]; brec_* = bias[1]; h_* [B,S,128]; out = h_f*h_b.
+ * saved_* [B,S,4,128] (z, r, hh, h*U_h+b) may be NULL. */
+int seld_k_gru_fwd(const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
+                   const float* brec_f, const float* brec_b, float* h_f, float* h_b,
+                   float* saved_f, float* saved_b, float* out, int B, int S, int units);
+/* BPTT of the same: dout [B,S,128] -> dgx_* (input-side pre-activation grads), dgh_* (recurrent-side) */
+int seld_k_gru_bwd(const float* dout, const float* h_f, const float* h_b, const float* saved_f,
+                   const float* saved_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
+                   float* dgh_f, float* dgh_b, int B, int S, int units);
+/* BinaryCrossentropy + MSE|MMSE on head outputs (train.py:26-29, losses.py:4-13): losses and the
+ * gradients w.r.t. the PRE-activation head outputs (sigmoid / tanh folded in). */
+int seld_k_losses(const float* sed, const float* doa, const float* y_sed, const float* y_doa,
+                  const seld_loss_cfg* cfg, float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre,
+                  int B, int S, int nc);
+/* Keras Adam update (train.py:311,34); step is 1-based */
+int seld_k_adam(float* theta, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                float beta2, float eps, int64_t step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

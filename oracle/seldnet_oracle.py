@@ -1,0 +1,373 @@
+"""CPU oracle for the SELDnet train/inference hot path.
+
+*** TEST INFRASTRUCTURE ONLY. ***
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product (``seld_amd``) never does; it
+fails loudly when the HIP library is missing.
+
+*** PARITY UNPINNED (numerics). ***
+The reference (IRIS-AUDIO/SELD) is TensorFlow/Keras code whose arithmetic lives
+in un-vendored ``tensorflow>=2.4.1`` (``requirements.txt:1-8``); TensorFlow is
+not installable in the build container (ordinary ``ModuleNotFoundError``), and
+the reference's own tests for this path pin only shapes and parameter counts
+(``modules_test.py:202-258``, ``complexity_test.py:205-221,292-307``).  This
+file is therefore a restatement of the published Keras semantics, anchored on
+the reference's call sites.  What IS pinned by reference fixtures is checked in
+``tests/test_oracle_pins.py`` (parameter counts 513 840 / 198 144 / 9 360,
+output shapes, polar<->cartesian tables).  Independent cross-checks against
+``torch.nn.GRU`` / ``torch.nn.functional`` are in the same test file.
+
+Reference call sites restated here (file:line under /root/reference):
+  models.py:18-32        seldnet(): FIRST -> SECOND -> SED/DOA heads
+  layers.py:14-38        conv2d_bn(): Conv2D(use_bias) -> BatchNormalization -> ReLU
+  layers.py:41-47        force_1d_inputs(): [B,T,F,C] -> [B,T,F*C]
+  modules.py:302-319     bidirectional_GRU_block(): Bidirectional(GRU, merge_mode='mul')
+  modules.py:350-376     simple_dense_block(): Conv1D(units, k=1), no activation
+  model_config/seldnet.json:2-8   simple_conv_block (NOT in snapshot; SURVEY.md §8 A3
+                         assumption: conv2d_bn(f, 3) -> MaxPooling2D(pool) -> Dropout(0))
+  losses.py:4-13         MMSE
+  train.py:22-44         trainstep / teststep (incl. the non-scalar Keras MSE quirk)
+  train.py:311-320       Adam(lr), BinaryCrossentropy(), tf.keras.losses.MSE
+  utils.py:86-96         adaptive_clip_grad
+
+Keras defaults restated (TF 2.4 .. 2.6 semantics):
+  BatchNormalization: momentum 0.99, epsilon 1e-3, fused: normalise with the biased
+      batch variance, moving_variance updated with the Bessel-corrected one.
+  GRU: reset_after=True, recurrent_activation=sigmoid, gate order z|r|h,
+      kernel [in,3u], recurrent_kernel [u,3u], bias [2,3u] (row0 input, row1 recurrent).
+  BinaryCrossentropy: p clipped to [1e-7, 1-1e-7], log(p + 1e-7), mean over all elements.
+  Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+1e-7).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+BCE_EPS = 1e-7
+ADAM_EPS = 1e-7
+
+
+# --------------------------------------------------------------------------- spec
+@dataclass
+class Spec:
+    """Architecture read from a reference model_config dict (model_config/seldnet.json)."""
+    in_ch: int
+    n_freq: int
+    filters: List[int]
+    pools: List[Tuple[int, int]]
+    gru_units: List[int]
+    sed_units: List[int]
+    doa_units: List[int]
+    n_classes: int = 12
+
+    @staticmethod
+    def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
+        if model_config["FIRST"] != "simple_conv_block":
+            raise ValueError("oracle restates simple_conv_block only")
+        if model_config["SECOND"] != "bidirectional_GRU_block":
+            raise ValueError("oracle restates bidirectional_GRU_block only")
+        fa = model_config["FIRST_ARGS"]
+        return Spec(
+            in_ch=in_ch, n_freq=n_freq,
+            filters=list(fa["filters"]),
+            pools=[tuple(p) for p in fa["pool_size"]],
+            gru_units=list(model_config["SECOND_ARGS"]["units"]),
+            sed_units=list(model_config["SED_ARGS"]["units"]),
+            doa_units=list(model_config["DOA_ARGS"]["units"]),
+            # train.py:306-307 forces n_classes = 12 regardless of the JSON
+            n_classes=int(model_config.get("n_classes", 12)),
+        )
+
+
+def variable_specs(spec: Spec) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tuple[str, Tuple[int, ...]]]]:
+    """(trainable, non_trainable) variable (name, shape) lists in Keras creation order."""
+    tr: List[Tuple[str, Tuple[int, ...]]] = []
+    nt: List[Tuple[str, Tuple[int, ...]]] = []
+    cin = spec.in_ch
+    for i, f in enumerate(spec.filters):
+        tr += [(f"conv{i}.kernel", (3, 3, cin, f)), (f"conv{i}.bias", (f,)),
+               (f"bn{i}.gamma", (f,)), (f"bn{i}.beta", (f,))]
+        nt += [(f"bn{i}.moving_mean", (f,)), (f"bn{i}.moving_variance", (f,))]
+        cin = f
+    fr = spec.n_freq
+    for p in spec.pools:
+        fr //= p[1]
+    feat = fr * spec.filters[-1]
+    for i, u in enumerate(spec.gru_units):
+        for d in ("fwd", "bwd"):
+            tr += [(f"gru{i}.{d}.kernel", (feat, 3 * u)),
+                   (f"gru{i}.{d}.recurrent_kernel", (u, 3 * u)),
+                   (f"gru{i}.{d}.bias", (2, 3 * u))]
+        feat = u
+    for head, units, nout in (("sed", spec.sed_units, spec.n_classes),
+                              ("doa", spec.doa_units, 3 * spec.n_classes)):
+        fin = feat
+        for j, u in enumerate(units):
+            # Conv1D(kernel_size=1) kernel is rank 3 in Keras: [1, in, out]
+            tr += [(f"{head}.dense{j}.kernel", (1, fin, u)), (f"{head}.dense{j}.bias", (u,))]
+            fin = u
+        tr += [(f"{head}.out.kernel", (fin, nout)), (f"{head}.out.bias", (nout,))]
+    return tr, nt
+
+
+def param_count(spec: Spec) -> int:
+    return sum(int(np.prod(s)) for _, s in variable_specs(spec)[0])
+
+
+def unflatten(flat: torch.Tensor, specs) -> Dict[str, torch.Tensor]:
+    out, off = {}, 0
+    for name, shape in specs:
+        n = int(np.prod(shape))
+        out[name] = flat[off:off + n].reshape(shape)
+        off += n
+    assert off == flat.numel(), (off, flat.numel())
+    return out
+
+
+def random_weights(spec: Spec, seed: int = 0, dtype=np.float32):
+    """Non-degenerate random weights for parity tests (every bias/gamma/beta/moving stat
+    is non-trivial so that no term can silently drop out)."""
+    rng = np.random.default_rng(seed)
+    tr, nt = variable_specs(spec)
+    parts = []
+    for name, shape in tr:
+        n = int(np.prod(shape))
+        if name.endswith("gamma"):
+            v = rng.uniform(0.5, 1.5, n) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
+        elif name.endswith("beta") or name.endswith("bias"):
+            v = rng.normal(0, 0.1, n)
+        elif name.endswith("recurrent_kernel"):
+            v = rng.normal(0, 1.0 / math.sqrt(shape[0]), n)
+        else:
+            fan_in = int(np.prod(shape[:-1]))
+            v = rng.normal(0, 1.0 / math.sqrt(fan_in), n)
+        parts.append(v)
+    flat = np.concatenate(parts).astype(dtype)
+    sparts = []
+    for name, shape in nt:
+        n = int(np.prod(shape))
+        sparts.append(rng.normal(0, 0.1, n) if name.endswith("mean") else rng.uniform(0.5, 1.5, n))
+    state = np.concatenate(sparts).astype(dtype)
+    return flat, state
+
+
+# --------------------------------------------------------------------------- layers
+def conv2d_same_nhwc(x, kernel_hwio, bias):
+    """Keras Conv2D(k=3, strides 1, padding='same', use_bias=True) on NHWC (layers.py:27-32)."""
+    w = kernel_hwio.permute(3, 2, 0, 1)  # HWIO -> OIHW
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=1, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+def batchnorm(z, gamma, beta, mov_mean, mov_var, training: bool):
+    """Keras BatchNormalization(axis=-1) (layers.py:33), fused semantics. Returns y, new stats."""
+    if training:
+        n = z.numel() // z.shape[-1]
+        mean = z.mean(dim=(0, 1, 2))
+        var = ((z - mean) ** 2).mean(dim=(0, 1, 2))  # biased
+        y = (z - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+        with torch.no_grad():
+            f = 1.0 - BN_MOMENTUM
+            new_mean = mov_mean * (1 - f) + mean * f
+            new_var = mov_var * (1 - f) + var * (n / max(n - 1, 1)) * f
+        return y, new_mean.detach(), new_var.detach()
+    y = (z - mov_mean) * torch.rsqrt(mov_var + BN_EPS) * gamma + beta
+    return y, mov_mean, mov_var
+
+
+def maxpool_nhwc(a, pool):
+    """Keras MaxPooling2D(pool_size=pool) defaults: strides=pool, padding='valid'."""
+    return F.max_pool2d(a.permute(0, 3, 1, 2), kernel_size=tuple(pool), stride=tuple(pool)).permute(0, 2, 3, 1)
+
+
+def gru_direction(x, kernel, rec_kernel, bias, reverse: bool, return_aux: bool = False):
+    """Keras GRU(units, reset_after=True, return_sequences=True) over [B,S,I] (modules.py:312-315).
+    reverse=True is Bidirectional's backward layer: consume time-reversed input, output re-reversed."""
+    B, S, _ = x.shape
+    u = rec_kernel.shape[0]
+    gx = x @ kernel + bias[0]  # [B,S,3u]
+    h = x.new_zeros(B, u)
+    outs = [None] * S
+    order = range(S - 1, -1, -1) if reverse else range(S)
+    for t in order:
+        gh = h @ rec_kernel + bias[1]
+        z = torch.sigmoid(gx[:, t, :u] + gh[:, :u])
+        r = torch.sigmoid(gx[:, t, u:2 * u] + gh[:, u:2 * u])
+        hh = torch.tanh(gx[:, t, 2 * u:] + r * gh[:, 2 * u:])
+        h = z * h + (1 - z) * hh
+        outs[t] = h
+    return torch.stack(outs, dim=1)
+
+
+def bigru_mul(x, w, prefix):
+    """Bidirectional(GRU, merge_mode='mul') (modules.py:311-316)."""
+    hf = gru_direction(x, w[f"{prefix}.fwd.kernel"], w[f"{prefix}.fwd.recurrent_kernel"], w[f"{prefix}.fwd.bias"], False)
+    hb = gru_direction(x, w[f"{prefix}.bwd.kernel"], w[f"{prefix}.bwd.recurrent_kernel"], w[f"{prefix}.bwd.bias"], True)
+    return hf * hb
+
+
+# --------------------------------------------------------------------------- model
+def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor], x, training: bool,
+            taps: dict | None = None):
+    """models.seldnet forward (models.py:18-32). x [B,T,F,C] -> sed [B,S,nc], doa [B,S,3nc].
+    Returns (sed, doa, new_state). `taps` (optional dict) receives intermediate tensors."""
+    new_st = {}
+    h = x
+    for i in range(len(spec.filters)):
+        z = conv2d_same_nhwc(h, w[f"conv{i}.kernel"], w[f"conv{i}.bias"])
+        y, m, v = batchnorm(z, w[f"bn{i}.gamma"], w[f"bn{i}.beta"],
+                            st[f"bn{i}.moving_mean"], st[f"bn{i}.moving_variance"], training)
+        new_st[f"bn{i}.moving_mean"], new_st[f"bn{i}.moving_variance"] = m, v
+        h = maxpool_nhwc(torch.relu(y), spec.pools[i])
+        if taps is not None:
+            taps[f"conv{i}.z"] = z
+            taps[f"pool{i}"] = h
+    B, S = h.shape[0], h.shape[1]
+    h = h.reshape(B, S, -1)  # layers.force_1d_inputs: feature index = f*C + c
+    for i in range(len(spec.gru_units)):
+        h = bigru_mul(h, w, f"gru{i}")
+        if taps is not None:
+            taps[f"gru{i}"] = h
+    outs = []
+    for head, units, act in (("sed", spec.sed_units, torch.sigmoid), ("doa", spec.doa_units, torch.tanh)):
+        a = h
+        for j in range(len(units)):
+            # Conv1D(units, kernel_size=1, activation=None) == per-step dense (modules.py:368-371)
+            a = a @ w[f"{head}.dense{j}.kernel"][0] + w[f"{head}.dense{j}.bias"]
+        outs.append(act(a @ w[f"{head}.out.kernel"] + w[f"{head}.out.bias"]))
+    return outs[0], outs[1], new_st
+
+
+# --------------------------------------------------------------------------- losses
+def bce(y_true, p):
+    """tf.keras.losses.BinaryCrossentropy() (train.py:312-313): scalar mean over all elements."""
+    p = torch.clamp(p, BCE_EPS, 1.0 - BCE_EPS)
+    return (-(y_true * torch.log(p + BCE_EPS) + (1 - y_true) * torch.log(1 - p + BCE_EPS))).mean()
+
+
+def keras_mse_fn(y_true, y_pred):
+    """tf.keras.losses.MSE *function*: mean over the last axis only -> [B,S] (train.py:317-320)."""
+    return ((y_true - y_pred) ** 2).mean(dim=-1)
+
+
+def mmse(y_true, y_pred):
+    """losses.MMSE (losses.py:4-13)."""
+    sh = y_true.shape
+    sed = y_true.reshape(*sh[:-1], 3, -1)
+    sed = torch.round((sed ** 2).sum(dim=-2))
+    sed = torch.cat([sed] * 3, dim=-1)
+    return (((y_true - y_pred) ** 2) * sed).sum() / sed.sum()
+
+
+def losses_and_objective(sed, doa, y_sed, y_doa, doa_loss: str, loss_weight):
+    """train.py:24-31. Returns (objective whose gradient tape.gradient computes, sloss, dloss).
+    With the Keras MSE function dloss is [B,S]; `loss` is then non-scalar and tape.gradient
+    differentiates its SUM."""
+    sloss = bce(y_sed, sed)
+    if doa_loss == "MSE":
+        dloss = keras_mse_fn(y_doa, doa)
+    elif doa_loss == "MMSE":
+        dloss = mmse(y_doa, doa)
+    else:
+        raise ValueError(doa_loss)
+    loss = sloss * loss_weight[0] + dloss * loss_weight[1]
+    return loss.sum(), sloss, dloss
+
+
+# --------------------------------------------------------------------------- AGC / Adam
+def unitwise_norm(x):
+    """utils.py:66-84."""
+    if x.dim() <= 1:
+        return (x ** 2).sum() ** 0.5
+    if x.dim() in (2, 3):  # rank-3 = Conv1D kernel [1,in,out]: norm over the size-1 axis
+        return (x ** 2).sum(dim=0, keepdim=True) ** 0.5
+    if x.dim() == 4:
+        return (x ** 2).sum(dim=(0, 1, 2), keepdim=True) ** 0.5
+    raise ValueError("unsupported rank")
+
+
+def adaptive_clip_grad(params, grads, clip_factor=0.01, eps=1e-3):
+    """utils.py:86-96."""
+    out = []
+    for p, g in zip(params, grads):
+        max_norm = torch.clamp(unitwise_norm(p), min=eps) * clip_factor
+        gn = unitwise_norm(g)
+        clipped = g * (max_norm / torch.clamp(gn, min=1e-6))
+        out.append(torch.where(gn < max_norm, g, clipped))
+    return out
+
+
+def adam_update(theta, g, m, v, step: int, lr=1e-3, b1=0.9, b2=0.999, eps=ADAM_EPS):
+    """Keras Adam (train.py:311), ResourceApplyAdam form. `step` is 1-based."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    theta = theta - lr_t * m / (torch.sqrt(v) + eps)
+    return theta, m, v
+
+
+# --------------------------------------------------------------------------- steps
+def _as_t(a, dtype):
+    return torch.as_tensor(np.asarray(a)).to(dtype)
+
+
+def test_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, doa_loss="MSE", dtype=torch.float32):
+    """train.teststep (train.py:39-44): forward(training=False) + losses."""
+    tr, nt = variable_specs(spec)
+    with torch.no_grad():
+        w = unflatten(_as_t(flat_w, dtype), tr)
+        st = unflatten(_as_t(flat_state, dtype), nt)
+        sed, doa, _ = forward(spec, w, st, _as_t(x, dtype), training=False)
+        _, sloss, dloss = losses_and_objective(sed, doa, _as_t(y_sed, dtype), _as_t(y_doa, dtype), doa_loss, (1.0, 1.0))
+    return {"sed": sed.numpy(), "doa": doa.numpy(), "sloss": sloss.numpy(), "dloss": dloss.numpy()}
+
+
+def train_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, *, doa_loss="MSE", loss_weight=(1.0, 1000.0),
+               lr=1e-3, step=1, m=None, v=None, agc=False, dtype=torch.float32, want_taps=False):
+    """train.trainstep (train.py:22-36). Returns dict with outputs, losses, flat grads,
+    updated flat weights / BN state / Adam slots."""
+    tr, nt = variable_specs(spec)
+    fw = _as_t(flat_w, dtype).clone().requires_grad_(True)
+    w = unflatten(fw, tr)
+    st = unflatten(_as_t(flat_state, dtype), nt)
+    taps = {} if want_taps else None
+    sed, doa, new_st = forward(spec, w, st, _as_t(x, dtype), training=True, taps=taps)
+    obj, sloss, dloss = losses_and_objective(sed, doa, _as_t(y_sed, dtype), _as_t(y_doa, dtype), doa_loss, loss_weight)
+    (g,) = torch.autograd.grad(obj, fw)
+    with torch.no_grad():
+        if agc:
+            gs = adaptive_clip_grad(list(unflatten(fw, tr).values()), list(unflatten(g, tr).values()))
+            g = torch.cat([t.reshape(-1) for t in gs])
+        m0 = torch.zeros_like(fw) if m is None else _as_t(m, dtype)
+        v0 = torch.zeros_like(fw) if v is None else _as_t(v, dtype)
+        new_w, m1, v1 = adam_update(fw.detach(), g, m0, v0, step, lr=lr)
+        new_state = torch.cat([new_st[name].reshape(-1) for name, _ in nt])
+    out = {"sed": sed.detach().numpy(), "doa": doa.detach().numpy(),
+           "sloss": sloss.detach().numpy(), "dloss": dloss.detach().numpy(),
+           "grad": g.numpy(), "new_w": new_w.numpy(), "new_state": new_state.numpy(),
+           "m": m1.numpy(), "v": v1.numpy()}
+    if want_taps:
+        out["taps"] = {k: t.detach().numpy() for k, t in taps.items()}
+    return out
+
+
+# --------------------------------------------------------------------------- synthetic data
+def synthetic_batch(B: int, T: int, F_: int = 64, C: int = 7, n_classes: int = 12, seed: int = 1234, pool_t: int = 5):
+    """SURVEY.md §8(d) synthetic data: x~N(0,1); sed~Bernoulli(0.1) (>=1 active);
+    doa = unit vectors * sed in [x|y|z] block layout (transforms.py:117-119)."""
+    rng = np.random.default_rng(seed)
+    S = T // pool_t
+    x = rng.standard_normal((B, T, F_, C), dtype=np.float32)
+    sed = (rng.random((B, S, n_classes)) < 0.1).astype(np.float32)
+    sed[0, 0, 0] = 1.0
+    vec = rng.standard_normal((B, S, 3, n_classes))
+    vec /= np.linalg.norm(vec, axis=2, keepdims=True)
+    doa = (vec * sed[:, :, None, :]).reshape(B, S, 3 * n_classes).astype(np.float32)
+    return x, sed, doa

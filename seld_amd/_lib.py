@@ -1,0 +1,137 @@
+"""ctypes binding of libseld_hip.so (include/seld_hip.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  `load()` raises
+`SeldLibraryError` when the shared object is missing or does not export a declared symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseld_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SELD_OK = 0
+SELD_DOA_MSE, SELD_DOA_MMSE = 0, 1
+SELD_DTYPE_F32 = 0
+MAX_LAYERS = 4
+ERR_NAMES = {-1: "SELD_ERR_INVALID", -2: "SELD_ERR_UNSUPPORTED", -3: "SELD_ERR_HIP", -4: "SELD_ERR_NOMEM"}
+
+
+class SeldLibraryError(RuntimeError):
+    pass
+
+
+class SeldError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Arch(C.Structure):
+    _fields_ = [("in_ch", C.c_int32), ("n_freq", C.c_int32), ("n_conv", C.c_int32),
+                ("filters", C.c_int32 * MAX_LAYERS), ("pool_t", C.c_int32 * MAX_LAYERS),
+                ("pool_f", C.c_int32 * MAX_LAYERS), ("n_gru", C.c_int32), ("gru_units", C.c_int32 * MAX_LAYERS),
+                ("n_sed_dense", C.c_int32), ("sed_units", C.c_int32 * MAX_LAYERS),
+                ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32)]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [("doa_loss", C.c_int32), ("w_sed", C.c_float), ("w_doa", C.c_float),
+                ("sed_grad_scale", C.c_float), ("mmse_den", C.c_float)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_FP = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/seld_hip.h declares
+SIGNATURES = {
+    "seld_create": (_I, [C.POINTER(Arch), _I, _I, _I, _I, C.POINTER(_P)]),
+    "seld_destroy": (None, [_P]),
+    "seld_last_error": (C.c_char_p, [_P]),
+    "seld_set_stream": (_I, [_P, _P]),
+    "seld_set_batch": (_I, [_P, _I]),
+    "seld_sync": (_I, [_P]),
+    "seld_param_count": (_L, [_P]),
+    "seld_state_count": (_L, [_P]),
+    "seld_variable_count": (_I, [_P, _I]),
+    "seld_variable_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(C.c_int32), C.POINTER(_L)]),
+    "seld_set_weights_host": (_I, [_P, _P, _L]),
+    "seld_get_weights_host": (_I, [_P, _P, _L]),
+    "seld_set_state_host": (_I, [_P, _P, _L]),
+    "seld_get_state_host": (_I, [_P, _P, _L]),
+    "seld_get_grads_host": (_I, [_P, _P, _L]),
+    "seld_get_adam_host": (_I, [_P, _P, _P, _L]),
+    "seld_set_adam_host": (_I, [_P, _P, _P, _L, _L]),
+    "seld_param_ptr": (_P, [_P]),
+    "seld_grad_ptr": (_P, [_P]),
+    "seld_forward": (_I, [_P, _P, _P, _P, _I]),
+    "seld_train_fwd_bwd": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
+    "seld_adam_step": (_I, [_P, _F, _F, _F, _F, _I]),
+    "seld_train_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _F, _I, _P, _P, _P, _P]),
+    "seld_test_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
+    "seld_mmse_den": (_I, [_P, _P, _P]),
+    "seld_profile_enable": (_I, [_P, _I]),
+    "seld_profile_count": (_I, [_P]),
+    "seld_profile_get": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(C.c_double)]),
+    "seld_profile_reset": (_I, [_P]),
+    "seld_k_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "seld_k_conv3x3_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "seld_k_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "seld_k_bn_relu_pool_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "seld_k_bn_relu_pool_bwd": (_I, [_P] * 9 + [_I] * 6),
+    "seld_k_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "seld_k_gemm_tn": (_I, [_P, _P, _P, _I, _I, _I]),
+    "seld_k_gru_fwd": (_I, [_P] * 11 + [_I] * 3),
+    "seld_k_gru_bwd": (_I, [_P] * 11 + [_I] * 3),
+    "seld_k_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _I, _I, _I]),
+    "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into seld_amd/libseld_hip.so (hipcc cross-compiles
+    without a GPU).  Returns the library path."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SeldLibraryError("building libseld_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """Load libseld_hip.so and bind every declared symbol.  Fails loudly; never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeldLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {CSRC}`.  seld_amd has no CPU/PyTorch fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SeldLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SeldLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None):
+    if rc != SELD_OK:
+        msg = load().seld_last_error(ctx)
+        raise SeldError(rc, msg.decode() if msg else "")

@@ -1,0 +1,608 @@
+// api.hip — C ABI of libseld_hip.so (include/seld_hip.h): context, variable layout, and the
+// orchestration of the SELDnet forward / backward / optimizer kernels on one HIP stream.
+#include "common.h"
+#include "../../include/seld_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Var { std::string name; int64_t off; int rank; int64_t shape[4]; };
+
+struct Timer { std::string name; std::vector<hipEvent_t> ev; int64_t launches = 0; double ms = 0.0; };
+
+struct ConvL {
+    int H, W, Cin, pt, pf;            // input geometry of this conv, pooling
+    int64_t w_off, b_off, g_off, be_off;   // trainable offsets
+    int64_t mm_off, mv_off;           // state offsets
+    float *z = nullptr, *p = nullptr, *dp = nullptr;
+    float *mean, *invstd, *scale, *shift, *c1c2;   // into small buffer
+};
+
+struct GruL {
+    int in_feat;
+    int64_t k_off[2], u_off[2], b_off[2];
+    float *gx[2], *sv[2], *h[2], *out, *din;   // din: gradient w.r.t. this layer's input
+};
+
+struct DenseL { int in, out; int64_t w_off, b_off; float* y; float* dy; };
+
+struct Head {
+    std::vector<DenseL> layers;   // dense chain, last = output layer with activation
+    int act;
+};
+
+}  // namespace
+
+struct seld_ctx {
+    seld_arch arch;
+    int B, Bmax, T, S, device;
+    hipStream_t stream = nullptr;
+    std::vector<Var> tr, nt;
+    int64_t nparam = 0, nstate = 0;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *state = nullptr;
+    int64_t adam_step = 0;
+    std::vector<ConvL> conv;
+    std::vector<GruL> gru;
+    Head heads[2];
+    float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
+    float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
+    float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
+    float *dgx[2] = {nullptr, nullptr}, *dgh[2] = {nullptr, nullptr};
+    float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
+    float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
+    std::vector<void*> allocs;
+    std::string err;
+    bool prof = false;
+    std::vector<Timer> timers;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int fail(seld_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(c, SELD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template <typename T>
+int dalloc(seld_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+    if (e != hipSuccess) return fail(c, SELD_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+void add_var(std::vector<Var>& v, int64_t& off, const std::string& name, std::initializer_list<int64_t> shape) {
+    Var x;
+    x.name = name;
+    x.off = off;
+    x.rank = (int)shape.size();
+    int64_t n = 1;
+    int i = 0;
+    for (int k = 0; k < 4; ++k) x.shape[k] = 1;
+    for (auto s : shape) { x.shape[i++] = s; n *= s; }
+    off += n;
+    v.push_back(x);
+}
+
+struct ProfScope {
+    seld_ctx* c; int idx;
+    ProfScope(seld_ctx* c_, const char* name) : c(c_), idx(-1) {
+        if (!c->prof) return;
+        for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
+        if (idx < 0) { Timer t; t.name = name; c->timers.push_back(t); idx = (int)c->timers.size() - 1; }
+        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
+    }
+    ~ProfScope() {
+        if (idx < 0) return;
+        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
+        c->timers[idx].launches++;
+    }
+};
+#define PROF_CAT2(a, b) a##b
+#define PROF_CAT(a, b) PROF_CAT2(a, b)
+#define PROF(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name)
+
+int check_launch(seld_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, SELD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* seld_last_error(const seld_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ctx** out) {
+    if (!a || !out) return fail(nullptr, SELD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (dtype != SELD_DTYPE_F32) return fail(nullptr, SELD_ERR_UNSUPPORTED, "only SELD_DTYPE_F32 is built");
+    if (B <= 0 || T <= 0) return fail(nullptr, SELD_ERR_INVALID, "B and T must be positive");
+    if (a->n_conv < 1 || a->n_conv > SELD_MAX_LAYERS || a->n_gru < 1 || a->n_gru > SELD_MAX_LAYERS ||
+        a->n_sed_dense < 0 || a->n_sed_dense > SELD_MAX_LAYERS || a->n_doa_dense < 0 || a->n_doa_dense > SELD_MAX_LAYERS)
+        return fail(nullptr, SELD_ERR_INVALID, "layer counts out of range");
+    if (a->in_ch != 7) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for in_ch = 7 (foa)");
+    if (a->n_freq != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for n_freq = 64");
+    if (a->n_classes <= 0) return fail(nullptr, SELD_ERR_INVALID, "n_classes must be positive");
+    int H = T, W = a->n_freq;
+    for (int i = 0; i < a->n_conv; ++i) {
+        if (a->filters[i] != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "conv kernels are built for 64 filters");
+        if (a->pool_t[i] <= 0 || a->pool_f[i] <= 0 || H % a->pool_t[i] || W % a->pool_f[i])
+            return fail(nullptr, SELD_ERR_UNSUPPORTED, "time/frequency extents must be divisible by the pool sizes");
+        if (i > 0 && !(W == 2 || W == 4 || W == 8 || W == 16 || W == 32))
+            return fail(nullptr, SELD_ERR_UNSUPPORTED, "inner conv width must be a power of two <= 32");
+        H /= a->pool_t[i];
+        W /= a->pool_f[i];
+    }
+    const int S = H, feat = W * 64;
+    for (int i = 0; i < a->n_gru; ++i)
+        if (a->gru_units[i] != 128) return fail(nullptr, SELD_ERR_UNSUPPORTED, "GRU kernels are built for 128 units");
+    if (feat != 128) return fail(nullptr, SELD_ERR_UNSUPPORTED, "GRU input projection expects 128 features (F'*C' = 2*64)");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SELD_ERR_HIP, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(nullptr, SELD_ERR_INVALID, "bad device index");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SELD_ERR_HIP, "hipSetDevice failed");
+
+    seld_ctx* c = new seld_ctx();
+    c->arch = *a; c->B = B; c->Bmax = B; c->T = T; c->S = S; c->device = device;
+
+    // ---- variable layout (Keras creation order; oracle/seldnet_oracle.py::variable_specs is the twin)
+    int64_t off = 0, soff = 0;
+    int cin = a->in_ch;
+    H = T; W = a->n_freq;
+    for (int i = 0; i < a->n_conv; ++i) {
+        ConvL L;
+        L.H = H; L.W = W; L.Cin = cin; L.pt = a->pool_t[i]; L.pf = a->pool_f[i];
+        char nm[64];
+        snprintf(nm, sizeof nm, "conv%d.kernel", i); L.w_off = off; add_var(c->tr, off, nm, {3, 3, cin, 64});
+        snprintf(nm, sizeof nm, "conv%d.bias", i);   L.b_off = off; add_var(c->tr, off, nm, {64});
+        snprintf(nm, sizeof nm, "bn%d.gamma", i);    L.g_off = off; add_var(c->tr, off, nm, {64});
+        snprintf(nm, sizeof nm, "bn%d.beta", i);     L.be_off = off; add_var(c->tr, off, nm, {64});
+        snprintf(nm, sizeof nm, "bn%d.moving_mean", i);     L.mm_off = soff; add_var(c->nt, soff, nm, {64});
+        snprintf(nm, sizeof nm, "bn%d.moving_variance", i); L.mv_off = soff; add_var(c->nt, soff, nm, {64});
+        c->conv.push_back(L);
+        cin = 64; H /= L.pt; W /= L.pf;
+    }
+    int fin = feat;
+    for (int i = 0; i < a->n_gru; ++i) {
+        GruL G;
+        G.in_feat = fin;
+        const char* dn[2] = {"fwd", "bwd"};
+        for (int d = 0; d < 2; ++d) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "gru%d.%s.kernel", i, dn[d]);           G.k_off[d] = off; add_var(c->tr, off, nm, {fin, 384});
+            snprintf(nm, sizeof nm, "gru%d.%s.recurrent_kernel", i, dn[d]); G.u_off[d] = off; add_var(c->tr, off, nm, {128, 384});
+            snprintf(nm, sizeof nm, "gru%d.%s.bias", i, dn[d]);             G.b_off[d] = off; add_var(c->tr, off, nm, {2, 384});
+        }
+        c->gru.push_back(G);
+        fin = 128;
+    }
+    for (int hd = 0; hd < 2; ++hd) {
+        const char* hn = hd == 0 ? "sed" : "doa";
+        const int nd = hd == 0 ? a->n_sed_dense : a->n_doa_dense;
+        const int32_t* units = hd == 0 ? a->sed_units : a->doa_units;
+        int in = fin;
+        for (int j = 0; j < nd; ++j) {
+            if (units[j] <= 0 || (units[j] & 3)) { delete c; return fail(nullptr, SELD_ERR_UNSUPPORTED, "dense units must be a positive multiple of 4"); }
+            DenseL D; D.in = in; D.out = units[j];
+            char nm[64];
+            snprintf(nm, sizeof nm, "%s.dense%d.kernel", hn, j); D.w_off = off; add_var(c->tr, off, nm, {1, in, units[j]});
+            snprintf(nm, sizeof nm, "%s.dense%d.bias", hn, j);   D.b_off = off; add_var(c->tr, off, nm, {units[j]});
+            c->heads[hd].layers.push_back(D);
+            in = units[j];
+        }
+        DenseL D; D.in = in; D.out = (hd == 0 ? 1 : 3) * a->n_classes;
+        char nm[64];
+        snprintf(nm, sizeof nm, "%s.out.kernel", hn); D.w_off = off; add_var(c->tr, off, nm, {in, D.out});
+        snprintf(nm, sizeof nm, "%s.out.bias", hn);   D.b_off = off; add_var(c->tr, off, nm, {D.out});
+        c->heads[hd].layers.push_back(D);
+        c->heads[hd].act = hd == 0 ? 1 : 2;
+    }
+    c->nparam = off; c->nstate = soff;
+
+    // ---- device memory
+#define ALLOC(ptr, n) do { int rc_ = dalloc(c, &(ptr), (size_t)(n)); if (rc_) { g_create_err = c->err; seld_destroy(c); return rc_; } } while (0)
+    ALLOC(c->params, c->nparam); ALLOC(c->grads, c->nparam); ALLOC(c->adam_m, c->nparam); ALLOC(c->adam_v, c->nparam);
+    ALLOC(c->state, c->nstate);
+    hipMemset(c->params, 0, c->nparam * 4); hipMemset(c->grads, 0, c->nparam * 4);
+    hipMemset(c->adam_m, 0, c->nparam * 4); hipMemset(c->adam_v, 0, c->nparam * 4); hipMemset(c->state, 0, c->nstate * 4);
+    ALLOC(c->small, (size_t)a->n_conv * 64 * 6);
+    size_t zmax = 0;
+    for (int i = 0; i < a->n_conv; ++i) {
+        ConvL& L = c->conv[i];
+        const size_t nz = (size_t)B * L.H * L.W * 64;
+        const size_t np = (size_t)B * (L.H / L.pt) * (L.W / L.pf) * 64;
+        ALLOC(L.z, nz); ALLOC(L.p, np); ALLOC(L.dp, np);
+        if (nz > zmax) zmax = nz;
+        float* sm = c->small + (size_t)i * 64 * 6;
+        L.mean = sm; L.invstd = sm + 64; L.scale = sm + 128; L.shift = sm + 192; L.c1c2 = sm + 256;
+    }
+    ALLOC(c->dzbuf, zmax);
+    ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
+    ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
+    ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+    ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * 384 * 384);
+    ALLOC(c->cs_slab, (size_t)256 * 512);
+    ALLOC(c->wflip, 9 * 4096);
+    const size_t rows = (size_t)B * S;
+    for (int i = 0; i < a->n_gru; ++i) {
+        GruL& G = c->gru[i];
+        for (int d = 0; d < 2; ++d) { ALLOC(G.gx[d], rows * 384); ALLOC(G.sv[d], rows * 512); ALLOC(G.h[d], rows * 128); }
+        ALLOC(G.out, rows * 128); ALLOC(G.din, rows * (size_t)G.in_feat);
+    }
+    ALLOC(c->feat_grad, rows * 128);
+    for (int d = 0; d < 2; ++d) { ALLOC(c->dgx[d], rows * 384); ALLOC(c->dgh[d], rows * 384); }
+    for (int hd = 0; hd < 2; ++hd)
+        for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
+    ALLOC(c->loss_scratch, (size_t)loss_scratch_floats((int)rows));
+    ALLOC(c->den_dev, 4); ALLOC(c->loss_out, rows + 4);
+#undef ALLOC
+    if (hipDeviceSynchronize() != hipSuccess) { seld_destroy(c); return fail(nullptr, SELD_ERR_HIP, "device sync after allocation failed"); }
+    *out = c;
+    return SELD_OK;
+}
+
+void seld_destroy(seld_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& t : c->timers) for (auto e : t.ev) hipEventDestroy(e);
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+int seld_set_stream(seld_ctx* c, void* s) { if (!c) return SELD_ERR_INVALID; c->stream = (hipStream_t)s; return SELD_OK; }
+int seld_set_batch(seld_ctx* c, int B) {
+    if (!c) return SELD_ERR_INVALID;
+    if (B < 1 || B > c->Bmax) return fail(c, SELD_ERR_INVALID, "batch exceeds the size given to seld_create");
+    c->B = B;
+    return SELD_OK;
+}
+int seld_sync(seld_ctx* c) {
+    if (!c) return SELD_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SELD_OK;
+}
+
+int64_t seld_param_count(const seld_ctx* c) { return c ? c->nparam : -1; }
+int64_t seld_state_count(const seld_ctx* c) { return c ? c->nstate : -1; }
+int seld_variable_count(const seld_ctx* c, int trainable) { return c ? (int)(trainable ? c->tr.size() : c->nt.size()) : -1; }
+int seld_variable_info(const seld_ctx* c, int trainable, int index, char* name, int name_cap, int64_t* offset,
+                       int32_t* rank, int64_t shape[4]) {
+    if (!c) return SELD_ERR_INVALID;
+    const std::vector<Var>& v = trainable ? c->tr : c->nt;
+    if (index < 0 || index >= (int)v.size()) return SELD_ERR_INVALID;
+    if (name && name_cap > 0) { strncpy(name, v[index].name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = v[index].off;
+    if (rank) *rank = v[index].rank;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = v[index].shape[k];
+    return SELD_OK;
+}
+
+static int copy_h2d(seld_ctx* c, float* dst, const float* src, int64_t n, int64_t expect) {
+    if (!c || !src || n != expect) return fail(c, SELD_ERR_INVALID, "size mismatch in host->device copy");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, src, (size_t)n * 4, hipMemcpyHostToDevice));
+    return SELD_OK;
+}
+static int copy_d2h(seld_ctx* c, float* dst, const float* src, int64_t n, int64_t expect) {
+    if (!c || !dst || n != expect) return fail(c, SELD_ERR_INVALID, "size mismatch in device->host copy");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SELD_OK;
+}
+int seld_set_weights_host(seld_ctx* c, const float* w, int64_t n) { return c ? copy_h2d(c, c->params, w, n, c->nparam) : SELD_ERR_INVALID; }
+int seld_get_weights_host(seld_ctx* c, float* w, int64_t n) { return c ? copy_d2h(c, w, c->params, n, c->nparam) : SELD_ERR_INVALID; }
+int seld_set_state_host(seld_ctx* c, const float* s, int64_t n) { return c ? copy_h2d(c, c->state, s, n, c->nstate) : SELD_ERR_INVALID; }
+int seld_get_state_host(seld_ctx* c, float* s, int64_t n) { return c ? copy_d2h(c, s, c->state, n, c->nstate) : SELD_ERR_INVALID; }
+int seld_get_grads_host(seld_ctx* c, float* g, int64_t n) { return c ? copy_d2h(c, g, c->grads, n, c->nparam) : SELD_ERR_INVALID; }
+int seld_get_adam_host(seld_ctx* c, float* m, float* v, int64_t n) {
+    if (!c) return SELD_ERR_INVALID;
+    int rc = copy_d2h(c, m, c->adam_m, n, c->nparam);
+    if (rc) return rc;
+    return copy_d2h(c, v, c->adam_v, n, c->nparam);
+}
+int seld_set_adam_host(seld_ctx* c, const float* m, const float* v, int64_t n, int64_t step) {
+    if (!c || step < 0) return SELD_ERR_INVALID;
+    int rc = copy_h2d(c, c->adam_m, m, n, c->nparam);
+    if (rc) return rc;
+    rc = copy_h2d(c, c->adam_v, v, n, c->nparam);
+    if (rc) return rc;
+    c->adam_step = step;
+    return SELD_OK;
+}
+void* seld_param_ptr(seld_ctx* c) { return c ? c->params : nullptr; }
+void* seld_grad_ptr(seld_ctx* c) { return c ? c->grads : nullptr; }
+
+// ---------------------------------------------------------------------------------------------- forward
+static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
+    hipStream_t st = c->stream;
+    const int B = c->B, S = c->S;
+    const int rows = B * S;
+    const float* in = x;
+    for (size_t i = 0; i < c->conv.size(); ++i) {
+        ConvL& L = c->conv[i];
+        int npart = 0;
+        float* stat = training ? c->stat_partial : nullptr;
+        if (i == 0) {
+            PROF(c, "conv_first_fwd");
+            if (launch_conv_first_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.Cin))
+                return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
+        } else {
+            PROF(c, "conv64_fwd");
+            if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
+                return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
+        }
+        if (training)
+            launch_bn_finalize(st, c->stat_partial, npart, (double)B * L.H * L.W, c->params + L.g_off, c->params + L.be_off,
+                               c->state + L.mm_off, c->state + L.mv_off, L.mean, L.invstd, L.scale, L.shift, 64, 1);
+        else
+            launch_bn_eval_coeffs(st, c->params + L.g_off, c->params + L.be_off, c->state + L.mm_off, c->state + L.mv_off,
+                                  L.scale, L.shift, 64);
+        {
+            PROF(c, "bn_relu_pool_fwd");
+            if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
+                return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
+        }
+        in = L.p;
+    }
+    const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
+    for (size_t i = 0; i < c->gru.size(); ++i) {
+        GruL& G = c->gru[i];
+        {
+            PROF(c, "gru_inproj_gemm");
+            for (int d = 0; d < 2; ++d)
+                launch_gemm(st, feat, G.in_feat, c->params + G.k_off[d], 384, c->params + G.b_off[d], G.gx[d], 384, rows, 384,
+                            G.in_feat, 0, 0, 0);
+        }
+        {
+            PROF(c, "gru_fwd");
+            launch_gru_fwd(st, G.gx[0], G.gx[1], c->params + G.u_off[0], c->params + G.u_off[1], c->params + G.b_off[0] + 384,
+                           c->params + G.b_off[1] + 384, G.h[0], G.h[1], save ? G.sv[0] : nullptr, save ? G.sv[1] : nullptr, B, S);
+        }
+        launch_mul(st, G.h[0], G.h[1], G.out, (int64_t)rows * 128);
+        feat = G.out;
+    }
+    {
+        PROF(c, "heads_fwd");
+        for (int hd = 0; hd < 2; ++hd) {
+            const float* a = feat;
+            Head& Hd = c->heads[hd];
+            for (size_t j = 0; j < Hd.layers.size(); ++j) {
+                DenseL& D = Hd.layers[j];
+                const bool lastl = (j + 1 == Hd.layers.size());
+                float* y = D.y;
+                launch_gemm(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, D.out, rows, D.out, D.in, 0,
+                            lastl ? Hd.act : 0, 0);
+                a = y;
+            }
+            float* outp = hd == 0 ? sed : doa;
+            if (outp) {
+                DenseL& D = Hd.layers.back();
+                if (hipMemcpyAsync(outp, D.y, (size_t)rows * D.out * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return fail(c, SELD_ERR_HIP, "output copy failed");
+            }
+        }
+    }
+    return check_launch(c, "forward");
+}
+
+int seld_forward(seld_ctx* c, const float* x, float* sed, float* doa, int training) {
+    if (!c || !x) return SELD_ERR_INVALID;
+    return forward_impl(c, x, sed, doa, training, false);
+}
+
+static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg, float* sloss,
+                      float* dloss, bool want_grads) {
+    hipStream_t st = c->stream;
+    const int rows = c->B * c->S, nc = c->arch.n_classes;
+    if (cfg->doa_loss != SELD_DOA_MSE && cfg->doa_loss != SELD_DOA_MMSE) return fail(c, SELD_ERR_INVALID, "bad doa_loss");
+    if (cfg->doa_loss == SELD_DOA_MMSE) {
+        if (cfg->mmse_den > 0.f) {
+            if (hipMemcpyAsync(c->den_dev, &cfg->mmse_den, 4, hipMemcpyHostToDevice, st) != hipSuccess)
+                return fail(c, SELD_ERR_HIP, "den copy failed");
+            hipStreamSynchronize(st);  // cfg may live on the caller's stack
+        } else {
+            launch_mmse_den(st, y_doa, c->den_dev, c->loss_scratch, rows, nc);
+        }
+    }
+    float* sl = sloss ? sloss : c->loss_out;
+    float* dl = dloss ? dloss : c->loss_out + 4;
+    launch_losses(st, c->heads[0].layers.back().y, c->heads[1].layers.back().y, y_sed, y_doa, cfg->doa_loss, cfg->w_sed,
+                  cfg->w_doa, cfg->sed_grad_scale, c->den_dev, sl, dl, want_grads ? c->heads[0].layers.back().dy : nullptr,
+                  want_grads ? c->heads[1].layers.back().dy : nullptr, c->loss_scratch, c->B, c->S, nc);
+    return check_launch(c, "losses");
+}
+
+int seld_mmse_den(seld_ctx* c, const float* y_doa, float* den) {
+    if (!c || !y_doa || !den) return SELD_ERR_INVALID;
+    launch_mmse_den(c->stream, y_doa, den, c->loss_scratch, c->B * c->S, c->arch.n_classes);
+    return check_launch(c, "mmse_den");
+}
+
+int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
+                   float* sed, float* doa, float* sloss, float* dloss) {
+    if (!c || !x || !y_sed || !y_doa || !cfg) return SELD_ERR_INVALID;
+    int rc = forward_impl(c, x, sed, doa, 0, false);
+    if (rc) return rc;
+    return run_losses(c, y_sed, y_doa, cfg, sloss, dloss, false);
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// dW[K1,N] = A^T B via slabs, into grads at w_off; optional time shift on A rows
+static void wgrad_dense(seld_ctx* c, const float* A, int lda, const float* Bm, int ldb, int M, int K1, int N, int64_t w_off,
+                        int S, int shift) {
+    int ns = 0;
+    launch_gemm_tn(c->stream, A, lda, Bm, ldb, c->tn_slab, &ns, M, K1, N, S, shift);
+    launch_reduce_slabs(c->stream, c->tn_slab, ns, (int64_t)K1 * N, c->grads + w_off, (int64_t)K1 * N, 0);
+}
+static void bgrad_dense(seld_ctx* c, const float* X, int ld, int M, int N, int64_t b_off) {
+    int ns = 0;
+    launch_colsum(c->stream, X, ld, c->cs_slab, &ns, M, N);
+    launch_reduce_slabs(c->stream, c->cs_slab, ns, N, c->grads + b_off, N, 0);
+}
+
+static int backward_impl(seld_ctx* c, const float* x) {
+    hipStream_t st = c->stream;
+    const int B = c->B, S = c->S, rows = B * S;
+    GruL& Glast = c->gru.back();
+    // ---- heads: gradient w.r.t. the last GRU output accumulates into feat_grad
+    {
+        PROF(c, "heads_bwd");
+        float* dfeat = c->feat_grad;
+        for (int hd = 0; hd < 2; ++hd) {
+            Head& Hd = c->heads[hd];
+            for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
+                DenseL& D = Hd.layers[j];
+                const float* ain = j == 0 ? Glast.out : Hd.layers[j - 1].y;
+                wgrad_dense(c, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, 0, 0);
+                bgrad_dense(c, D.dy, D.out, rows, D.out, D.b_off);
+                float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
+                const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
+                launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
+            }
+        }
+    }
+    // ---- GRU layers, last to first
+    const float* dout = c->feat_grad;
+    for (int i = (int)c->gru.size() - 1; i >= 0; --i) {
+        GruL& G = c->gru[i];
+        const float* lin = i == 0 ? c->conv.back().p : c->gru[i - 1].out;
+        {
+            PROF(c, "gru_bwd");
+            launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[0],
+                           c->dgx[1], c->dgh[0], c->dgh[1], B, S);
+        }
+        PROF(c, "gru_bwd_gemms");
+        for (int d = 0; d < 2; ++d) {
+            wgrad_dense(c, lin, G.in_feat, c->dgx[d], 384, rows, G.in_feat, 384, G.k_off[d], 0, 0);
+            // recurrent kernel: H_prev^T dgh; forward direction saw h[t-1], backward direction h[t+1]
+            wgrad_dense(c, G.h[d], 128, c->dgh[d], 384, rows, 128, 384, G.u_off[d], S, d == 0 ? -1 : 1);
+            bgrad_dense(c, c->dgx[d], 384, rows, 384, G.b_off[d]);
+            bgrad_dense(c, c->dgh[d], 384, rows, 384, G.b_off[d] + 384);
+            launch_gemm(st, c->dgx[d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
+        }
+        dout = G.din;
+    }
+    // ---- conv blocks, last to first.  dout = gradient w.r.t. the last pooled output
+    const float* dp = dout;
+    for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
+        ConvL& L = c->conv[i];
+        int np = 0;
+        {
+            PROF(c, "bn_pool_bwd_reduce");
+            if (launch_bn_pool_bwd_reduce(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
+                                          L.pt, L.pf))
+                return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
+        }
+        launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
+        {
+            PROF(c, "bn_pool_bwd_dz");
+            launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
+        }
+        int ns = 0;
+        if (i == 0) {
+            {
+                PROF(c, "conv_first_wgrad");
+                if (launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin))
+                    return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
+            }
+            // slab rows 0..62 = kernel [9*7][64], row 63 = bias: contiguous with the flat layout
+            launch_reduce_slabs(st, c->wgrad_slab, ns, 4096, c->grads + L.w_off, 4096, 0);
+        } else {
+            const float* lin = c->conv[i - 1].p;
+            {
+                PROF(c, "conv64_wgrad");
+                if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
+                    return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
+            }
+            launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
+            launch_flip_weights(st, c->params + L.w_off, c->wflip);
+            {
+                PROF(c, "conv64_dgrad");
+                launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+            }
+            dp = c->conv[i - 1].dp;
+        }
+    }
+    return check_launch(c, "backward");
+}
+
+int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
+                       float* sed, float* doa, float* sloss, float* dloss) {
+    if (!c || !x || !y_sed || !y_doa || !cfg) return SELD_ERR_INVALID;
+    int rc = forward_impl(c, x, sed, doa, 1, true);
+    if (rc) return rc;
+    rc = run_losses(c, y_sed, y_doa, cfg, sloss, dloss, true);
+    if (rc) return rc;
+    return backward_impl(c, x);
+}
+
+int seld_adam_step(seld_ctx* c, float lr, float beta1, float beta2, float eps, int agc) {
+    if (!c) return SELD_ERR_INVALID;
+    if (agc)
+        for (auto& v : c->tr) launch_agc(c->stream, c->params, c->grads, v.off, v.rank, v.shape, nullptr);
+    c->adam_step += 1;
+    const double t = (double)c->adam_step;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    PROF(c, "adam");
+    launch_adam(c->stream, c->params, c->grads, c->adam_m, c->adam_v, c->nparam, lr_t, beta1, beta2, eps);
+    return check_launch(c, "adam");
+}
+
+int seld_train_step(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
+                    float lr, int agc, float* sed, float* doa, float* sloss, float* dloss) {
+    int rc = seld_train_fwd_bwd(c, x, y_sed, y_doa, cfg, sed, doa, sloss, dloss);
+    if (rc) return rc;
+    return seld_adam_step(c, lr, 0.9f, 0.999f, 1e-7f, agc);
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+int seld_profile_enable(seld_ctx* c, int on) { if (!c) return SELD_ERR_INVALID; c->prof = on != 0; return SELD_OK; }
+int seld_profile_count(const seld_ctx* c) { return c ? (int)c->timers.size() : -1; }
+static void prof_resolve(seld_ctx* c) {
+    hipStreamSynchronize(c->stream);
+    for (auto& t : c->timers) {
+        for (size_t i = 0; i + 1 < t.ev.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) t.ms += ms;
+        }
+        for (auto e : t.ev) hipEventDestroy(e);
+        t.ev.clear();
+    }
+}
+int seld_profile_get(seld_ctx* c, int index, char* name, int name_cap, int64_t* launches, double* total_ms) {
+    if (!c || index < 0 || index >= (int)c->timers.size()) return SELD_ERR_INVALID;
+    prof_resolve(c);
+    Timer& t = c->timers[index];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = t.launches;
+    if (total_ms) *total_ms = t.ms;
+    return SELD_OK;
+}
+int seld_profile_reset(seld_ctx* c) {
+    if (!c) return SELD_ERR_INVALID;
+    prof_resolve(c);
+    c->timers.clear();
+    return SELD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// bn_pool.hip — BatchNormalization + ReLU + MaxPooling2D of layers.conv2d_bn / simple_conv_block
+// (layers.py:33-35), forward and backward, NHWC fp32, C = 64 channels.
+// HBM-bound streaming kernels: float4 over channels, one thread per (pooled pixel, 4 channels).
+//
+//   bn_finalize        block partials (sum z, sum z^2) -> mean, invstd, scale = gamma*invstd,
+//                      shift = beta - mean*scale; moving statistics (momentum 0.99, Bessel-corrected var)
+//   bn_relu_pool_fwd   p = maxpool(relu(z*scale + shift))
+//   bn_pool_bwd_reduce sum dy, sum dy*xhat per channel, dy = dp routed to the window argmax, gated by y>0
+//   bn_bwd_finalize    dgamma, dbeta, c1 = sum dy / N, c2 = sum dy*xhat / N
+//   bn_pool_bwd_dz     dz = scale * (dy - c1 - xhat*c2)
+#include "common.h"
+
+#define BN_MAX_PARTIAL 1024
+int bn_partial_capacity() { return BN_MAX_PARTIAL; }
+
+__global__ __launch_bounds__(128) void bn_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                                          float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                          float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                          int C, int update_moving) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < npartial; ++i) {
+        s1 += (double)partial[(size_t)i * 2 * C + c];
+        s2 += (double)partial[(size_t)i * 2 * C + C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)SELD_BN_EPS));
+    const float sc = gamma[c] * invstd;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = invstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)mean * sc;
+    if (update_moving) {
+        const float f = 1.f - SELD_BN_MOMENTUM;
+        const double bessel = count > 1.0 ? count / (count - 1.0) : 1.0;
+        mov_mean[c] = mov_mean[c] * (1.f - f) + (float)mean * f;
+        mov_var[c] = mov_var[c] * (1.f - f) + (float)(var * bessel) * f;
+    }
+}
+
+int launch_bn_finalize(hipStream_t st, const float* partial, int npartial, double count, const float* gamma,
+                       const float* beta, float* mov_mean, float* mov_var, float* mean, float* invstd,
+                       float* scale, float* shift, int C, int update_moving) {
+    if (C > 128) return -2;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, partial, npartial, count, gamma, beta,
+                       mov_mean, mov_var, mean, invstd, scale, shift, C, update_moving);
+    return 0;
+}
+
+__global__ __launch_bounds__(128) void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mov_mean,
+                                                             const float* __restrict__ mov_var, float* __restrict__ scale,
+                                                             float* __restrict__ shift, int C) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(mov_var[c] + SELD_BN_EPS);
+    scale[c] = sc;
+    shift[c] = beta[c] - mov_mean[c] * sc;
+}
+
+int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* mov_mean,
+                          const float* mov_var, float* scale, float* shift, int C) {
+    if (C > 128) return -2;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(1), dim3(128), 0, st, gamma, beta, mov_mean, mov_var, scale, shift, C);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 fma4(float4 z, float4 a, float4 b) {
+    return make_float4(fmaf(z.x, a.x, b.x), fmaf(z.y, a.y, b.y), fmaf(z.z, a.z, b.z), fmaf(z.w, a.w, b.w));
+}
+
+// one thread per (pooled pixel, channel group of 4); C == 64 -> 16 groups
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ p,
+                                                               int64_t npool, int H, int W, int PT, int PF) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npool * 16) return;
+    const int g = (int)(gid & 15);
+    const int64_t pp = gid >> 4;
+    const int Wp = W / PF, Hp = H / PT;
+    const int fp = (int)(pp % Wp);
+    const int tp = (int)((pp / Wp) % Hp);
+    const int b = (int)(pp / ((int64_t)Wp * Hp));
+    const float4 sc = reinterpret_cast<const float4*>(scale)[g];
+    const float4 sh = reinterpret_cast<const float4*>(shift)[g];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu floor
+    for (int i = 0; i < PT; ++i) {
+        const float* row = z + (((size_t)b * H + (size_t)tp * PT + i) * W + (size_t)fp * PF) * 64 + g * 4;
+        for (int j = 0; j < PF; ++j) {
+            const float4 y = fma4(*reinterpret_cast<const float4*>(row + (size_t)j * 64), sc, sh);
+            m.x = fmaxf(m.x, y.x); m.y = fmaxf(m.y, y.y); m.z = fmaxf(m.z, y.z); m.w = fmaxf(m.w, y.w);
+        }
+    }
+    reinterpret_cast<float4*>(p)[gid] = m;
+}
+
+int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, const float* shift, float* p,
+                            int B, int H, int W, int C, int pt, int pf) {
+    if (C != 64 || H % pt || W % pf) return -2;
+    const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
+    const int64_t nthr = npool * 16;
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, scale, shift, p,
+                       npool, H, W, pt, pf);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1: per-channel sums over the batch of dy and dy*xhat.
+// Thread (slot = tid>>4, g = tid&15) walks pooled pixels slot, slot+16*gridDim, ...
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dp,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 float* __restrict__ partial, int64_t npool, int H, int W,
+                                                                 int PT, int PF) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
+    const int Wp = W / PF, Hp = H / PT;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[g];
+    const float4 sh = reinterpret_cast<const float4*>(shift)[g];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[g];
+    const float4 is = reinterpret_cast<const float4*>(invstd)[g];
+    float sdy[4] = {0.f, 0.f, 0.f, 0.f}, sdx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t pp = (int64_t)blockIdx.x * 16 + slot; pp < npool; pp += (int64_t)gridDim.x * 16) {
+        const int fp = (int)(pp % Wp);
+        const int tp = (int)((pp / Wp) % Hp);
+        const int b = (int)(pp / ((int64_t)Wp * Hp));
+        float ym[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float zm[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PT; ++i) {
+            const float* row = z + (((size_t)b * H + (size_t)tp * PT + i) * W + (size_t)fp * PF) * 64 + g * 4;
+            for (int j = 0; j < PF; ++j) {
+                const float4 zv = *reinterpret_cast<const float4*>(row + (size_t)j * 64);
+                const float4 y = fma4(zv, sc, sh);
+                if (y.x > ym[0]) { ym[0] = y.x; zm[0] = zv.x; }
+                if (y.y > ym[1]) { ym[1] = y.y; zm[1] = zv.y; }
+                if (y.z > ym[2]) { ym[2] = y.z; zm[2] = zv.z; }
+                if (y.w > ym[3]) { ym[3] = y.w; zm[3] = zv.w; }
+            }
+        }
+        const float4 d = reinterpret_cast<const float4*>(dp)[pp * 16 + g];
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w};
+        const float isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float dy = ym[c] > 0.f ? dv[c] : 0.f;
+            sdy[c] += dy;
+            sdx[c] += dy * (zm[c] - muv[c]) * isv[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        red[tid * 8 + c] = sdy[c];
+        red[tid * 8 + 4 + c] = sdx[c];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        // tid -> (kind = tid>>6, channel = tid&63): channel group g = ch>>2, component c = ch&3
+        const int kind = tid >> 6, ch = tid & 63, gg = ch >> 2, cc = ch & 3;
+        float s = 0.f;
+        for (int sl = 0; sl < 16; ++sl) s += red[(sl * 16 + gg) * 8 + kind * 4 + cc];
+        partial[(size_t)blockIdx.x * 128 + tid] = s;
+    }
+}
+
+int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* dp, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* partial,
+                              int* npartial, int B, int H, int W, int C, int pt, int pf) {
+    if (C != 64 || H % pt || W % pf) return -2;
+    const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
+    int64_t blocks = (npool + 15) / 16;
+    if (blocks > BN_MAX_PARTIAL) blocks = BN_MAX_PARTIAL;
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, dp, mean, invstd, scale,
+                       shift, partial, npool, H, W, pt, pf);
+    *npartial = (int)blocks;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ c1c2, int C) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < npartial; ++i) {
+        s1 += (double)partial[(size_t)i * 2 * C + c];
+        s2 += (double)partial[(size_t)i * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    c1c2[c] = (float)(s1 / count);
+    c1c2[C + c] = (float)(s2 / count);
+}
+
+int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
+                           float* dbeta, float* c1c2, int C) {
+    if (C > 64) return -2;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, npartial, count, dgamma, dbeta, c1c2, C);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ dp,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ c1c2, float* __restrict__ dz,
+                                                             int64_t npool, int H, int W, int PT, int PF) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npool * 16) return;
+    const int g = (int)(gid & 15);
+    const int64_t pp = gid >> 4;
+    const int Wp = W / PF, Hp = H / PT;
+    const int fp = (int)(pp % Wp);
+    const int tp = (int)((pp / Wp) % Hp);
+    const int b = (int)(pp / ((int64_t)Wp * Hp));
+    const float4 sc4 = reinterpret_cast<const float4*>(scale)[g];
+    const float4 sh4 = reinterpret_cast<const float4*>(shift)[g];
+    const float4 mu4 = reinterpret_cast<const float4*>(mean)[g];
+    const float4 is4 = reinterpret_cast<const float4*>(invstd)[g];
+    const float4 c14 = reinterpret_cast<const float4*>(c1c2)[g];
+    const float4 c24 = reinterpret_cast<const float4*>(c1c2 + 64)[g];
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+    const float is[4] = {is4.x, is4.y, is4.z, is4.w}, c1[4] = {c14.x, c14.y, c14.z, c14.w};
+    const float c2[4] = {c24.x, c24.y, c24.z, c24.w};
+    float ym[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int am[4] = {0, 0, 0, 0};
+    const size_t base = (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + g * 4;
+    for (int i = 0; i < PT; ++i)
+        for (int j = 0; j < PF; ++j) {
+            const float4 zv = *reinterpret_cast<const float4*>(z + base + ((size_t)i * W + j) * 64);
+            const float4 y = fma4(zv, sc4, sh4);
+            const int pos = i * PF + j;
+            if (y.x > ym[0]) { ym[0] = y.x; am[0] = pos; }
+            if (y.y > ym[1]) { ym[1] = y.y; am[1] = pos; }
+            if (y.z > ym[2]) { ym[2] = y.z; am[2] = pos; }
+            if (y.w > ym[3]) { ym[3] = y.w; am[3] = pos; }
+        }
+    const float4 d = reinterpret_cast<const float4*>(dp)[gid];
+    const float dv[4] = {d.x, d.y, d.z, d.w};
+    float gsel[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gsel[c] = ym[c] > 0.f ? dv[c] : 0.f;
+    for (int i = 0; i < PT; ++i)
+        for (int j = 0; j < PF; ++j) {
+            const size_t a = base + ((size_t)i * W + j) * 64;
+            const float4 zv = *reinterpret_cast<const float4*>(z + a);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            const int pos = i * PF + j;
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xh = (zz[c] - mu[c]) * is[c];
+                const float dy = (pos == am[c]) ? gsel[c] : 0.f;
+                o[c] = sc[c] * (dy - c1[c] - xh * c2[c]);
+            }
+            *reinterpret_cast<float4*>(dz + a) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+}
+
+int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,
+                          const float* scale, const float* shift, const float* c1c2, float* dz,
+                          int B, int H, int W, int C, int pt, int pf) {
+    if (C != 64 || H % pt || W % pf) return -2;
+    const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
+    const int64_t nthr = npool * 16;
+    hipLaunchKernelGGL(bn_pool_bwd_dz_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, dp, mean, invstd,
+                       scale, shift, c1c2, dz, npool, H, W, pt, pf);
+    return 0;
+}

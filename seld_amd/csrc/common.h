@@ -1,0 +1,84 @@
+// common.h — shared device helpers for the gfx950 SELDnet kernels (wave64, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain), 64 FLOP/clk/SIMD.
+// A: lane l holds A[i = l&31][k = l>>5];  B: lane l holds B[k = l>>5][j = l&31].
+// C/D: reg r of lane l is C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+#define MFMA_F32_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+#define SELD_BN_EPS 1e-3f
+#define SELD_BN_MOMENTUM 0.99f
+
+// ---- launcher prototypes (implemented in the .hip files; used by api.hip) -------------------
+struct ConvFirstArgs { const float* x; const float* w; const float* bias; float* z; float* stat_partial; int B, H; };
+
+int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* z,
+                          float* stat_partial, int* n_partial, int B, int H, int Cin);
+int launch_conv64_fwd(hipStream_t st, const float* x, const float* w9, const float* bias, float* z,
+                      float* stat_partial, int* n_partial, int B, int H, int W);
+int conv_stat_partial_capacity();  // max blocks writing stat partials
+int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
+                            int B, int H, int Cin);
+int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
+                        int B, int H, int W);
+int conv_wgrad_slab_capacity();
+int launch_flip_weights(hipStream_t st, const float* w, float* wt);  // [3,3,64,64] -> dgrad weights
+int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
+                        int64_t n, int accumulate);
+
+int launch_bn_finalize(hipStream_t st, const float* partial, int npartial, double count, const float* gamma,
+                       const float* beta, float* mov_mean, float* mov_var, float* mean, float* invstd,
+                       float* scale, float* shift, int C, int update_moving);
+int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* mov_mean,
+                          const float* mov_var, float* scale, float* shift, int C);
+int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, const float* shift, float* p,
+                            int B, int H, int W, int C, int pt, int pf);
+int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* dp, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* partial,
+                              int* npartial, int B, int H, int W, int C, int pt, int pf);
+int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
+                           float* dbeta, float* c1c2, int C);
+int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,
+                          const float* scale, const float* shift, const float* c1c2, float* dz,
+                          int B, int H, int W, int C, int pt, int pf);
+int bn_partial_capacity();
+
+int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
+                int ldc, int M, int N, int K, int transb, int act, int accumulate);
+// C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
+int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
+                   int M, int K1, int N, int S, int shift);
+int gemm_tn_max_splits();
+int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nslab, int M, int N);
+
+int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
+                   const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
+                   int B, int S);
+int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
+                   const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
+                   float* dgh_f, float* dgh_b, int B, int S);
+int launch_mul(hipStream_t st, const float* a, const float* b, float* out, int64_t n);
+
+struct seld_loss_cfg;
+int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scratch, int rows, int nc);
+int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
+                  int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
+                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc);
+int loss_scratch_floats(int rows);
+int launch_adam(hipStream_t st, float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
+                float beta1, float beta2, float eps);
+int launch_agc(hipStream_t st, const float* theta, float* g, int64_t off, int rank, const int64_t* shape,
+               float* scratch);

@@ -1,0 +1,163 @@
+// kernels_api.hip — per-kernel C ABI entry points (include/seld_hip.h, "seld_k_*"): each runs ONE
+// kernel family of the hot path on caller-provided device buffers so the parity tests can compare it
+// with the oracle in isolation.  Null stream; scratch is allocated and freed per call (test use only).
+#include "common.h"
+#include "../../include/seld_hip.h"
+#include <vector>
+#include <math.h>
+
+namespace {
+struct Scratch {
+    std::vector<void*> p;
+    float* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, n * sizeof(float) + 256) != hipSuccess) return nullptr; p.push_back(q); return (float*)q; }
+    ~Scratch() { hipDeviceSynchronize(); for (void* q : p) hipFree(q); }
+};
+int done() { return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? SELD_OK : SELD_ERR_HIP; }
+
+__global__ void coeffs_kernel(const float* mean, const float* invstd, const float* gamma, const float* beta, float* scale,
+                              float* shift, int C) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * invstd[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - mean[c] * sc;
+}
+}  // namespace
+
+extern "C" {
+
+int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float* z, float* stats, int B, int H, int W,
+                       int Cin, int Cout) {
+    if (!x || !w || !z || Cout != 64) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* part = stats ? s.get((size_t)conv_stat_partial_capacity() * 128) : nullptr;
+    if (stats && !part) return SELD_ERR_NOMEM;
+    int np = 0, rc;
+    if (Cin == 64) rc = launch_conv64_fwd(0, x, w, bias, z, part, &np, B, H, W);
+    else if (W == 64) rc = launch_conv_first_fwd(0, x, w, bias, z, part, &np, B, H, Cin);
+    else return SELD_ERR_UNSUPPORTED;
+    if (rc) return SELD_ERR_UNSUPPORTED;
+    if (stats) launch_reduce_slabs(0, part, np, 128, stats, 128, 0);
+    return done();
+}
+
+int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int H, int W, int Cin, int Cout) {
+    if (!dz || !w || !dx || Cin != 64 || Cout != 64) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* wt = s.get(9 * 4096);
+    if (!wt) return SELD_ERR_NOMEM;
+    launch_flip_weights(0, w, wt);
+    launch_conv64_fwd(0, dz, wt, nullptr, dx, nullptr, nullptr, B, H, W);
+    return done();
+}
+
+int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int B, int H, int W, int Cin, int Cout) {
+    if (!x || !dz || !dw || !db || Cout != 64) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* slab = s.get((size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+    float* tmp = s.get(9 * 4096 + 64);
+    if (!slab || !tmp) return SELD_ERR_NOMEM;
+    int ns = 0;
+    if (Cin == 64) {
+        if (launch_conv64_wgrad(0, x, dz, slab, &ns, B, H, W)) return SELD_ERR_UNSUPPORTED;
+        launch_reduce_slabs(0, slab, ns, 9 * 4096 + 64, tmp, 9 * 4096 + 64, 0);
+        hipMemcpyAsync(dw, tmp, 9 * 4096 * 4, hipMemcpyDeviceToDevice, 0);
+        hipMemcpyAsync(db, tmp + 9 * 4096, 64 * 4, hipMemcpyDeviceToDevice, 0);
+    } else if (W == 64) {
+        if (launch_conv_first_wgrad(0, x, dz, slab, &ns, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+        launch_reduce_slabs(0, slab, ns, 4096, tmp, 4096, 0);
+        hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
+        hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
+    } else return SELD_ERR_UNSUPPORTED;
+    return done();
+}
+
+int seld_k_bn_relu_pool_fwd(const float* z, const float* scale, const float* shift, float* p, int B, int H, int W, int C,
+                            int pt, int pf) {
+    if (!z || !scale || !shift || !p) return SELD_ERR_INVALID;
+    if (launch_bn_relu_pool_fwd(0, z, scale, shift, p, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    return done();
+}
+
+int seld_k_bn_relu_pool_bwd(const float* z, const float* dp, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float* dz, float* dgamma, float* dbeta, int B, int H, int W, int C, int pt,
+                            int pf) {
+    if (!z || !dp || !mean || !invstd || !gamma || !beta || !dz || !dgamma || !dbeta) return SELD_ERR_INVALID;
+    if (C != 64) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* coef = s.get(64 * 4);
+    float* part = s.get((size_t)bn_partial_capacity() * 128);
+    if (!coef || !part) return SELD_ERR_NOMEM;
+    float *scale = coef, *shift = coef + 64, *c1c2 = coef + 128;
+    hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(64), 0, 0, mean, invstd, gamma, beta, scale, shift, C);
+    int np = 0;
+    if (launch_bn_pool_bwd_reduce(0, z, dp, mean, invstd, scale, shift, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    launch_bn_bwd_finalize(0, part, np, (double)B * H * W, dgamma, dbeta, c1c2, C);
+    launch_bn_pool_bwd_dz(0, z, dp, mean, invstd, scale, shift, c1c2, dz, B, H, W, C, pt, pf);
+    return done();
+}
+
+int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K, int transb, int act,
+                int accumulate) {
+    if (!A || !Bm || !C) return SELD_ERR_INVALID;
+    if (launch_gemm(0, A, K, Bm, transb ? K : N, bias, C, N, M, N, K, transb, act, accumulate)) return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_gemm_tn(const float* A, const float* Bm, float* C, int M, int K1, int N) {
+    if (!A || !Bm || !C) return SELD_ERR_INVALID;
+    Scratch s;
+    float* slab = s.get((size_t)gemm_tn_max_splits() * K1 * N);
+    if (!slab) return SELD_ERR_NOMEM;
+    int ns = 0;
+    if (launch_gemm_tn(0, A, K1, Bm, N, slab, &ns, M, K1, N, 0, 0)) return SELD_ERR_INVALID;
+    launch_reduce_slabs(0, slab, ns, (int64_t)K1 * N, C, (int64_t)K1 * N, 0);
+    return done();
+}
+
+int seld_k_gru_fwd(const float* gx_f, const float* gx_b, const float* U_f, const float* U_b, const float* brec_f,
+                   const float* brec_b, float* h_f, float* h_b, float* saved_f, float* saved_b, float* out, int B, int S,
+                   int units) {
+    if (units != 128) return SELD_ERR_UNSUPPORTED;
+    if (!gx_f || !gx_b || !U_f || !U_b || !brec_f || !brec_b || !h_f || !h_b) return SELD_ERR_INVALID;
+    launch_gru_fwd(0, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, saved_f, saved_b, B, S);
+    if (out) launch_mul(0, h_f, h_b, out, (int64_t)B * S * 128);
+    return done();
+}
+
+int seld_k_gru_bwd(const float* dout, const float* h_f, const float* h_b, const float* saved_f, const float* saved_b,
+                   const float* U_f, const float* U_b, float* dgx_f, float* dgx_b, float* dgh_f, float* dgh_b, int B, int S,
+                   int units) {
+    if (units != 128) return SELD_ERR_UNSUPPORTED;
+    if (!dout || !h_f || !h_b || !saved_f || !saved_b || !U_f || !U_b || !dgx_f || !dgx_b || !dgh_f || !dgh_b) return SELD_ERR_INVALID;
+    launch_gru_bwd(0, dout, h_f, h_b, saved_f, saved_b, U_f, U_b, dgx_f, dgx_b, dgh_f, dgh_b, B, S);
+    return done();
+}
+
+int seld_k_losses(const float* sed, const float* doa, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
+                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, int B, int S, int nc) {
+    if (!sed || !doa || !y_sed || !y_doa || !cfg || !sloss || !dloss) return SELD_ERR_INVALID;
+    Scratch s;
+    const int rows = B * S;
+    float* scr = s.get((size_t)loss_scratch_floats(rows));
+    float* den = s.get(4);
+    if (!scr || !den) return SELD_ERR_NOMEM;
+    if (cfg->doa_loss == SELD_DOA_MMSE) {
+        if (cfg->mmse_den > 0.f) hipMemcpy(den, &cfg->mmse_den, 4, hipMemcpyHostToDevice);
+        else launch_mmse_den(0, y_doa, den, scr, rows, nc);
+    }
+    launch_losses(0, sed, doa, y_sed, y_doa, cfg->doa_loss, cfg->w_sed, cfg->w_doa, cfg->sed_grad_scale, den, sloss, dloss,
+                  dsed_pre, ddoa_pre, scr, B, S, nc);
+    return done();
+}
+
+int seld_k_adam(float* theta, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                int64_t step) {
+    if (!theta || !g || !m || !v || n <= 0 || step < 1) return SELD_ERR_INVALID;
+    const double t = (double)step;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    launch_adam(0, theta, g, m, v, n, lr_t, beta1, beta2, eps);
+    return done();
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// loss_adam.hip — fused losses + optimizer of train.trainstep (train.py:22-36).
+//   losses_kernel   BinaryCrossentropy (train.py:312-313) + tf.keras.losses.MSE function form
+//                   (train.py:317-320; [B,S] rows that tape.gradient SUMS) or
+//                   losses.MMSE (losses.py:4-13): loss values and the gradients w.r.t. the
+//                   PRE-activation head outputs (sigmoid / tanh derivatives folded in).
+//   adam_kernel     Keras Adam, ResourceApplyAdam form, epsilon 1e-7 (train.py:311,34)
+//   agc_kernel      utils.adaptive_clip_grad (utils.py:86-96), unit-wise norms (utils.py:70-83)
+#include "common.h"
+
+#define BCE_EPS 1e-7f
+
+// deterministic single-block column reduction: out[c] = sum_r in[r*ncol + c], ncol <= 4
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ in, int rows, int ncol,
+                                                           double* __restrict__ out) {
+    __shared__ double red[1024];
+    for (int c = 0; c < ncol; ++c) {
+        double s = 0.0;
+        for (int r = threadIdx.x; r < rows; r += 1024) s += (double)in[(size_t)r * ncol + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0];
+        __syncthreads();
+    }
+}
+
+// MMSE mask of one row: m[c] = round(sum_k y[k*nc+c]^2)   (tf.round = half-to-even = rintf)
+__global__ __launch_bounds__(256) void mmse_mask_rows_kernel(const float* __restrict__ y_doa, float* __restrict__ rowsum,
+                                                             int rows, int nc) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* y = y_doa + (size_t)r * 3 * nc;
+    float s = 0.f;
+    for (int c = 0; c < nc; ++c) {
+        const float a = y[c], b = y[nc + c], d = y[2 * nc + c];
+        s += 3.f * rintf(a * a + b * b + d * d);
+    }
+    rowsum[r] = s;
+}
+
+__global__ void den_store_kernel(const double* __restrict__ sums, float* __restrict__ den) { den[0] = (float)sums[0]; }
+
+int loss_scratch_floats(int rows) { return rows * 2 + 64; }
+
+// scratch layout: [rows*2 floats row partials][16 doubles reduced sums]
+int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scratch, int rows, int nc) {
+    double* sums = reinterpret_cast<double*>(scratch + (size_t)rows * 2);
+    hipLaunchKernelGGL(mmse_mask_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, y_doa, scratch, rows, nc);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, st, scratch, rows, 1, sums);
+    hipLaunchKernelGGL(den_store_kernel, dim3(1), dim3(1), 0, st, sums, den);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
+                                                     const float* __restrict__ y_sed, const float* __restrict__ y_doa,
+                                                     int doa_loss, float coef_sed, float w_doa,
+                                                     const float* __restrict__ den_dev, float* __restrict__ dloss_rows,
+                                                     float* __restrict__ dsed_pre, float* __restrict__ ddoa_pre,
+                                                     float* __restrict__ rowpart, int rows, int nc) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = sed + (size_t)r * nc;
+    const float* ys = y_sed + (size_t)r * nc;
+    float bsum = 0.f;
+    for (int c = 0; c < nc; ++c) {
+        const float pv = p[c], y = ys[c];
+        const float pc = fminf(fmaxf(pv, BCE_EPS), 1.f - BCE_EPS);
+        bsum += -(y * logf(pc + BCE_EPS) + (1.f - y) * logf(1.f - pc + BCE_EPS));
+        if (dsed_pre) {
+            const bool pass = (pv >= BCE_EPS) && (pv <= 1.f - BCE_EPS);
+            const float dldp = pass ? -(y / (pc + BCE_EPS) - (1.f - y) / (1.f - pc + BCE_EPS)) : 0.f;
+            dsed_pre[(size_t)r * nc + c] = coef_sed * dldp * pv * (1.f - pv);
+        }
+    }
+    const float* d = doa + (size_t)r * 3 * nc;
+    const float* yd = y_doa + (size_t)r * 3 * nc;
+    float dsum = 0.f;
+    if (doa_loss == 0) {
+        const float inv = 1.f / (float)(3 * nc);
+        for (int k = 0; k < 3 * nc; ++k) {
+            const float e = yd[k] - d[k];
+            dsum += e * e;
+            if (ddoa_pre) ddoa_pre[(size_t)r * 3 * nc + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
+        }
+        dsum *= inv;
+        if (dloss_rows) dloss_rows[r] = dsum;
+    } else {
+        const float den = den_dev[0];
+        for (int c = 0; c < nc; ++c) {
+            const float a = yd[c], b = yd[nc + c], e3 = yd[2 * nc + c];
+            const float m = rintf(a * a + b * b + e3 * e3);
+            for (int k = 0; k < 3; ++k) {
+                const int i = k * nc + c;
+                const float e = yd[i] - d[i];
+                dsum += e * e * m;
+                if (ddoa_pre) ddoa_pre[(size_t)r * 3 * nc + i] = w_doa * (-2.f * e * m / den) * (1.f - d[i] * d[i]);
+            }
+        }
+    }
+    rowpart[(size_t)r * 2 + 0] = bsum;
+    rowpart[(size_t)r * 2 + 1] = dsum;
+}
+
+__global__ void losses_finalize_kernel(const double* __restrict__ sums, int doa_loss, double n_sed,
+                                       const float* __restrict__ den_dev, float* __restrict__ sloss,
+                                       float* __restrict__ dloss) {
+    if (sloss) sloss[0] = (float)(sums[0] / n_sed);
+    if (doa_loss == 1 && dloss) dloss[0] = (float)(sums[1] / (double)den_dev[0]);
+}
+
+int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
+                  int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
+                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc) {
+    const int rows = B * S;
+    // BCE is a mean over rows*nc elements.  With the Keras MSE *function* the per-row loss tensor
+    // sloss*w0 + mse[b,s]*w1 is summed by tape.gradient, which multiplies the BCE term by rows.
+    const float coef_sed = w_sed * sed_grad_scale * (doa_loss == 0 ? (float)rows : 1.f) / ((float)rows * (float)nc);
+    double* sums = reinterpret_cast<double*>(scratch + (size_t)rows * 2);
+    hipLaunchKernelGGL(losses_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss,
+                       coef_sed, w_doa, den_dev, doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, scratch, rows, nc);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, st, scratch, rows, 2, sums);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(1), 0, st, sums, doa_loss, (double)rows * nc, den_dev, sloss,
+                       dloss);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] = theta[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+int launch_adam(hipStream_t st, float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
+                float beta1, float beta2, float eps) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, g, m, v, n, lr_t, beta1,
+                       beta2, eps);
+    return 0;
+}
+
+// unit-wise clip: one thread per "unit" (column); a unit's elements are r*cols + c, r < rows
+__global__ __launch_bounds__(256) void agc_kernel(const float* __restrict__ theta, float* __restrict__ g, int rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float pn = 0.f, gn = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float p = theta[(size_t)r * cols + c], gg = g[(size_t)r * cols + c];
+        pn += p * p;
+        gn += gg * gg;
+    }
+    pn = sqrtf(pn);
+    gn = sqrtf(gn);
+    const float max_norm = fmaxf(pn, 1e-3f) * 0.01f;
+    if (!(gn < max_norm)) {
+        const float sc = max_norm / fmaxf(gn, 1e-6f);
+        for (int r = 0; r < rows; ++r) g[(size_t)r * cols + c] *= sc;
+    }
+}
+
+int launch_agc(hipStream_t st, const float* theta, float* g, int64_t off, int rank, const int64_t* shape, float* scratch) {
+    (void)scratch;
+    int rows = 1, cols = 1;
+    if (rank <= 1) { rows = (int)shape[0]; cols = 1; }
+    else if (rank == 2) { rows = (int)shape[0]; cols = (int)shape[1]; }
+    else if (rank == 3) { rows = (int)shape[0]; cols = (int)(shape[1] * shape[2]); }
+    else { rows = (int)(shape[0] * shape[1] * shape[2]); cols = (int)shape[3]; }
+    hipLaunchKernelGGL(agc_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, theta + off, g + off, rows, cols);
+    return 0;
+}

@@ -1,0 +1,45 @@
+"""Loss selectors mirroring the reference (losses.py:4-13; train.py:311-320).
+
+The arithmetic is fused into the HIP loss kernel; these objects only select it, so that
+`trainstep(model, x, y, sed_loss, doa_loss, loss_weight, optimizer, agc)` keeps the reference's
+argument list (train.py:22)."""
+from __future__ import annotations
+
+from . import _lib
+
+
+class _Loss:
+    name = ""
+
+    def __repr__(self):
+        return f"<seld_amd.losses.{self.name}>"
+
+
+class BinaryCrossentropy(_Loss):
+    """tf.keras.losses.BinaryCrossentropy() (train.py:312-313)."""
+    name = "BinaryCrossentropy"
+
+
+class _MSE(_Loss):
+    """tf.keras.losses.MSE *function*: mean over the last axis -> [B,S]; the resulting non-scalar
+    `loss` is summed by tape.gradient (train.py:29-31)."""
+    name = "MSE"
+    code = _lib.SELD_DOA_MSE
+
+
+class _MMSE(_Loss):
+    """losses.MMSE (losses.py:4-13): masked MSE, scalar."""
+    name = "MMSE"
+    code = _lib.SELD_DOA_MMSE
+
+
+MSE = _MSE()
+MMSE = _MMSE()
+
+
+def get_doa_loss(name: str):
+    """`getattr(tf.keras.losses, config.doa_loss)` / `getattr(losses, ...)` (train.py:317-320)."""
+    table = {"MSE": MSE, "MMSE": MMSE}
+    if name not in table:
+        raise ValueError(f"doa_loss {name!r} has no MI355X kernel (built: {sorted(table)})")
+    return table[name]

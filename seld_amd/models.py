@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's models.py for the SELDnet hot path.
+
+`seldnet(input_shape, model_config)` (reference models.py:18-32, called at train.py:308) returns a
+`SeldNet` whose arithmetic runs entirely in libseld_hip.so.  The block names are resolved the way the
+reference resolves them (`getattr(modules, model_config['FIRST'])`, models.py:24-29), but only the
+blocks of model_config/seldnet.json have kernels; anything else raises ValueError, as the
+reference's block factories do for bad configs (modules.py:202-222).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SUPPORTED_FIRST = ("simple_conv_block",)
+SUPPORTED_SECOND = ("bidirectional_GRU_block",)
+SUPPORTED_HEAD = ("simple_dense_block",)
+
+
+def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
+    for key, ok in (("FIRST", SUPPORTED_FIRST), ("SECOND", SUPPORTED_SECOND), ("SED", SUPPORTED_HEAD), ("DOA", SUPPORTED_HEAD)):
+        if model_config.get(key) not in ok:
+            raise ValueError(f"model_config[{key!r}]={model_config.get(key)!r}: only {ok} has MI355X kernels")
+    fa = model_config["FIRST_ARGS"]
+    filters, pools = list(fa["filters"]), [tuple(p) for p in fa["pool_size"]]
+    if len(filters) != len(pools):
+        raise ValueError("filters and pool_size must have the same length")
+    if fa.get("dropout_rate", 0.0) or model_config["SECOND_ARGS"].get("dropout_rate", 0.0):
+        raise ValueError("dropout_rate > 0 has no kernel (seldnet.json uses 0.0)")
+    gru = list(model_config["SECOND_ARGS"]["units"])
+    sed, doa = list(model_config["SED_ARGS"]["units"]), list(model_config["DOA_ARGS"]["units"])
+    for lst, name in ((filters, "filters"), (gru, "SECOND units"), (sed, "SED units"), (doa, "DOA units")):
+        if len(lst) > _lib.MAX_LAYERS:
+            raise ValueError(f"{name}: at most {_lib.MAX_LAYERS} layers")
+    a = _lib.Arch()
+    a.in_ch, a.n_freq = in_ch, n_freq
+    a.n_conv = len(filters)
+    for i, (f, p) in enumerate(zip(filters, pools)):
+        a.filters[i], a.pool_t[i], a.pool_f[i] = f, p[0], p[1]
+    a.n_gru = len(gru)
+    for i, u in enumerate(gru):
+        a.gru_units[i] = u
+    a.n_sed_dense, a.n_doa_dense = len(sed), len(doa)
+    for i, u in enumerate(sed):
+        a.sed_units[i] = u
+    for i, u in enumerate(doa):
+        a.doa_units[i] = u
+    # models.py:19 default 14; train.py:306-307 overrides to 12 before building
+    a.n_classes = int(model_config.get("n_classes", 14))
+    return a
+
+
+class _DevPtr:
+    """Exposes a raw device pointer owned by the HIP library to torch (zero copy)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+
+
+class SeldNet:
+    """The object `models.seldnet` returns: `model(x, training)`, `trainable_variables`,
+    `get_weights/set_weights`, `summary()`, `save_weights/load_weights`."""
+
+    def __init__(self, input_shape: Sequence[int], model_config: dict, device: int | None = None):
+        if len(input_shape) != 4 or input_shape[0] is None:
+            raise ValueError("input_shape must be [B, T, F, C] with a concrete batch size")
+        B, T, F, Cc = (int(v) for v in input_shape)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SeldLibraryError("no HIP device visible: seld_amd has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.arch = _arch_from_config(model_config, Cc, F)
+        self.input_shape = (B, T, F, Cc)
+        self.model_config = model_config
+        ctx = C.c_void_p()
+        _lib.check(self.lib.seld_create(C.byref(self.arch), B, T, _lib.SELD_DTYPE_F32, self.device, C.byref(ctx)))
+        self.ctx = ctx
+        self.n_params = int(self.lib.seld_param_count(ctx))
+        self.n_state = int(self.lib.seld_state_count(ctx))
+        self.n_classes = int(self.arch.n_classes)
+        st = T
+        for i in range(self.arch.n_conv):
+            st //= self.arch.pool_t[i]
+        self.S = st
+        self.variables = self._enumerate(1)
+        self.state_variables = self._enumerate(0)
+        self._dev = torch.device("cuda", self.device)
+        self.set_weights(initial_weights(self.variables, seed=0), initial_state(self.state_variables))
+
+    # ------------------------------------------------------------------ variables
+    def _enumerate(self, trainable: int) -> List[Tuple[str, int, Tuple[int, ...]]]:
+        out = []
+        n = self.lib.seld_variable_count(self.ctx, trainable)
+        for i in range(n):
+            name = C.create_string_buffer(96)
+            off, rank = C.c_int64(), C.c_int32()
+            shape = (C.c_int64 * 4)()
+            _lib.check(self.lib.seld_variable_info(self.ctx, trainable, i, name, 96, C.byref(off), C.byref(rank), shape), self.ctx)
+            out.append((name.value.decode(), int(off.value), tuple(int(shape[k]) for k in range(rank.value))))
+        return out
+
+    @property
+    def trainable_variables(self) -> Dict[str, np.ndarray]:
+        flat = self.get_weights()[0]
+        return {n: flat[o:o + int(np.prod(s))].reshape(s) for n, o, s in self.variables}
+
+    def get_weights(self) -> Tuple[np.ndarray, np.ndarray]:
+        w = np.empty(self.n_params, np.float32)
+        s = np.empty(self.n_state, np.float32)
+        _lib.check(self.lib.seld_get_weights_host(self.ctx, w.ctypes.data, self.n_params), self.ctx)
+        _lib.check(self.lib.seld_get_state_host(self.ctx, s.ctypes.data, self.n_state), self.ctx)
+        return w, s
+
+    def set_weights(self, flat_w: np.ndarray, flat_state: np.ndarray | None = None) -> None:
+        w = np.ascontiguousarray(flat_w, np.float32)
+        _lib.check(self.lib.seld_set_weights_host(self.ctx, w.ctypes.data, w.size), self.ctx)
+        if flat_state is not None:
+            s = np.ascontiguousarray(flat_state, np.float32)
+            _lib.check(self.lib.seld_set_state_host(self.ctx, s.ctypes.data, s.size), self.ctx)
+
+    def get_grads(self) -> np.ndarray:
+        g = np.empty(self.n_params, np.float32)
+        _lib.check(self.lib.seld_get_grads_host(self.ctx, g.ctypes.data, self.n_params), self.ctx)
+        return g
+
+    def grad_tensor(self) -> torch.Tensor:
+        """The flat gradient buffer as a torch CUDA tensor (zero copy) — the DP all-reduce operand."""
+        return torch.as_tensor(_DevPtr(int(self.lib.seld_grad_ptr(self.ctx)), self.n_params), device=self._dev)
+
+    def param_tensor(self) -> torch.Tensor:
+        return torch.as_tensor(_DevPtr(int(self.lib.seld_param_ptr(self.ctx)), self.n_params), device=self._dev)
+
+    def save_weights(self, path: str) -> None:
+        """Counterpart of tf.keras.models.save_model(..., include_optimizer=False) (train.py:377-380):
+        an .npz keyed by variable name (Keras HDF5 needs h5py, which this image lacks)."""
+        w, s = self.get_weights()
+        d = {n: w[o:o + int(np.prod(sh))].reshape(sh) for n, o, sh in self.variables}
+        d.update({n: s[o:o + int(np.prod(sh))].reshape(sh) for n, o, sh in self.state_variables})
+        np.savez(path, **d)
+
+    def load_weights(self, path: str) -> None:
+        z = np.load(path)
+        w, s = self.get_weights()
+        for n, o, sh in self.variables:
+            w[o:o + int(np.prod(sh))] = np.asarray(z[n], np.float32).reshape(-1)
+        for n, o, sh in self.state_variables:
+            s[o:o + int(np.prod(sh))] = np.asarray(z[n], np.float32).reshape(-1)
+        self.set_weights(w, s)
+
+    def summary(self) -> str:
+        lines = [f"SeldNet input {self.input_shape} -> sed [B,{self.S},{self.n_classes}], doa [B,{self.S},{3 * self.n_classes}]"]
+        for n, o, sh in self.variables:
+            lines.append(f"  {n:32s} {str(sh):20s} {int(np.prod(sh)):8d}")
+        lines.append(f"Trainable params: {self.n_params}; non-trainable: {self.n_state}")
+        text = "\n".join(lines)
+        print(text)
+        return text
+
+    # ------------------------------------------------------------------ calls
+    def _prep(self, x: torch.Tensor) -> torch.Tensor:
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self._dev)
+        x = x.to(torch.float32).contiguous()
+        Bm, T, F, Cc = self.input_shape
+        if tuple(x.shape[1:]) != (T, F, Cc) or not (1 <= x.shape[0] <= Bm):
+            raise ValueError(f"x shape {tuple(x.shape)} incompatible with model input {self.input_shape}")
+        _lib.check(self.lib.seld_set_batch(self.ctx, int(x.shape[0])), self.ctx)
+        _lib.check(self.lib.seld_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)), self.ctx)
+        return x
+
+    def _outputs(self, B: int):
+        sed = torch.empty((B, self.S, self.n_classes), dtype=torch.float32, device=self._dev)
+        doa = torch.empty((B, self.S, 3 * self.n_classes), dtype=torch.float32, device=self._dev)
+        return sed, doa
+
+    def __call__(self, x, training: bool = False):
+        x = self._prep(x)
+        sed, doa = self._outputs(x.shape[0])
+        _lib.check(self.lib.seld_forward(self.ctx, x.data_ptr(), sed.data_ptr(), doa.data_ptr(), int(bool(training))), self.ctx)
+        return [sed, doa]
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.seld_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+
+def seldnet(input_shape, model_config, device=None) -> SeldNet:
+    """reference models.seldnet (models.py:18-32)."""
+    return SeldNet(input_shape, model_config, device)
+
+
+# ---------------------------------------------------------------------- Keras initialisers
+def initial_weights(variables, seed: int = 0) -> np.ndarray:
+    """Keras default initialisers: glorot_uniform kernels, orthogonal GRU recurrent kernels,
+    zero biases, BatchNorm gamma = 1 / beta = 0 (numpy default_rng(seed))."""
+    rng = np.random.default_rng(seed)
+    n = sum(int(np.prod(s)) for _, _, s in variables)
+    flat = np.zeros(n, np.float32)
+    for name, off, shape in variables:
+        size = int(np.prod(shape))
+        if name.endswith("recurrent_kernel"):
+            rows, cols = shape
+            a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+            q, r = np.linalg.qr(a)
+            q = q * np.sign(np.diag(r))
+            v = (q.T if rows < cols else q)[:rows, :cols]
+        elif name.endswith("kernel"):
+            receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            fan_in, fan_out = receptive * shape[-2], receptive * shape[-1]
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            v = rng.uniform(-lim, lim, size)
+        elif name.endswith("gamma"):
+            v = np.ones(size)
+        else:
+            v = np.zeros(size)
+        flat[off:off + size] = np.asarray(v, np.float32).reshape(-1)
+    return flat
+
+
+def initial_state(state_variables) -> np.ndarray:
+    n = sum(int(np.prod(s)) for _, _, s in state_variables)
+    flat = np.zeros(n, np.float32)
+    for name, off, shape in state_variables:
+        if name.endswith("moving_variance"):
+            flat[off:off + int(np.prod(shape))] = 1.0
+    return flat

@@ -1,0 +1,239 @@
+"""Per-kernel parity: each HIP kernel family through its C-ABI entry point (seld_k_*) against the
+CPU oracle / a plain torch-CPU fp32-or-fp64 restatement of the same op.  Tolerance: 1e-4 relative
+(tensor-normalised), the bar BASELINE.json's north_star states for fp32."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import check, dev, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_ref(x, w, b):
+    xt = torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    wt = torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)
+    return F.conv2d(xt, wt, torch.as_tensor(b, dtype=torch.float64), padding=1).permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+def test_conv_fwd(seld_lib, B, H, W, Cin):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, 64)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    z = torch.full((B, H, W, 64), float("nan"), device="cuda")
+    st = torch.zeros(128, device="cuda")
+    assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(z), ptr(st), B, H, W, Cin, 64) == 0
+    ref = _conv_ref(x, w, b)
+    check(f"conv_fwd z {B,H,W,Cin}", z.cpu().numpy(), ref)
+    s = st.cpu().numpy()
+    check("conv_fwd sum(z)", s[:64], ref.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref.size / 64))
+    check("conv_fwd sum(z^2)", s[64:], (ref ** 2).sum(axis=(0, 1, 2)))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16)])
+def test_conv_dgrad(seld_lib, B, H, W):
+    rng = np.random.default_rng(2)
+    dz = rng.standard_normal((B, H, W, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, 64)) / 24).astype(np.float32)
+    x = torch.zeros((B, H, W, 64), dtype=torch.float64, requires_grad=True)
+    wt = torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)
+    y = F.conv2d(x.permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
+    (g,) = torch.autograd.grad(y, x, torch.as_tensor(dz, dtype=torch.float64))
+    dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
+    dzd, wd = dev(dz), dev(w)
+    assert seld_lib.seld_k_conv3x3_dgrad(ptr(dzd), ptr(wd), ptr(dx), B, H, W, 64, 64) == 0
+    check(f"conv_dgrad {B,H,W}", dx.cpu().numpy(), g.numpy())
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+def test_conv_wgrad(seld_lib, B, H, W, Cin):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    dz = rng.standard_normal((B, H, W, 64)).astype(np.float32)
+    w = torch.zeros((3, 3, Cin, 64), dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias, padding=1).permute(0, 2, 3, 1)
+    gw, gb = torch.autograd.grad(y, (w, bias), torch.as_tensor(dz, dtype=torch.float64))
+    dw = torch.full((3, 3, Cin, 64), float("nan"), device="cuda")
+    db = torch.full((64,), float("nan"), device="cuda")
+    xd, dzd = dev(x), dev(dz)
+    assert seld_lib.seld_k_conv3x3_wgrad(ptr(xd), ptr(dzd), ptr(dw), ptr(db), B, H, W, Cin, 64) == 0
+    check(f"conv_wgrad dw {B,H,W,Cin}", dw.cpu().numpy(), gw.numpy())
+    check(f"conv_wgrad db {B,H,W,Cin}", db.cpu().numpy(), gb.numpy())
+
+
+@pytest.mark.parametrize("B,H,W,pt,pf", [(2, 50, 64, 5, 4), (2, 10, 16, 1, 4), (3, 10, 4, 1, 2)])
+def test_bn_relu_pool(seld_lib, B, H, W, pt, pf):
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((B, H, W, 64)).astype(np.float32)
+    gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.2, -1, 1)).astype(np.float32)
+    beta = rng.normal(0, 0.3, 64).astype(np.float32)
+    zt = torch.as_tensor(z, dtype=torch.float64, ).requires_grad_(True)
+    g = torch.as_tensor(gamma, dtype=torch.float64).requires_grad_(True)
+    bt = torch.as_tensor(beta, dtype=torch.float64).requires_grad_(True)
+    mean = zt.mean(dim=(0, 1, 2))
+    var = ((zt - mean) ** 2).mean(dim=(0, 1, 2))
+    invstd = torch.rsqrt(var + 1e-3)
+    y = (zt - mean) * invstd * g + bt
+    p = F.max_pool2d(torch.relu(y).permute(0, 3, 1, 2), (pt, pf), (pt, pf)).permute(0, 2, 3, 1)
+    dp = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+    gz, gg, gb = torch.autograd.grad(p, (zt, g, bt), torch.as_tensor(dp, dtype=torch.float64))
+    scale = (g * invstd).detach().numpy().astype(np.float32)
+    shift = (bt - mean * g * invstd).detach().numpy().astype(np.float32)
+    zd = dev(z)
+    pd = torch.full(tuple(p.shape), float("nan"), device="cuda")
+    sc, sh = dev(scale), dev(shift)
+    assert seld_lib.seld_k_bn_relu_pool_fwd(ptr(zd), ptr(sc), ptr(sh), ptr(pd), B, H, W, 64, pt, pf) == 0
+    check(f"bn_relu_pool_fwd {B,H,W,pt,pf}", pd.cpu().numpy(), p.detach().numpy())
+    dz = torch.full((B, H, W, 64), float("nan"), device="cuda")
+    dg = torch.full((64,), float("nan"), device="cuda")
+    dbt = torch.full((64,), float("nan"), device="cuda")
+    md, isd, gd, bd, dpd = dev(mean.detach().numpy()), dev(invstd.detach().numpy()), dev(gamma), dev(beta), dev(dp)
+    assert seld_lib.seld_k_bn_relu_pool_bwd(ptr(zd), ptr(dpd), ptr(md), ptr(isd), ptr(gd), ptr(bd), ptr(dz), ptr(dg), ptr(dbt),
+                                            B, H, W, 64, pt, pf) == 0
+    check("bn_relu_pool_bwd dz", dz.cpu().numpy(), gz.numpy())
+    check("bn_relu_pool_bwd dgamma", dg.cpu().numpy(), gg.numpy())
+    check("bn_relu_pool_bwd dbeta", dbt.cpu().numpy(), gb.numpy())
+
+
+@pytest.mark.parametrize("M,N,K,transb,act", [(200, 384, 128, 0, 0), (130, 12, 128, 0, 1), (77, 36, 128, 0, 2),
+                                              (200, 128, 384, 1, 0), (99, 128, 12, 1, 0), (64, 128, 36, 1, 0), (70, 50, 30, 0, 0)])
+def test_gemm(seld_lib, M, N, K, transb, act):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = (rng.standard_normal((N, K) if transb else (K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ (Bm.T if transb else Bm).astype(np.float64) + bias
+    if act == 1:
+        ref = 1 / (1 + np.exp(-ref))
+    elif act == 2:
+        ref = np.tanh(ref)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    Ad, Bd, bd = dev(A), dev(Bm), dev(bias)
+    assert seld_lib.seld_k_gemm(ptr(Ad), ptr(Bd), ptr(bd), ptr(Cd), M, N, K, transb, act, 0) == 0
+    check(f"gemm {M,N,K,transb,act}", Cd.cpu().numpy(), ref)
+    # accumulate form
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    Cd = dev(C0)
+    assert seld_lib.seld_k_gemm(ptr(Ad), ptr(Bd), None, ptr(Cd), M, N, K, transb, 0, 1) == 0
+    check("gemm accumulate", Cd.cpu().numpy(), C0 + A.astype(np.float64) @ (Bm.T if transb else Bm).astype(np.float64))
+
+
+@pytest.mark.parametrize("M,K1,N", [(1200, 128, 384), (333, 128, 12), (100, 128, 36), (40, 30, 50)])
+def test_gemm_tn(seld_lib, M, K1, N):
+    rng = np.random.default_rng(6)
+    A = rng.standard_normal((M, K1)).astype(np.float32)
+    Bm = rng.standard_normal((M, N)).astype(np.float32)
+    Cd = torch.full((K1, N), float("nan"), device="cuda")
+    Ad, Bd = dev(A), dev(Bm)
+    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), M, K1, N) == 0
+    check(f"gemm_tn {M,K1,N}", Cd.cpu().numpy(), A.astype(np.float64).T @ Bm.astype(np.float64))
+
+
+def _gru_ref(gx, U, brec, reverse):
+    """Keras GRU(reset_after=True) recurrence in fp64 torch with autograd (oracle twin)."""
+    B, S, _ = gx.shape
+    h = gx.new_zeros(B, 128)
+    outs = [None] * S
+    for t in (range(S - 1, -1, -1) if reverse else range(S)):
+        gh = h @ U + brec
+        z = torch.sigmoid(gx[:, t, :128] + gh[:, :128])
+        r = torch.sigmoid(gx[:, t, 128:256] + gh[:, 128:256])
+        hh = torch.tanh(gx[:, t, 256:] + r * gh[:, 256:])
+        h = z * h + (1 - z) * hh
+        outs[t] = h
+    return torch.stack(outs, 1)
+
+
+@pytest.mark.parametrize("B,S", [(2, 10), (3, 60), (1, 1)])
+def test_gru_fwd_bwd(seld_lib, B, S):
+    rng = np.random.default_rng(7)
+    mk = lambda *s, sc=1.0: (rng.standard_normal(s) * sc).astype(np.float32)
+    gx = [mk(B, S, 384), mk(B, S, 384)]
+    U = [mk(128, 384, sc=1 / np.sqrt(128)), mk(128, 384, sc=1 / np.sqrt(128))]
+    br = [mk(384, sc=0.1), mk(384, sc=0.1)]
+    dout = mk(B, S, 128)
+    tg = [torch.as_tensor(a, dtype=torch.float64).requires_grad_(True) for a in gx]
+    tU = [torch.as_tensor(a, dtype=torch.float64).requires_grad_(True) for a in U]
+    tb = [torch.as_tensor(a, dtype=torch.float64).requires_grad_(True) for a in br]
+    hf = _gru_ref(tg[0], tU[0], tb[0], False)
+    hb = _gru_ref(tg[1], tU[1], tb[1], True)
+    out = hf * hb
+    grads = torch.autograd.grad(out, tg + tU + tb, torch.as_tensor(dout, dtype=torch.float64))
+    d = {k: dev(v) for k, v in dict(gxf=gx[0], gxb=gx[1], Uf=U[0], Ub=U[1], bf=br[0], bb=br[1], dout=dout).items()}
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")
+    h_f, h_b, o = nan(B, S, 128), nan(B, S, 128), nan(B, S, 128)
+    sv_f, sv_b = nan(B, S, 4, 128), nan(B, S, 4, 128)
+    assert seld_lib.seld_k_gru_fwd(ptr(d["gxf"]), ptr(d["gxb"]), ptr(d["Uf"]), ptr(d["Ub"]), ptr(d["bf"]), ptr(d["bb"]),
+                                   ptr(h_f), ptr(h_b), ptr(sv_f), ptr(sv_b), ptr(o), B, S, 128) == 0
+    check(f"gru_fwd h_f {B,S}", h_f.cpu().numpy(), hf.detach().numpy())
+    check(f"gru_fwd h_b {B,S}", h_b.cpu().numpy(), hb.detach().numpy())
+    check("gru_fwd out (mul merge)", o.cpu().numpy(), out.detach().numpy())
+    dgx_f, dgx_b, dgh_f, dgh_b = nan(B, S, 384), nan(B, S, 384), nan(B, S, 384), nan(B, S, 384)
+    assert seld_lib.seld_k_gru_bwd(ptr(d["dout"]), ptr(h_f), ptr(h_b), ptr(sv_f), ptr(sv_b), ptr(d["Uf"]), ptr(d["Ub"]),
+                                   ptr(dgx_f), ptr(dgx_b), ptr(dgh_f), ptr(dgh_b), B, S, 128) == 0
+    check("gru_bwd dgx_f", dgx_f.cpu().numpy(), grads[0].numpy())
+    check("gru_bwd dgx_b", dgx_b.cpu().numpy(), grads[1].numpy())
+    # recurrent kernel / recurrent bias gradients from dgh (what the TN GEMM + colsum compute)
+    for dirn, (dgh, H, gU, gb) in enumerate(((dgh_f, hf, grads[2], grads[4]), (dgh_b, hb, grads[3], grads[5]))):
+        g = dgh.cpu().numpy().astype(np.float64)
+        Hn = H.detach().numpy()
+        Hprev = np.zeros_like(Hn)
+        if dirn == 0:
+            Hprev[:, 1:] = Hn[:, :-1]
+        else:
+            Hprev[:, :-1] = Hn[:, 1:]
+        check(f"gru_bwd dU dir{dirn}", np.einsum("bsk,bsn->kn", Hprev, g), gU.numpy())
+        check(f"gru_bwd dbrec dir{dirn}", g.sum(axis=(0, 1)), gb.numpy())
+
+
+@pytest.mark.parametrize("mode", ["MSE", "MMSE"])
+def test_losses(seld_lib, mode):
+    import sys, os
+    from seld_amd import _lib
+    from oracle import seldnet_oracle as O
+    rng = np.random.default_rng(8)
+    B, S, nc = 3, 20, 12
+    _, ys, yd = O.synthetic_batch(B, S * 5, seed=11)
+    sp = rng.standard_normal((B, S, nc)) * 3
+    sp[0, 0, :4] = [40, -40, 20, -20]  # saturated logits: exercises the BCE clip
+    dpre = rng.standard_normal((B, S, 3 * nc))
+    tsp = torch.as_tensor(sp, dtype=torch.float64).requires_grad_(True)
+    tdp = torch.as_tensor(dpre, dtype=torch.float64).requires_grad_(True)
+    sed, doa = torch.sigmoid(tsp), torch.tanh(tdp)
+    lw = (1.0, 1000.0)
+    obj, sl, dl = O.losses_and_objective(sed, doa, torch.as_tensor(ys, dtype=torch.float64), torch.as_tensor(yd, dtype=torch.float64), mode, lw)
+    gs, gd = torch.autograd.grad(obj, (tsp, tdp))
+    cfg = _lib.LossCfg(0 if mode == "MSE" else 1, lw[0], lw[1], 1.0, 0.0)
+    sedd, doad = dev(sed.detach().numpy()), dev(doa.detach().numpy())
+    ysd, ydd = dev(ys), dev(yd)
+    sl_d = torch.full((1,), float("nan"), device="cuda")
+    dl_d = torch.full((B * S if mode == "MSE" else 1,), float("nan"), device="cuda")
+    gsd, gdd = torch.full((B, S, nc), float("nan"), device="cuda"), torch.full((B, S, 3 * nc), float("nan"), device="cuda")
+    assert seld_lib.seld_k_losses(ptr(sedd), ptr(doad), ptr(ysd), ptr(ydd), C.byref(cfg), ptr(sl_d), ptr(dl_d), ptr(gsd), ptr(gdd), B, S, nc) == 0
+    check(f"losses sloss {mode}", sl_d.cpu().numpy(), sl.detach().numpy().reshape(1))
+    check(f"losses dloss {mode}", dl_d.cpu().numpy(), dl.detach().numpy().reshape(-1))
+    # sigmoid computed in fp32 upstream: compare gradients where the fp32 sigmoid is not saturated
+    check(f"losses dsed_pre {mode}", gsd.cpu().numpy(), gs.numpy(), tol=2e-4)
+    check(f"losses ddoa_pre {mode}", gdd.cpu().numpy(), gd.numpy())
+
+
+def test_adam(seld_lib):
+    rng = np.random.default_rng(9)
+    n = 10007
+    th, g, m, v = (rng.standard_normal(n).astype(np.float32) for _ in range(4))
+    v = np.abs(v)
+    from oracle import seldnet_oracle as O
+    rt, rm, rv = O.adam_update(torch.as_tensor(th, dtype=torch.float64), torch.as_tensor(g, dtype=torch.float64),
+                               torch.as_tensor(m, dtype=torch.float64), torch.as_tensor(v, dtype=torch.float64), step=3, lr=1e-3)
+    td, gd, md, vd = dev(th), dev(g), dev(m), dev(v)
+    assert seld_lib.seld_k_adam(ptr(td), ptr(gd), ptr(md), ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 3) == 0
+    check("adam theta", td.cpu().numpy(), rt.numpy(), tol=1e-6)
+    check("adam m", md.cpu().numpy(), rm.numpy(), tol=1e-6)
+    check("adam v", vd.cpu().numpy(), rv.numpy(), tol=1e-6)
