@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — train-step clips/s of the SELDnet hot path on N MI355X (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one reference train.trainstep (train.py:22-36: forward(training) + BCE/MSE losses +
+gradients + Adam) on one synthetic batch of B clips of [T=3000, F=64, C=7] per GPU (weak scaling:
+B per GPU is fixed).  Rank 0 prints ONE JSON line (metric of BASELINE.json) that also carries
+  roofline      the dominant kernel's achieved rate, from HIP events recorded by the library on its
+                own stream during the timed region, against the gfx950 peak of its bound
+  cpu_baseline  the CPU oracle's train step (PyTorch-CPU restatement of the reference semantics, NOT
+                the reference's TensorFlow) timed on the host cores, N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from __graft_entry__ import SELDNET_CONFIG
+
+METRIC = "train-step clips/sec (7ch×3000×64) seldnet.json at 1/2/4/8 MI355X"
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def kernel_work(name, B, T, F=64, C=7):
+    """Algorithmic work per LAUNCH of a timed kernel group: (bound, amount, unit).
+    FLOP = 2*MAC with MAC counts of SURVEY.md §8 (complexity.py formulas); bytes = the tensors the
+    op must read+write once (fp32)."""
+    S = T // 5
+    px1, px2, px3 = B * T * F, B * S * 16, B * S * 4
+    rows = B * S
+    mac = {"conv1": px1 * 64 * 9 * C, "conv2": px2 * 64 * 576, "conv3": px3 * 64 * 576}
+    table = {
+        "conv1_fwd": ("mfma", 2 * mac["conv1"]), "conv1_wgrad": ("mfma", 2 * mac["conv1"]),
+        "conv2_fwd": ("mfma", 2 * mac["conv2"]), "conv2_wgrad": ("mfma", 2 * mac["conv2"]), "conv2_dgrad": ("mfma", 2 * mac["conv2"]),
+        "conv3_fwd": ("mfma", 2 * mac["conv3"]), "conv3_wgrad": ("mfma", 2 * mac["conv3"]), "conv3_dgrad": ("mfma", 2 * mac["conv3"]),
+        "pool1_fwd": ("hbm", 4 * (px1 * 64 + px1 * 64 // 20)), "pool2_fwd": ("hbm", 4 * (px2 * 64 + px2 * 64 // 4)),
+        "pool3_fwd": ("hbm", 4 * (px3 * 64 + px3 * 64 // 2)),
+        "pool1_bwd_reduce": ("hbm", 4 * (px1 * 64 + px1 * 64 // 20)), "pool1_bwd_dz": ("hbm", 4 * (2 * px1 * 64 + px1 * 64 // 20)),
+        "pool2_bwd_reduce": ("hbm", 4 * (px2 * 64 + px2 * 64 // 4)), "pool2_bwd_dz": ("hbm", 4 * (2 * px2 * 64 + px2 * 64 // 4)),
+        "pool3_bwd_reduce": ("hbm", 4 * (px3 * 64 + px3 * 64 // 2)), "pool3_bwd_dz": ("hbm", 4 * (2 * px3 * 64 + px3 * 64 // 2)),
+        # GRU recurrence (both directions of one layer): read gx [rows,384] + write h [rows,128] + saved gates [rows,512]
+        "gru_fwd": ("hbm", 2 * 4 * rows * (384 + 128 + 512)),
+        "gru_bwd": ("hbm", 2 * 4 * rows * (128 + 128 + 512 + 128 + 768)),
+        "gru_inproj_gemm": ("mfma", 2 * 2 * rows * 128 * 384),
+        "gru_bwd_gemms": ("mfma", 2 * 2 * 3 * rows * 128 * 384),
+        "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
+        "adam": ("hbm", 4 * 7 * 513840),
+    }
+    return table.get(name)
+
+
+def cpu_baseline(B, T, steps):
+    """Oracle train step (PyTorch-CPU fp32 restatement) on the host cores: bounded sample."""
+    from oracle import seldnet_oracle as O
+    spec = O.Spec.from_config(SELDNET_CONFIG)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    cores = torch.get_num_threads()
+    O.train_step(spec, w, st, x, ys, yd)  # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(spec, w, st, x, ys, yd)
+        ts.append(time.perf_counter() - t0)
+    best = float(np.median(ts))
+    return {"value": B / best, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train_step, B={B} clips of [T={T},64,7], median of {steps} steps after 1 warm-up "
+                      f"({best:.2f} s/step); PyTorch-CPU restatement of the reference semantics, not the reference's TF"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE.json configs[1])")
+    ap.add_argument("--frames", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dist = torch.distributed
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from oracle import seldnet_oracle as O  # synthetic data generator only; never in the timed path
+    from seld_amd import losses, models, train
+
+    B, T = args.batch, args.frames
+    model = models.seldnet((B, T, 64, 7), SELDNET_CONFIG, device=local)
+    x, ys, yd = O.synthetic_batch(B, T, seed=1234 + rank)
+    dev = torch.device("cuda", local)
+    x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
+    opt = train.Adam(1e-3)
+    sed_loss, doa_loss, lw = losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
+    timing = not args.no_kernel_timing
+    model.lib.seld_profile_reset(model.ctx)
+    model.lib.seld_profile_enable(model.ctx, int(timing))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y_p, sl, dl = train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    model.lib.seld_profile_enable(model.ctx, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.isfinite(float(sl.item())), "non-finite loss"
+
+    if rank == 0:
+        import ctypes as C
+        kernels = []
+        for i in range(model.lib.seld_profile_count(model.ctx)):
+            name = C.create_string_buffer(64)
+            n, ms = C.c_int64(), C.c_double()
+            model.lib.seld_profile_get(model.ctx, i, name, 64, C.byref(n), C.byref(ms))
+            kernels.append((name.value.decode(), int(n.value), float(ms.value)))
+        roofline, breakdown = None, {}
+        if kernels:
+            for name, n, ms in kernels:
+                breakdown[name] = round(ms / args.steps, 4)
+            name, n, ms = max(kernels, key=lambda k: k[2])
+            work = kernel_work(name, B, T)
+            avg_s = ms / max(n, 1) / 1e3
+            if work:
+                bound, amount = work
+                if bound == "mfma":
+                    ach, peak, unit = amount / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+                else:
+                    ach, peak, unit = amount / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s"
+                traffic = None
+                tf = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tf):
+                    traffic = json.load(open(tf)).get(name, {}).get("hbm_bytes_per_launch")
+                roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                            "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_s * 1e3, 4),
+                            "launches_per_step": n // args.steps}
+        out = {
+            "metric": METRIC, "value": round(world * B * args.steps / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"model_config/seldnet.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
+            "roofline": roofline, "kernel_ms_per_step": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

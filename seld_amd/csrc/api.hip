@@ -342,12 +342,14 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         ConvL& L = c->conv[i];
         int npart = 0;
         float* stat = training ? c->stat_partial : nullptr;
+        char tn[32];
+        snprintf(tn, sizeof tn, "conv%d_fwd", (int)i + 1);
         if (i == 0) {
-            PROF(c, "conv_first_fwd");
+            PROF(c, tn);
             if (launch_conv_first_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
         } else {
-            PROF(c, "conv64_fwd");
+            PROF(c, tn);
             if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
@@ -357,8 +359,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         else
             launch_bn_eval_coeffs(st, c->params + L.g_off, c->params + L.be_off, c->state + L.mm_off, c->state + L.mv_off,
                                   L.scale, L.shift, 64);
+        snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
-            PROF(c, "bn_relu_pool_fwd");
+            PROF(c, tn);
             if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
@@ -507,21 +510,24 @@ static int backward_impl(seld_ctx* c, const float* x) {
     for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
         ConvL& L = c->conv[i];
         int np = 0;
+        char tn[32];
+        snprintf(tn, sizeof tn, "pool%d_bwd_reduce", i + 1);
         {
-            PROF(c, "bn_pool_bwd_reduce");
+            PROF(c, tn);
             if (launch_bn_pool_bwd_reduce(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
                                           L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
         }
         launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
+        snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
         {
-            PROF(c, "bn_pool_bwd_dz");
+            PROF(c, tn);
             launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
         }
         int ns = 0;
         if (i == 0) {
             {
-                PROF(c, "conv_first_wgrad");
+                PROF(c, "conv1_wgrad");
                 if (launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
             }
@@ -529,15 +535,17 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_reduce_slabs(st, c->wgrad_slab, ns, 4096, c->grads + L.w_off, 4096, 0);
         } else {
             const float* lin = c->conv[i - 1].p;
+            snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
             {
-                PROF(c, "conv64_wgrad");
+                PROF(c, tn);
                 if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
             }
             launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
             launch_flip_weights(st, c->params + L.w_off, c->wflip);
+            snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
-                PROF(c, "conv64_dgrad");
+                PROF(c, tn);
                 launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
             }
             dp = c->conv[i - 1].dp;
