@@ -141,8 +141,9 @@ int seld_k_bn_relu_pool_bwd(const float* z, const float* dp, const float* mean, 
 /* C[M,N] = act(A[M,K] * op(B) + bias); transb=0: B [K,N]; 1: B [N,K]; act 0 none,1 sigmoid,2 tanh */
 int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,
                 int transb, int act, int accumulate);
-/* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels) */
-int seld_k_gemm_tn(const float* A, const float* Bm, float* C, int M, int K1, int N);
+/* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels); colsum (may be NULL): [N] = sum_m B[m,:]
+ * (the matching bias gradient, produced by the same launch) */
+int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N);
 /* Bidirectional(GRU(128, reset_after=True), merge_mode='mul') recurrence (modules.py:311-316).
  * gx_* [B,S,384] = x*kernel + bias[0]; U_* [128,384]; brec_* = bias[1]; h_* [B,S,128]; out = h_f*h_b.
  * saved_* [B,S,4,128] (z, r, hh, h*U_h+b) may be NULL. */

@@ -239,7 +239,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
     ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
-    ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * 384 * 384);
+    ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
     const size_t rows = (size_t)B * S;
@@ -451,16 +451,12 @@ int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float*
 
 // ---------------------------------------------------------------------------------------------- backward
 // dW[K1,N] = A^T B via slabs, into grads at w_off; optional time shift on A rows
+// dW[K1,N] = A^T B and db[N] = colsum(B) in one TN launch + one fixed-order slab reduction
 static void wgrad_dense(seld_ctx* c, const float* A, int lda, const float* Bm, int ldb, int M, int K1, int N, int64_t w_off,
-                        int S, int shift) {
+                        int64_t b_off, int S, int shift) {
     int ns = 0;
-    launch_gemm_tn(c->stream, A, lda, Bm, ldb, c->tn_slab, &ns, M, K1, N, S, shift);
-    launch_reduce_slabs(c->stream, c->tn_slab, ns, (int64_t)K1 * N, c->grads + w_off, (int64_t)K1 * N, 0);
-}
-static void bgrad_dense(seld_ctx* c, const float* X, int ld, int M, int N, int64_t b_off) {
-    int ns = 0;
-    launch_colsum(c->stream, X, ld, c->cs_slab, &ns, M, N);
-    launch_reduce_slabs(c->stream, c->cs_slab, ns, N, c->grads + b_off, N, 0);
+    launch_gemm_tn(c->stream, A, lda, Bm, ldb, c->tn_slab, &ns, M, K1, N, S, shift, 1);
+    launch_reduce_slabs2(c->stream, c->tn_slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
 }
 
 static int backward_impl(seld_ctx* c, const float* x) {
@@ -476,8 +472,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
                 DenseL& D = Hd.layers[j];
                 const float* ain = j == 0 ? Glast.out : Hd.layers[j - 1].y;
-                wgrad_dense(c, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, 0, 0);
-                bgrad_dense(c, D.dy, D.out, rows, D.out, D.b_off);
+                wgrad_dense(c, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, D.b_off, 0, 0);
                 float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
                 const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
                 launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
@@ -496,11 +491,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
         }
         PROF(c, "gru_bwd_gemms");
         for (int d = 0; d < 2; ++d) {
-            wgrad_dense(c, lin, G.in_feat, c->dgx[d], 384, rows, G.in_feat, 384, G.k_off[d], 0, 0);
-            // recurrent kernel: H_prev^T dgh; forward direction saw h[t-1], backward direction h[t+1]
-            wgrad_dense(c, G.h[d], 128, c->dgh[d], 384, rows, 128, 384, G.u_off[d], S, d == 0 ? -1 : 1);
-            bgrad_dense(c, c->dgx[d], 384, rows, 384, G.b_off[d]);
-            bgrad_dense(c, c->dgh[d], 384, rows, 384, G.b_off[d] + 384);
+            // kernel + input bias (bias row 0)
+            wgrad_dense(c, lin, G.in_feat, c->dgx[d], 384, rows, G.in_feat, 384, G.k_off[d], G.b_off[d], 0, 0);
+            // recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction h[t+1]) + bias row 1
+            wgrad_dense(c, G.h[d], 128, c->dgh[d], 384, rows, 128, 384, G.u_off[d], G.b_off[d] + 384, S, d == 0 ? -1 : 1);
             launch_gemm(st, c->dgx[d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
         }
         dout = G.din;

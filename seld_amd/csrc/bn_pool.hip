@@ -13,21 +13,35 @@
 #define BN_MAX_PARTIAL 1024
 int bn_partial_capacity() { return BN_MAX_PARTIAL; }
 
-__global__ __launch_bounds__(128) void bn_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ mov_mean, float* __restrict__ mov_var,
-                                                          float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                                          float* __restrict__ scale_o, float* __restrict__ shift_o,
-                                                          int C, int update_moving) {
+// sum the [npartial][2C] block partials: thread (v = tid & 127 value, part = tid >> 7) strides the partials,
+// the 8 parts are combined through LDS in a fixed order (double accumulation, bit-reproducible)
+__device__ __forceinline__ double reduce_partials_128(const float* __restrict__ partial, int npartial, double* red) {
+    const int v = threadIdx.x & 127, part = threadIdx.x >> 7;
+    double s = 0.0;
+    for (int i = part; i < npartial; i += 8) s += (double)partial[(size_t)i * 128 + v];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < 128)
+        for (int p = 0; p < 8; ++p) tot += red[p * 128 + threadIdx.x];
+    return tot;  // valid for threadIdx.x < 128
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                           float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                           int C, int update_moving) {
+    __shared__ double red[1024];
+    __shared__ double tot[128];
+    const double t = reduce_partials_128(partial, npartial, red);
+    if (threadIdx.x < 128) tot[threadIdx.x] = t;
+    __syncthreads();
     const int c = threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < npartial; ++i) {
-        s1 += (double)partial[(size_t)i * 2 * C + c];
-        s2 += (double)partial[(size_t)i * 2 * C + C + c];
-    }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    const double mean = tot[c] / count;
+    double var = tot[64 + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)SELD_BN_EPS));
     const float sc = gamma[c] * invstd;
@@ -46,8 +60,8 @@ __global__ __launch_bounds__(128) void bn_finalize_kernel(const float* __restric
 int launch_bn_finalize(hipStream_t st, const float* partial, int npartial, double count, const float* gamma,
                        const float* beta, float* mov_mean, float* mov_var, float* mean, float* invstd,
                        float* scale, float* shift, int C, int update_moving) {
-    if (C > 128) return -2;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, partial, npartial, count, gamma, beta,
+    if (C != 64) return -2;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, npartial, count, gamma, beta,
                        mov_mean, mov_var, mean, invstd, scale, shift, C, update_moving);
     return 0;
 }
@@ -184,26 +198,21 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* dp, c
     return 0;
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ c1c2, int C) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < npartial; ++i) {
-        s1 += (double)partial[(size_t)i * 2 * C + c];
-        s2 += (double)partial[(size_t)i * 2 * C + C + c];
-    }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-    c1c2[c] = (float)(s1 / count);
-    c1c2[C + c] = (float)(s2 / count);
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int npartial, double count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ c1c2, int C) {
+    __shared__ double red[1024];
+    const double t = reduce_partials_128(partial, npartial, red);
+    const int v = threadIdx.x;
+    if (v >= 128) return;
+    if (v < 64) { dbeta[v] = (float)t; c1c2[v] = (float)(t / count); }
+    else { dgamma[v - 64] = (float)t; c1c2[v] = (float)(t / count); }
 }
 
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C) {
-    if (C > 64) return -2;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, npartial, count, dgamma, dbeta, c1c2, C);
+    if (C != 64) return -2;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, npartial, count, dgamma, dbeta, c1c2, C);
     return 0;
 }
 

@@ -59,8 +59,11 @@ int bn_partial_capacity();
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
                 int ldc, int M, int N, int K, int transb, int act, int accumulate);
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
+// slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift);
+                   int M, int K1, int N, int S, int shift, int want_bias);
+int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
+                         float* out_b, int64_t n_b);
 int gemm_tn_max_splits();
 int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nslab, int M, int N);
 

@@ -135,7 +135,7 @@ int gemm_tn_max_splits() { return TN_MAX_SPLITS; }
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ Bm, int ldb,
                                                       float* __restrict__ slab, int M, int K1, int N,
-                                                      int rows_per_split, int S, int shift) {
+                                                      int rows_per_split, int S, int shift, int want_bias) {
     __shared__ __attribute__((aligned(16))) float As[32 * 64];
     __shared__ __attribute__((aligned(16))) float Bs[32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const bool a_vec = ((lda & 3) == 0) && ((K1 & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
     f32x16 acc = zero16();
+    float bsum = 0.f;  // tid < 64 of the k1-tile-0 blocks: column sum of B (bias gradient)
+    const bool do_bias = want_bias && blockIdx.y == 0 && tid < 64;
     for (int mm0 = mbeg; mm0 < mend; mm0 += 32) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -187,6 +189,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             *reinterpret_cast<float4*>(&Bs[r * 64 + c4]) = make_float4(vb[0], vb[1], vb[2], vb[3]);
         }
         __syncthreads();
+        if (do_bias) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bsum += Bs[r * 64 + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 2) {
             const float a = As[(kk + hi) * 64 + wr * 32 + li];
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    float* out = slab + (size_t)blockIdx.z * K1 * N;
+    float* out = slab + (size_t)blockIdx.z * ((size_t)K1 * N + N);
+    if (do_bias && n0 + tid < N) out[(size_t)K1 * N + n0 + tid] = bsum;
     const int col = n0 + wc * 32 + li;
     if (col < N) {
 #pragma unroll
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift) {
+                   int M, int K1, int N, int S, int shift, int want_bias) {
     if (M <= 0 || K1 <= 0 || N <= 0) return -1;
     int splits = (M + 511) / 512;
     if (splits > TN_MAX_SPLITS) splits = TN_MAX_SPLITS;
@@ -215,7 +222,7 @@ int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
     dim3 grid((N + 63) / 64, (K1 + 63) / 64, splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, Bm, ldb, slab, M, K1, N, rps, S > 0 ? S : M, shift);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, Bm, ldb, slab, M, K1, N, rps, S > 0 ? S : M, shift, want_bias);
     *nslab = splits;
     return 0;
 }
@@ -253,6 +260,26 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     float v = (float)s;
     if (accumulate) v += out[i];
     out[i] = v;
+}
+
+// slab[z] = [n_w main | n_b tail]: out_w[i] = sum_z main, out_b[i] = sum_z tail
+__global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* __restrict__ slab, int nslab, int64_t stride,
+                                                            float* __restrict__ out_w, int64_t n_w,
+                                                            float* __restrict__ out_b, int64_t n_b) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_w + n_b) return;
+    double s = 0.0;
+    for (int z = 0; z < nslab; ++z) s += (double)slab[(size_t)z * stride + i];
+    if (i < n_w) out_w[i] = (float)s;
+    else out_b[i - n_w] = (float)s;
+}
+
+int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
+                         float* out_b, int64_t n_b) {
+    const int64_t n = n_w + n_b;
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab, stride, out_w,
+                       n_w, out_b, n_b);
+    return 0;
 }
 
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,

@@ -4,9 +4,12 @@
 // The recurrence is a serial chain of S steps (600 at T=3000), each a [1,128]x[128,384] product per batch
 // row: latency-bound, not bandwidth- or MFMA-bound.  Design: ONE workgroup (512 threads) per
 // (batch row, direction); the recurrent kernel U lives in registers for the whole sequence (96 fp32 per
-// thread), h is exchanged through a double-buffered 512-byte LDS vector with one barrier per step, the
-// next step's global operands are issued before the current step's FMAs.  Batch rows are independent, so
-// B x 2 workgroups run concurrently (64 of the 256 CUs at B = 32) with no inter-workgroup traffic.
+// thread), h is exchanged through a double-buffered 512-byte LDS vector with ONE barrier per step.
+// Global operands never sit on the step's critical path: they are staged per chunk of steps
+// (issue the next chunk's float4 loads at the start of a chunk, commit them to LDS at its end), because
+// gfx950's in-order vmcnt would otherwise make every step wait for the newest prefetch.
+// Batch rows are independent, so B x 2 workgroups run concurrently (64 of the 256 CUs at B = 32) with
+// no inter-workgroup traffic.
 //
 // thread (j = tid>>2, q = tid&3): unit j, quarter q of the reduction axis; the 4 partial sums of a unit sit
 // in 4 adjacent lanes and are combined with two cross-lane adds.
@@ -18,11 +21,17 @@
 
 #define GRU_U 128
 #define GRU_G 384
+#define GRUF_CH 16   // forward: steps per staged chunk
+#define GRUB_CH 8    // backward
+#define GRUB_ROW 896 // floats staged per backward step: dout | h_other | z r hh gh | h_prev
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// branch-free activations: v_exp_f32 / v_rcp_f32 based, abs error ~1e-7 (parity bar 1e-4)
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// sum over the 4 lanes of a quad with DPP quad_perm moves (VALU; no LDS round trip like ds_bpermute)
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
     return v;
 }
 
@@ -39,6 +48,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     float* sv = dir ? sv_b : sv_f;
     if (sv) sv += (size_t)b * S * 4 * GRU_U;
     const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    __shared__ __attribute__((aligned(16))) float gxl[2][GRUF_CH * GRU_G];
     // padded h vector: index k lives at k + 4*(k>>5) so the 4 quarters start in different bank groups
     __shared__ __attribute__((aligned(16))) float hl[2][144];
     float u[3][32];
@@ -49,43 +59,75 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const float bz = brec[j], br = brec[GRU_U + j], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
-    __syncthreads();
-    int t = dir ? S - 1 : 0;
-    const int dt = dir ? -1 : 1;
-    float gxz = gx[(size_t)t * GRU_G + j], gxr = gx[(size_t)t * GRU_G + GRU_U + j], gxh = gx[(size_t)t * GRU_G + 2 * GRU_U + j];
-    for (int step = 0; step < S; ++step, t += dt) {
-        // prefetch next step's input projections
-        float nz = 0.f, nr = 0.f, nh = 0.f;
-        if (step + 1 < S) {
-            const float* gn = gx + (size_t)(t + dt) * GRU_G;
-            nz = gn[j]; nr = gn[GRU_U + j]; nh = gn[2 * GRU_U + j];
-        }
-        const float* hp = &hl[step & 1][36 * q];
-        float az = 0.f, ar = 0.f, ah = 0.f;
+    const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
+    float4 stg[3];
+    // chunk c = processing steps [c*CH, c*CH+n); its rows are contiguous in memory from row tlo
+    auto chunk_rows = [&](int c, int& n, int& tlo) {
+        const int s0 = c * GRUF_CH;
+        n = min(GRUF_CH, S - s0);
+        tlo = dir ? S - s0 - n : s0;
+    };
+    auto issue = [&](int c) {
+        int n, tlo;
+        chunk_rows(c, n, tlo);
+        const float4* src = reinterpret_cast<const float4*>(gx + (size_t)tlo * GRU_G);
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * k4);
-            az = fmaf(hv.x, u[0][4 * k4 + 0], az); ar = fmaf(hv.x, u[1][4 * k4 + 0], ar); ah = fmaf(hv.x, u[2][4 * k4 + 0], ah);
-            az = fmaf(hv.y, u[0][4 * k4 + 1], az); ar = fmaf(hv.y, u[1][4 * k4 + 1], ar); ah = fmaf(hv.y, u[2][4 * k4 + 1], ah);
-            az = fmaf(hv.z, u[0][4 * k4 + 2], az); ar = fmaf(hv.z, u[1][4 * k4 + 2], ar); ah = fmaf(hv.z, u[2][4 * k4 + 2], ah);
-            az = fmaf(hv.w, u[0][4 * k4 + 3], az); ar = fmaf(hv.w, u[1][4 * k4 + 3], ar); ah = fmaf(hv.w, u[2][4 * k4 + 3], ah);
+        for (int uu = 0; uu < 3; ++uu) {
+            const int idx = tid + 512 * uu;
+            stg[uu] = (idx < n * (GRU_G / 4)) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        az = quad_sum(az); ar = quad_sum(ar); ah = quad_sum(ah);
-        const float z = sigmoidf_(gxz + az + bz);
-        const float r = sigmoidf_(gxr + ar + br);
-        const float ghh = ah + bh;
-        const float hh = tanhf(gxh + r * ghh);
-        const float hn = z * h_own + (1.f - z) * hh;
-        h_own = hn;
-        if (q == 0) {
-            hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
-            H[(size_t)t * GRU_U + j] = hn;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) reinterpret_cast<float4*>(gxl[buf])[tid + 512 * uu] = stg[uu];
+    };
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int step = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        int n, tlo;
+        chunk_rows(c, n, tlo);
+        const bool has_next = c + 1 < nchunks;
+        if (has_next) issue(c + 1);
+        const float* gb = gxl[c & 1];
+        auto do_step = [&](int i) {
+            const int row = dir ? n - 1 - i : i;
+            const int t = tlo + row;
+            const float gxz = gb[row * GRU_G + j], gxr = gb[row * GRU_G + GRU_U + j], gxh = gb[row * GRU_G + 2 * GRU_U + j];
+            const float* hp = &hl[step & 1][36 * q];
+            float az = 0.f, ar = 0.f, ah = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * k4);
+                az = fmaf(hv.x, u[0][4 * k4 + 0], az); ar = fmaf(hv.x, u[1][4 * k4 + 0], ar); ah = fmaf(hv.x, u[2][4 * k4 + 0], ah);
+                az = fmaf(hv.y, u[0][4 * k4 + 1], az); ar = fmaf(hv.y, u[1][4 * k4 + 1], ar); ah = fmaf(hv.y, u[2][4 * k4 + 1], ah);
+                az = fmaf(hv.z, u[0][4 * k4 + 2], az); ar = fmaf(hv.z, u[1][4 * k4 + 2], ar); ah = fmaf(hv.z, u[2][4 * k4 + 2], ah);
+                az = fmaf(hv.w, u[0][4 * k4 + 3], az); ar = fmaf(hv.w, u[1][4 * k4 + 3], ar); ah = fmaf(hv.w, u[2][4 * k4 + 3], ah);
+            }
+            az = quad_sum(az); ar = quad_sum(ar); ah = quad_sum(ah);
+            const float z = sigmoid_(gxz + az + bz);
+            const float r = sigmoid_(gxr + ar + br);
+            const float ghh = ah + bh;
+            const float hh = tanh_(gxh + r * ghh);
+            const float hn = z * h_own + (1.f - z) * hh;
+            h_own = hn;
+            if (q == 0) {
+                hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
+                H[(size_t)t * GRU_U + j] = hn;
+            }
+            if (sv) {
+                const float val = q == 0 ? z : (q == 1 ? r : (q == 2 ? hh : ghh));
+                sv[((size_t)t * 4 + q) * GRU_U + j] = val;
+            }
+            ++step;
+        };
+        for (int i = 0; i < n - 1; ++i) {
+            do_step(i);
+            __syncthreads();
         }
-        if (sv) {
-            const float val = q == 0 ? z : (q == 1 ? r : (q == 2 ? hh : ghh));
-            sv[((size_t)t * 4 + q) * GRU_U + j] = val;
-        }
-        gxz = nz; gxr = nr; gxh = nh;
+        do_step(n - 1);
+        if (has_next) commit((c + 1) & 1);  // the only wait on the staged loads: one chunk after their issue
         __syncthreads();
     }
 }
@@ -120,64 +162,119 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     float* dgx = (dir ? dgx_b : dgx_f) + (size_t)b * S * GRU_G;
     float* dgh = (dir ? dgh_b : dgh_f) + (size_t)b * S * GRU_G;
     const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
-    // padded gate-gradient vector: index c lives at c + 4*(c/96)
-    __shared__ __attribute__((aligned(16))) float gl[2][400];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* stage = smem;                          // [2][GRUB_CH][GRUB_ROW]
+    float* gl = smem + 2 * GRUB_CH * GRUB_ROW;    // [2][400] padded gate-gradient vector: c -> c + 4*(c/96)
     float ut[96];
 #pragma unroll
     for (int cc = 0; cc < 96; ++cc) ut[cc] = U[(size_t)j * GRU_G + 96 * q + cc];
-    // forward processed t = 0..S-1 (dir 0) or S-1..0 (dir 1); BPTT walks it backwards
-    int t = dir ? 0 : S - 1;
-    const int dt = dir ? 1 : -1;        // BPTT direction
-    float carry = 0.f;
-    // operands of the current step
-    float c_do = dO[(size_t)t * GRU_U + j] * Hoth[(size_t)t * GRU_U + j];
-    float c_z = sv[((size_t)t * 4 + 0) * GRU_U + j], c_r = sv[((size_t)t * 4 + 1) * GRU_U + j];
-    float c_hh = sv[((size_t)t * 4 + 2) * GRU_U + j], c_gh = sv[((size_t)t * 4 + 3) * GRU_U + j];
-    float c_hp = (S > 1) ? Hown[(size_t)(t + dt) * GRU_U + j] : 0.f;  // h_prev = output of the step processed before t
-    for (int step = 0; step < S; ++step, t += dt) {
-        const bool last = (step + 1 == S);
-        const float hp = last ? 0.f : c_hp;
-        float n_do = 0.f, n_z = 0.f, n_r = 0.f, n_hh = 0.f, n_gh = 0.f, n_hp = 0.f;
-        if (!last) {
-            const int tn = t + dt;
-            n_do = dO[(size_t)tn * GRU_U + j] * Hoth[(size_t)tn * GRU_U + j];
-            n_z = sv[((size_t)tn * 4 + 0) * GRU_U + j]; n_r = sv[((size_t)tn * 4 + 1) * GRU_U + j];
-            n_hh = sv[((size_t)tn * 4 + 2) * GRU_U + j]; n_gh = sv[((size_t)tn * 4 + 3) * GRU_U + j];
-            if (step + 2 < S) n_hp = Hown[(size_t)(tn + dt) * GRU_U + j];
-        }
-        const float dh = c_do + carry;
-        const float dhh = dh * (1.f - c_z);
-        const float dzg = dh * (hp - c_hh);
-        const float a_h = dhh * (1.f - c_hh * c_hh);
-        const float a_z = dzg * c_z * (1.f - c_z);
-        const float a_r = a_h * c_gh * c_r * (1.f - c_r);
-        const float a_hr = a_h * c_r;
-        float* gw = gl[step & 1];
-        // padded positions: c + 4*(c/96)
-        if (q == 0) { const int c = j; gw[c + 4 * (c / 96)] = a_z; dgx[(size_t)t * GRU_G + c] = a_z; dgh[(size_t)t * GRU_G + c] = a_z; }
-        if (q == 1) { const int c = GRU_U + j; gw[c + 4 * (c / 96)] = a_r; dgx[(size_t)t * GRU_G + c] = a_r; dgh[(size_t)t * GRU_G + c] = a_r; }
-        if (q == 2) { const int c = 2 * GRU_U + j; gw[c + 4 * (c / 96)] = a_hr; dgx[(size_t)t * GRU_G + c] = a_h; dgh[(size_t)t * GRU_G + c] = a_hr; }
-        __syncthreads();
-        const float* gp = gw + 100 * q;
-        float s0 = 0.f, s1 = 0.f;
+    // the forward pass consumed t = 0..S-1 (dir 0) / S-1..0 (dir 1); BPTT walks that order backwards:
+    // BPTT step s is time t = S-1-s (dir 0) or s (dir 1); h_prev(t) = H[t-1] (dir 0) / H[t+1] (dir 1)
+    const int hshift = dir ? 1 : -1;
+    const int nchunks = (S + GRUB_CH - 1) / GRUB_CH;
+    float4 stg[4];
+    auto chunk_rows = [&](int c, int& n, int& tlo) {
+        const int s0 = c * GRUB_CH;
+        n = min(GRUB_CH, S - s0);
+        tlo = dir ? s0 : S - s0 - n;
+    };
+    auto issue = [&](int c) {
+        int n, tlo;
+        chunk_rows(c, n, tlo);
 #pragma unroll
-        for (int c4 = 0; c4 < 24; ++c4) {
-            const float4 gv = *reinterpret_cast<const float4*>(gp + 4 * c4);
-            s0 = fmaf(gv.x, ut[4 * c4 + 0], s0);
-            s1 = fmaf(gv.y, ut[4 * c4 + 1], s1);
-            s0 = fmaf(gv.z, ut[4 * c4 + 2], s0);
-            s1 = fmaf(gv.w, ut[4 * c4 + 3], s1);
+        for (int uu = 0; uu < 4; ++uu) {
+            const int idx = tid + 512 * uu;           // float4 slot: row = idx / 224, col4 = idx % 224
+            const int row = idx / (GRUB_ROW / 4), c4 = idx - row * (GRUB_ROW / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n) {
+                const int t = tlo + row;
+                if (c4 < 32) v = reinterpret_cast<const float4*>(dO + (size_t)t * GRU_U)[c4];
+                else if (c4 < 64) v = reinterpret_cast<const float4*>(Hoth + (size_t)t * GRU_U)[c4 - 32];
+                else if (c4 < 192) v = reinterpret_cast<const float4*>(sv + (size_t)t * 4 * GRU_U)[c4 - 64];
+                else {
+                    const int tp = t + hshift;
+                    if (tp >= 0 && tp < S) v = reinterpret_cast<const float4*>(Hown + (size_t)tp * GRU_U)[c4 - 192];
+                }
+            }
+            stg[uu] = v;
         }
-        const float sum = quad_sum(s0 + s1);
-        carry = dh * c_z + sum;
-        c_do = n_do; c_z = n_z; c_r = n_r; c_hh = n_hh; c_gh = n_gh; c_hp = n_hp;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int idx = tid + 512 * uu;
+            if (idx < GRUB_CH * (GRUB_ROW / 4)) reinterpret_cast<float4*>(stage + buf * GRUB_CH * GRUB_ROW)[idx] = stg[uu];
+        }
+    };
+    issue(0);
+    commit(0);
+    __syncthreads();
+    float carry = 0.f;
+    int step = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        int n, tlo;
+        chunk_rows(c, n, tlo);
+        const bool has_next = c + 1 < nchunks;
+        if (has_next) issue(c + 1);
+        const float* sb = stage + (c & 1) * GRUB_CH * GRUB_ROW;
+        float dh = 0.f, c_zs = 0.f;
+        float* gw = nullptr;
+        auto part1 = [&](int i) {   // gate gradients of step i -> LDS vector + global
+            const int row = dir ? i : n - 1 - i;
+            const int t = tlo + row;
+            const float* rp = sb + row * GRUB_ROW + j;
+            const float c_do = rp[0] * rp[128];
+            const float c_z = rp[256], c_r = rp[384], c_hh = rp[512], c_gh = rp[640], hp = rp[768];
+            dh = c_do + carry;
+            c_zs = c_z;
+            const float dhh = dh * (1.f - c_z);
+            const float dzg = dh * (hp - c_hh);
+            const float a_h = dhh * (1.f - c_hh * c_hh);
+            const float a_z = dzg * c_z * (1.f - c_z);
+            const float a_r = a_h * c_gh * c_r * (1.f - c_r);
+            const float a_hr = a_h * c_r;
+            gw = gl + (step & 1) * 400;
+            if (q < 3) {
+                const int cidx = q * GRU_U + j;
+                const float vx = q == 0 ? a_z : (q == 1 ? a_r : a_h);
+                const float vh = q == 0 ? a_z : (q == 1 ? a_r : a_hr);
+                gw[cidx + 4 * (cidx / 96)] = vh;
+                dgx[(size_t)t * GRU_G + cidx] = vx;
+                dgh[(size_t)t * GRU_G + cidx] = vh;
+            }
+        };
+        auto part2 = [&]() {        // carry = dh*z + dgh U^T
+            const float* gp = gw + 100 * q;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < 24; ++c4) {
+                const float4 gv = *reinterpret_cast<const float4*>(gp + 4 * c4);
+                s0 = fmaf(gv.x, ut[4 * c4 + 0], s0);
+                s1 = fmaf(gv.y, ut[4 * c4 + 1], s1);
+                s0 = fmaf(gv.z, ut[4 * c4 + 2], s0);
+                s1 = fmaf(gv.w, ut[4 * c4 + 3], s1);
+            }
+            carry = dh * c_zs + quad_sum(s0 + s1);
+            ++step;
+        };
+        for (int i = 0; i < n - 1; ++i) {
+            part1(i);
+            __syncthreads();
+            part2();
+        }
+        part1(n - 1);
+        if (has_next) commit((c + 1) & 1);  // the only wait on the staged loads
+        __syncthreads();
+        part2();
     }
 }
 
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S) {
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(512), 0, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
+    const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * 400) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);
     return 0;
 }

@@ -104,14 +104,15 @@ int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, in
     return done();
 }
 
-int seld_k_gemm_tn(const float* A, const float* Bm, float* C, int M, int K1, int N) {
+int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N) {
     if (!A || !Bm || !C) return SELD_ERR_INVALID;
     Scratch s;
-    float* slab = s.get((size_t)gemm_tn_max_splits() * K1 * N);
+    float* slab = s.get((size_t)gemm_tn_max_splits() * ((size_t)K1 * N + N));
     if (!slab) return SELD_ERR_NOMEM;
     int ns = 0;
-    if (launch_gemm_tn(0, A, K1, Bm, N, slab, &ns, M, K1, N, 0, 0)) return SELD_ERR_INVALID;
-    launch_reduce_slabs(0, slab, ns, (int64_t)K1 * N, C, (int64_t)K1 * N, 0);
+    if (launch_gemm_tn(0, A, K1, Bm, N, slab, &ns, M, K1, N, 0, 0, colsum ? 1 : 0)) return SELD_ERR_INVALID;
+    if (colsum) launch_reduce_slabs2(0, slab, ns, (int64_t)K1 * N + N, C, (int64_t)K1 * N, colsum, N);
+    else launch_reduce_slabs(0, slab, ns, (int64_t)K1 * N + N, C, (int64_t)K1 * N, 0);
     return done();
 }
 

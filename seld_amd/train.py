@@ -7,7 +7,7 @@ from typing import Sequence
 
 import torch
 
-from . import _lib, losses
+from . import _lib, losses, parallel
 from .models import SeldNet
 
 
@@ -52,20 +52,19 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     ys, yd = _labels(model, y, B)
     sed, doa = model._outputs(B)
     sloss, dloss = _loss_outputs(model, doa_loss, B)
-    dist = torch.distributed
-    world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-    sed_scale, den = 1.0, 0.0
-    if world > 1 and isinstance(doa_loss, losses._MMSE):
+    world = parallel.world_size(process_group)
+    is_mmse = isinstance(doa_loss, losses._MMSE)
+    dent = None
+    if world > 1 and is_mmse:
         # scalar objective: BCE is a mean over the GLOBAL batch, MMSE divides by the GLOBAL sum(mask)
         dent = torch.empty(1, dtype=torch.float32, device=model._dev)
         _lib.check(model.lib.seld_mmse_den(model.ctx, yd.data_ptr(), dent.data_ptr()), model.ctx)
-        dist.all_reduce(dent, group=process_group)
-        sed_scale, den = 1.0 / world, float(dent.item())
+    sed_scale, den = parallel.loss_scaling(is_mmse, dent, process_group)
     cfg = _cfg(doa_loss, loss_weight, sed_scale, den)
     _lib.check(model.lib.seld_train_fwd_bwd(model.ctx, x.data_ptr(), ys.data_ptr(), yd.data_ptr(), C.byref(cfg),
                                             sed.data_ptr(), doa.data_ptr(), sloss.data_ptr(), dloss.data_ptr()), model.ctx)
     if world > 1:
-        dist.all_reduce(model.grad_tensor(), group=process_group)
+        parallel.allreduce_gradients(model.grad_tensor(), process_group)
     _lib.check(model.lib.seld_adam_step(model.ctx, optimizer.learning_rate, optimizer.beta_1, optimizer.beta_2,
                                         optimizer.epsilon, int(bool(agc))), model.ctx)
     return [sed, doa], sloss, dloss

@@ -131,9 +131,14 @@ def test_gemm_tn(seld_lib, M, K1, N):
     A = rng.standard_normal((M, K1)).astype(np.float32)
     Bm = rng.standard_normal((M, N)).astype(np.float32)
     Cd = torch.full((K1, N), float("nan"), device="cuda")
+    cs = torch.full((N,), float("nan"), device="cuda")
     Ad, Bd = dev(A), dev(Bm)
-    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), M, K1, N) == 0
+    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), ptr(cs), M, K1, N) == 0
     check(f"gemm_tn {M,K1,N}", Cd.cpu().numpy(), A.astype(np.float64).T @ Bm.astype(np.float64))
+    check(f"gemm_tn colsum {M,K1,N}", cs.cpu().numpy(), Bm.astype(np.float64).sum(0))
+    Cd.fill_(float("nan"))
+    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), None, M, K1, N) == 0
+    check(f"gemm_tn (no colsum) {M,K1,N}", Cd.cpu().numpy(), A.astype(np.float64).T @ Bm.astype(np.float64))
 
 
 def _gru_ref(gx, U, brec, reverse):

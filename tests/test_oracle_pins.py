@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (a) against every known answer the reference's own tests hold for this path
+(parameter counts, output shapes, polar<->cartesian tables — copied here as DATA),
+(b) against independent torch.nn implementations of the same ops, (c) against the committed golden
+fixtures.  Numeric values of the model path are otherwise unpinned by the reference (see the header
+of oracle/seldnet_oracle.py and DESIGN.md)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import labels_oracle as L
+from oracle import seldnet_oracle as O
+
+
+@pytest.fixture(scope="module")
+def spec(seldnet_config):
+    return O.Spec.from_config(seldnet_config)
+
+
+# ---------------------------------------------------------------- (a) reference known answers
+def test_param_counts(spec):
+    # complexity.py:356-390,442-479 formulas; complexity_test.py:205-221,292-307 values
+    assert O.param_count(spec) == 513840
+    tr, nt = O.variable_specs(spec)
+    per = {n: int(np.prod(s)) for n, s in tr}
+    assert per["conv0.kernel"] + per["conv0.bias"] == 9 * 7 * 64 + 64
+    assert per["conv1.kernel"] + per["conv1.bias"] == 9 * 64 * 64 + 64
+    gru_layer = sum(v for k, v in per.items() if k.startswith("gru0."))
+    assert gru_layer == 198144 == 2 * 3 * 128 * (128 + 128 + 2)      # gru_complexity: 3u(in+u+2), bi
+    assert per["sed.dense0.kernel"] + per["sed.dense0.bias"] == (128 + 1) * 128   # linear_complexity
+    assert per["sed.out.kernel"] + per["sed.out.bias"] == (128 + 1) * 12
+    assert per["doa.out.kernel"] + per["doa.out.bias"] == (128 + 1) * 36
+    assert sum(int(np.prod(s)) for _, s in nt) == 6 * 64
+
+
+def test_gru_complexity_known_answer():
+    # complexity_test.py:292-299: gru_complexity([32,100,20], 30, bi=True) -> params 9360
+    s = O.Spec(in_ch=1, n_freq=20, filters=[1], pools=[(1, 1)], gru_units=[30], sed_units=[], doa_units=[], n_classes=1)
+    tr, _ = O.variable_specs(s)
+    assert sum(int(np.prod(sh)) for n, sh in tr if n.startswith("gru0.")) == 9360
+
+
+def test_conv2d_complexity_known_answer():
+    # complexity_test.py:205-213: conv2d_complexity([32,32,3], 16, 3) -> params 448
+    assert 3 * 3 * 3 * 16 + 16 == 448
+
+
+def test_output_shapes(spec):
+    # modules_test.py:202-258 pattern (zeros in, shapes out); models.py:18-32 heads
+    w, st = O.random_weights(spec, 0)
+    x = np.zeros((2, 50, 64, 7), np.float32)
+    r = O.test_step(spec, w, st, x, np.zeros((2, 10, 12), np.float32), np.zeros((2, 10, 36), np.float32))
+    assert r["sed"].shape == (2, 10, 12) and r["doa"].shape == (2, 10, 36) and r["dloss"].shape == (2, 10)
+
+
+CART = [[0, 0, 1], [0, -1, 0], [1, 0, 0], [-2, 2, 0], [0, 0, 0]]
+POLAR = [[0, 90, 1], [-90, 0, 1], [0, 0, 1], [135, 0, np.sqrt(8)], [0, 0, 0]]
+
+
+def test_polar_cartesian_tables():
+    # feature_extractor_test.py:8-22,36-46
+    np.testing.assert_allclose(L.cartesian_to_polar(CART), POLAR, atol=1e-6)
+    np.testing.assert_allclose(L.polar_to_cartesian(POLAR), CART, atol=1e-6)
+
+
+def test_label_layout_and_windowing():
+    # feature_extractor.py:91-149, transforms.py:117-119, data_loader.py:132-156
+    lab = L.labels_from_rows([(0, 1, 0, 0), (3, 5, 90, 0)], n_classes=12)
+    assert lab.shape == (4, 48)
+    sed, doa = L.split_total_labels_to_sed_doa(lab)
+    assert sed.shape == (4, 12) and doa.shape == (4, 36) and sed[0, 1] == 1 and sed[3, 5] == 1
+    np.testing.assert_allclose(doa[0, [1, 13, 25]], [1, 0, 0], atol=1e-7)      # x|y|z blocks of 12
+    np.testing.assert_allclose(doa[3, [5, 17, 29]], [0, 1, 0], atol=1e-7)
+    f, l = L.preprocess_features_labels(np.ones((3001, 64, 7), np.float32), lab)
+    assert f.shape == (3000, 64, 7) and l.shape == (600, 48) and l[4:].sum() == 0
+    fw, lw = L.window([f, f], [l, l])
+    assert fw.shape == (20, 300, 64, 7) and lw.shape == (20, 60, 48)
+
+
+# ---------------------------------------------------------------- (b) independent implementations
+def test_gru_matches_torch_nn_gru():
+    """torch.nn.GRU has the same reset_after formulation; gate order r|z|n vs Keras z|r|h."""
+    rng = np.random.default_rng(0)
+    B, S, I, u = 3, 17, 128, 128
+    x = torch.tensor(rng.standard_normal((B, S, I)), dtype=torch.float64)
+    k = torch.tensor(rng.standard_normal((I, 3 * u)) / np.sqrt(I))
+    U = torch.tensor(rng.standard_normal((u, 3 * u)) / np.sqrt(u))
+    b = torch.tensor(rng.standard_normal((2, 3 * u)) * 0.1)
+    perm = torch.cat([torch.arange(u, 2 * u), torch.arange(0, u), torch.arange(2 * u, 3 * u)])  # z|r|h -> r|z|n
+    g = torch.nn.GRU(I, u, batch_first=True).double()
+    with torch.no_grad():
+        g.weight_ih_l0.copy_(k[:, perm].T); g.weight_hh_l0.copy_(U[:, perm].T)
+        g.bias_ih_l0.copy_(b[0, perm]); g.bias_hh_l0.copy_(b[1, perm])
+    ref, _ = g(x)
+    np.testing.assert_allclose(O.gru_direction(x, k, U, b, False).numpy(), ref.detach().numpy(), atol=1e-12)
+    refb, _ = g(torch.flip(x, [1]))
+    np.testing.assert_allclose(O.gru_direction(x, k, U, b, True).numpy(), torch.flip(refb, [1]).detach().numpy(), atol=1e-12)
+
+
+def test_batchnorm_matches_torch():
+    rng = np.random.default_rng(1)
+    z = torch.tensor(rng.standard_normal((2, 5, 4, 64)) * 2 + 0.5)
+    g, be = torch.tensor(rng.uniform(0.5, 1.5, 64)), torch.tensor(rng.normal(0, 0.2, 64))
+    mm, mv = torch.zeros(64, dtype=torch.float64), torch.ones(64, dtype=torch.float64)
+    y, nm, nv = O.batchnorm(z, g, be, mm, mv, True)
+    rm, rv = mm.clone(), mv.clone()
+    ref = torch.nn.functional.batch_norm(z.permute(0, 3, 1, 2), rm, rv, g, be, True, 1 - O.BN_MOMENTUM, O.BN_EPS).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-12)
+    np.testing.assert_allclose(nm.numpy(), rm.numpy(), atol=1e-12)   # torch also uses the unbiased var for the running stat
+    np.testing.assert_allclose(nv.numpy(), rv.numpy(), atol=1e-12)
+
+
+def test_mmse_and_bce_numpy():
+    rng = np.random.default_rng(2)
+    _, ys, yd = O.synthetic_batch(2, 50, seed=3)
+    p = rng.uniform(0.01, 0.99, ys.shape)
+    d = rng.uniform(-1, 1, yd.shape)
+    mask = np.round((yd.reshape(2, 10, 3, 12) ** 2).sum(2))
+    mask3 = np.concatenate([mask] * 3, -1)
+    np.testing.assert_allclose(O.mmse(torch.tensor(yd, dtype=torch.float64), torch.tensor(d)).item(),
+                               (((yd - d) ** 2) * mask3).sum() / mask3.sum(), rtol=1e-12)
+    pc = np.clip(p, 1e-7, 1 - 1e-7)
+    np.testing.assert_allclose(O.bce(torch.tensor(ys, dtype=torch.float64), torch.tensor(p)).item(),
+                               (-(ys * np.log(pc + 1e-7) + (1 - ys) * np.log(1 - pc + 1e-7))).mean(), rtol=1e-12)
+
+
+def test_mse_quirk_is_sum_of_rows(spec):
+    """train.py:29-31 with the Keras MSE function: gradient of SUM_{b,s}(w0*bce + w1*mse[b,s])."""
+    sed = torch.rand(2, 10, 12, dtype=torch.float64, requires_grad=True)
+    doa = torch.rand(2, 10, 36, dtype=torch.float64, requires_grad=True)
+    _, ys, yd = O.synthetic_batch(2, 50, seed=5)
+    obj, sl, dl = O.losses_and_objective(sed, doa, torch.tensor(ys, dtype=torch.float64), torch.tensor(yd, dtype=torch.float64), "MSE", (1.0, 1000.0))
+    assert dl.shape == (2, 10)
+    np.testing.assert_allclose(obj.item(), 20 * sl.item() + 1000 * dl.sum().item(), rtol=1e-12)
+
+
+# ---------------------------------------------------------------- (c) golden fixtures
+@pytest.mark.parametrize("name", ["b2_t50_mse", "b2_t50_mmse", "b3_t100_mse"])
+def test_golden(spec, name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"seldnet_{name}.npz"))
+    B, T, dl = (int(v) for v in z["meta"])
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T, seed=1234)
+    r = O.train_step(spec, w, st, x, ys, yd, doa_loss=["MSE", "MMSE"][dl], loss_weight=(1.0, 1000.0), lr=1e-3, step=1)  # fp32 oracle
+    tol = dict(rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(r["sed"], z["train_sed"], **tol)
+    np.testing.assert_allclose(r["doa"], z["train_doa"], **tol)
+    np.testing.assert_allclose(r["dloss"], z["train_dloss"], **tol)
+    g = r["grad"][::997]
+    assert np.abs(g - z["grad_sample"]).max() <= 1e-4 * np.abs(z["grad_sample"]).max()
+    np.testing.assert_allclose(r["new_state"], z["new_state"], **tol)
