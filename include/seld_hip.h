@@ -130,6 +130,12 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
 int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int H, int W, int Cin, int Cout);
 /* kernel+bias gradient of the same conv: dw HWIO, db [Cout] */
 int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int B, int H, int W, int Cin, int Cout);
+/* first conv block backward in one fused pass: given the forward's pre-BN z [B,H,64,64], the batch mean/invstd and
+ * the gradient dp w.r.t. the pooled output, returns d(conv kernel) HWIO, d(conv bias), dgamma, dbeta.  Equals
+ * seld_k_bn_relu_pool_bwd followed by seld_k_conv3x3_wgrad without materialising dz. */
+int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, float* dw, float* db, float* dgamma, float* dbeta,
+                           int B, int H, int Cin, int pt, int pf);
 /* BatchNormalization(training) + ReLU + MaxPooling2D(pt,pf) given scale/shift per channel:
  * p = maxpool(relu(z*scale+shift)) (layers.py:33-35 + simple_conv_block) */
 int seld_k_bn_relu_pool_fwd(const float* z, const float* scale, const float* shift, float* p,

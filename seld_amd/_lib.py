@@ -83,6 +83,7 @@ SIGNATURES = {
     "seld_k_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_conv3x3_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "seld_k_conv1_bwd_fused": (_I, [_P] * 11 + [_I] * 5),
     "seld_k_bn_relu_pool_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "seld_k_bn_relu_pool_bwd": (_I, [_P] * 9 + [_I] * 6),
     "seld_k_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),

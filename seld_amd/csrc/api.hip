@@ -508,22 +508,26 @@ static int backward_impl(seld_ctx* c, const float* x) {
         snprintf(tn, sizeof tn, "pool%d_bwd_reduce", i + 1);
         {
             PROF(c, tn);
-            if (launch_bn_pool_bwd_reduce(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
+            if (launch_bn_pool_bwd_reduce(st, L.z, L.p, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
                                           L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
         }
         launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
-        snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
-        {
+        int ns = 0;
+        const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
+        if (!fused_first) {
+            snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
             PROF(c, tn);
             launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
         }
-        int ns = 0;
         if (i == 0) {
             {
                 PROF(c, "conv1_wgrad");
-                if (launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin))
-                    return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
+                // fused: dz = BN/ReLU/pool backward formed inside the wgrad kernel (L.mean.. are contiguous: 6 x 64)
+                const int rc = fused_first
+                    ? launch_conv_first_wgrad_fused(st, x, L.z, L.p, dp, L.mean, c->wgrad_slab, &ns, B, L.H, L.Cin, L.pt, L.pf)
+                    : launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin);
+                if (rc) return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
             }
             // slab rows 0..62 = kernel [9*7][64], row 63 = bias: contiguous with the flat layout
             launch_reduce_slabs(st, c->wgrad_slab, ns, 4096, c->grads + L.w_off, 4096, 0);

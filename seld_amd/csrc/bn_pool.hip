@@ -126,8 +126,13 @@ int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, 
 
 // ------------------------------------------------------------------------------------------------
 // backward pass 1: per-channel sums over the batch of dy and dy*xhat.
+// dy is non-zero only at the argmax of a pooling window whose pooled value is > 0, and there
+// y = p = z*scale + shift, so xhat = ((p - shift)/scale - mean)*invstd is recovered from the POOLED
+// tensors alone (2 x 79 MB instead of the 1.57 GB of Z for layer 1).  Channels with scale == 0
+// (gamma == 0: y is constant, xhat not recoverable from p) fall back to scanning the window of Z.
 // Thread (slot = tid>>4, g = tid&15) walks pooled pixels slot, slot+16*gridDim, ...
-__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dp,
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ p,
+                                                                 const float* __restrict__ dp,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ scale,
@@ -137,37 +142,36 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
     const int Wp = W / PF, Hp = H / PT;
-    const float4 sc = reinterpret_cast<const float4*>(scale)[g];
-    const float4 sh = reinterpret_cast<const float4*>(shift)[g];
-    const float4 mu = reinterpret_cast<const float4*>(mean)[g];
-    const float4 is = reinterpret_cast<const float4*>(invstd)[g];
+    const float4 sc4 = reinterpret_cast<const float4*>(scale)[g];
+    const float4 sh4 = reinterpret_cast<const float4*>(shift)[g];
+    const float4 mu4 = reinterpret_cast<const float4*>(mean)[g];
+    const float4 is4 = reinterpret_cast<const float4*>(invstd)[g];
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    const bool degenerate = (sc[0] == 0.f) | (sc[1] == 0.f) | (sc[2] == 0.f) | (sc[3] == 0.f);
     float sdy[4] = {0.f, 0.f, 0.f, 0.f}, sdx[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t pp = (int64_t)blockIdx.x * 16 + slot; pp < npool; pp += (int64_t)gridDim.x * 16) {
-        const int fp = (int)(pp % Wp);
-        const int tp = (int)((pp / Wp) % Hp);
-        const int b = (int)(pp / ((int64_t)Wp * Hp));
-        float ym[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        float zm[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < PT; ++i) {
-            const float* row = z + (((size_t)b * H + (size_t)tp * PT + i) * W + (size_t)fp * PF) * 64 + g * 4;
-            for (int j = 0; j < PF; ++j) {
-                const float4 zv = *reinterpret_cast<const float4*>(row + (size_t)j * 64);
-                const float4 y = fma4(zv, sc, sh);
-                if (y.x > ym[0]) { ym[0] = y.x; zm[0] = zv.x; }
-                if (y.y > ym[1]) { ym[1] = y.y; zm[1] = zv.y; }
-                if (y.z > ym[2]) { ym[2] = y.z; zm[2] = zv.z; }
-                if (y.w > ym[3]) { ym[3] = y.w; zm[3] = zv.w; }
-            }
+        const float4 pv4 = reinterpret_cast<const float4*>(p)[pp * 16 + g];
+        const float4 d4 = reinterpret_cast<const float4*>(dp)[pp * 16 + g];
+        const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        float zsel[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zsel[c] = (pv[c] - sh[c]) / sc[c];
+        if (degenerate) {
+            const int fp = (int)(pp % Wp);
+            const int tp = (int)((pp / Wp) % Hp);
+            const int b = (int)(pp / ((int64_t)Wp * Hp));
+            // first window element (the argmax of a constant window)
+            const float4 z0 = *reinterpret_cast<const float4*>(z + (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + g * 4);
+            const float zf[4] = {z0.x, z0.y, z0.z, z0.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (sc[c] == 0.f) zsel[c] = zf[c];
         }
-        const float4 d = reinterpret_cast<const float4*>(dp)[pp * 16 + g];
-        const float dv[4] = {d.x, d.y, d.z, d.w};
-        const float muv[4] = {mu.x, mu.y, mu.z, mu.w};
-        const float isv[4] = {is.x, is.y, is.z, is.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float dy = ym[c] > 0.f ? dv[c] : 0.f;
+            const float dy = pv[c] > 0.f ? dv[c] : 0.f;
             sdy[c] += dy;
-            sdx[c] += dy * (zm[c] - muv[c]) * isv[c];
+            sdx[c] += dy * (zsel[c] - mu[c]) * is[c];
         }
     }
 #pragma unroll
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
     }
 }
 
-int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* dp, const float* mean,
+int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, const float* dp, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* partial,
                               int* npartial, int B, int H, int W, int C, int pt, int pf) {
     if (C != 64 || H % pt || W % pf) return -2;
     const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
     int64_t blocks = (npool + 15) / 16;
     if (blocks > BN_MAX_PARTIAL) blocks = BN_MAX_PARTIAL;
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, dp, mean, invstd, scale,
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, p, dp, mean, invstd, scale,
                        shift, partial, npool, H, W, pt, pf);
     *npartial = (int)blocks;
     return 0;

@@ -19,6 +19,11 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (it is a
+// workgroup-scope fence for global memory), which would serialise the prefetched global loads and the
+// epilogue stores of the pipelined conv kernels behind every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define SELD_BN_EPS 1e-3f
 #define SELD_BN_MOMENTUM 0.99f
 
@@ -32,6 +37,9 @@ int launch_conv64_fwd(hipStream_t st, const float* x, const float* w9, const flo
 int conv_stat_partial_capacity();  // max blocks writing stat partials
 int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
                             int B, int H, int Cin);
+// fused BN/ReLU/pool backward + first-layer wgrad; coef = [mean|invstd|scale|shift|c1|c2] x 64 (contiguous)
+int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
+                                  const float* coef, float* slab, int* n_slab, int B, int H, int Cin, int pt, int pf);
 int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
                         int B, int H, int W);
 int conv_wgrad_slab_capacity();
@@ -46,7 +54,7 @@ int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta,
                           const float* mov_var, float* scale, float* shift, int C);
 int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, const float* shift, float* p,
                             int B, int H, int W, int C, int pt, int pf);
-int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* dp, const float* mean,
+int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, const float* dp, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* partial,
                               int* npartial, int B, int H, int W, int C, int pt, int pf);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,

@@ -27,28 +27,57 @@ struct FirstGeom {
     static constexpr int PATCH = 6 * ROWF;
 };
 
-// patch[r][c][ci] for image rows t0-1..t0+4, cols -1..64 (zeros outside the image)
+// The halo patch of a 4x64-pixel tile: patch[r][c][ci] for image rows t0-1..t0+4, cols -1..64.
+// Global side: each image row is 64*CIN contiguous floats -> float4 loads (PatchStage::NV per row).
+// LDS side: data lands at column 1 (offset CIN floats, not 16-B aligned) -> b32 writes; the halo
+// columns 0 and 65 are zeroed once per kernel and never overwritten.
 template <int CIN>
-__device__ __forceinline__ void stage_patch(float* patch, const float* __restrict__ x, int b, int t0, int H, int tid) {
-    constexpr int ROWF = FirstGeom<CIN>::ROWF;
-    for (int idx = tid; idx < 6 * ROWF; idx += 256) {
-        const int r = idx / ROWF, rem = idx - r * ROWF;
-        const int c = rem / CIN, ci = rem - c * CIN;
-        const int t = t0 - 1 + r;
-        float v = 0.f;
-        if (t >= 0 && t < H && c >= 1 && c <= 64) v = x[((size_t)(b * H + t) * 64 + (c - 1)) * CIN + ci];
-        patch[idx] = v;
+struct PatchStage {
+    static constexpr int NV = 64 * CIN / 4;        // float4 per image row
+    static constexpr int SLOTS = 6 * NV;           // float4 per patch
+    static constexpr int PER_THREAD = (SLOTS + 255) / 256;
+    float4 v[PER_THREAD];
+    __device__ __forceinline__ void issue(const float* __restrict__ x, int b, int t0, int H, int tid) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int idx = tid + 256 * u;
+            const int r = idx / NV, c4 = idx - r * NV;
+            const int t = t0 - 1 + r;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < SLOTS && t >= 0 && t < H)
+                v[u] = reinterpret_cast<const float4*>(x + (size_t)(b * H + t) * 64 * CIN)[c4];
+        }
     }
+    __device__ __forceinline__ void commit(float* patch, int tid) const {
+        constexpr int ROWF = 66 * CIN;
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < SLOTS) {
+                const int r = idx / NV, c4 = idx - r * NV;
+                float* d = patch + r * ROWF + CIN + 4 * c4;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+    }
+};
+
+template <int CIN>
+__device__ __forceinline__ void zero_patch(float* patch, int tid) {
+    for (int idx = tid; idx < FirstGeom<CIN>::PATCH; idx += 256) patch[idx] = 0.f;
 }
 
+// Pipeline per tile: [issue next tile's patch loads -> registers] [MFMA over the current LDS patch]
+// [epilogue: z stores, BN partial sums in registers] [commit the prefetched patch to the other LDS
+// buffer] [one LDS-only barrier].
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ z,
                                                              float* __restrict__ stat_partial, int B, int H) {
     using G = FirstGeom<CIN>;
-    constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
+    constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF, NS = KPAD / 2;
     __shared__ __attribute__((aligned(16))) float Wl[KPAD * 64];
-    __shared__ __attribute__((aligned(16))) float patch[G::PATCH];
+    __shared__ __attribute__((aligned(16))) float patch[2][G::PATCH];
     __shared__ float red[4 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
@@ -56,45 +85,68 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
         const int k = idx >> 6, co = idx & 63;
         Wl[idx] = (k < K) ? w[idx] : (k == K ? (bias ? bias[co] : 0.f) : 0.f);
     }
+    zero_patch<CIN>(patch[0], tid);
+    zero_patch<CIN>(patch[1], tid);
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
-    float run = 0.f;  // tid<64: sum z of channel tid; 64<=tid<128: sum z^2 of channel tid-64
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    PatchStage<CIN> stg;
+    int tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) {
         const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
-        __syncthreads();  // previous tile's patch reads / red reads are done
-        stage_patch<CIN>(patch, x, b, t0, H, tid);
-        __syncthreads();
+        stg.issue(x, b, t0, H, tid);
+        stg.commit(patch[0], tid);
+    }
+    __syncthreads();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};  // running BN sums of this lane's 2 channels
+    const int base0 = (wave * 66 + li) * CIN;      // pixel (row = wave, f = li) at tap (0,0)
+    const int base1 = base0 + 32 * CIN;
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
+        const int nxt = tile + gridDim.x;
+        const bool has_next = nxt < ntiles;
+        if (has_next) {
+            const int nb = nxt / tiles_per_img;
+            stg.issue(x, nb, (nxt - nb * tiles_per_img) * 4, H, tid);
+        }
+        const float* pt = patch[cur];
         f32x16 acc[2][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[p][c] = zero16();
-        const int base0 = (wave * 66 + li) * CIN;  // pixel (row = wave, f = li) at tap (0,0)
-        const int base1 = base0 + 32 * CIN;
-#pragma unroll
-        for (int s = 0; s < KPAD / 2; ++s) {
+        // operands of step s: k = 2s + hi
+        auto ld = [&](int s, float& a0, float& a1, float& b0, float& b1) {
             const int k = 2 * s + hi;
             const int kh = k / (3 * CIN);
             const int off = kh * ROWF + (k - kh * 3 * CIN);
-            float a0, a1;
-            if (2 * s + 1 < K) {  // both lanes' k are real im2col columns (compile-time per s)
-                a0 = patch[base0 + off];
-                a1 = patch[base1 + off];
-            } else {
+            if (2 * s + 1 < K) {
+                a0 = pt[base0 + off];
+                a1 = pt[base1 + off];
+            } else {  // last step(s): the bias row (A = 1) and zero padding
+                const bool real = k < K;
                 const float one = (k == K) ? 1.f : 0.f;
-                a0 = (k < K) ? patch[base0 + (k < K ? off : 0)] : one;
-                a1 = (k < K) ? patch[base1 + (k < K ? off : 0)] : one;
+                a0 = real ? pt[base0 + (real ? off : 0)] : one;
+                a1 = real ? pt[base1 + (real ? off : 0)] : one;
             }
-            const float b0 = Wl[k * 64 + li], b1 = Wl[k * 64 + 32 + li];
+            b0 = Wl[k * 64 + li];
+            b1 = Wl[k * 64 + 32 + li];
+        };
+        float a0, a1, b0, b1;
+        ld(0, a0, a1, b0, b1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (s + 1 < NS) ld(s + 1, na0, na1, nb0, nb1);
             acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
             acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
             acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
             acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         const int t = t0 + wave;
-        const bool row_ok = t < H;
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-        if (row_ok) {
+        if (t < H) {
             float* zr = z + (size_t)(b * H + t) * 64 * 64;
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -105,26 +157,28 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
                         const float v = acc[p][c][r];
                         zr[(p * 32 + mfma_row(r, hi)) * 64 + c * 32 + li] = v;
                         s1[c] += v;
-                        s2[c] += v * v;
+                        s2[c] = fmaf(v, v, s2[c]);
                     }
         }
-        if (stat_partial) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                s1[c] += __shfl_xor(s1[c], 32);
-                s2[c] += __shfl_xor(s2[c], 32);
-            }
-            if (hi == 0) {
-                red[wave * 128 + li] = s1[0];
-                red[wave * 128 + 32 + li] = s1[1];
-                red[wave * 128 + 64 + li] = s2[0];
-                red[wave * 128 + 96 + li] = s2[1];
-            }
-            __syncthreads();
-            if (tid < 128) run += red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
-        }
+        if (has_next) stg.commit(patch[cur ^ 1], tid);
+        lds_barrier();
+        cur ^= 1;
     }
-    if (stat_partial && tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = run;
+    if (stat_partial) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (hi == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    }
 }
 
 int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* z,
@@ -144,6 +198,8 @@ int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const 
 // ================================================================================================
 #define C64_LDA 129  // A tile [ci][px], +1 pad
 
+// Pipeline per tap: [issue tap+1's A tile and weights -> registers] [MFMA over tap's LDS tiles]
+// [LDS barrier] [commit registers] [LDS barrier].  BN partial sums stay in registers across tiles.
 template <bool STATS>
 __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                          const float* __restrict__ bias, float* __restrict__ z,
@@ -154,9 +210,10 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
     const int ntiles = (npix + 127) >> 7;
-    float run = 0.f;
     const int g4 = (tid & 15) * 4;   // channel group of this thread's staging loads
     const int pxs = tid >> 4;        // staging pixel slot (0..15), pixels pxs + 16u
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float4 ar[8], wr[4];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int p0 = tile << 7;
         // validity mask of the 9 taps for this thread's 8 staging pixels
@@ -175,29 +232,37 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
             }
             vmask[u] = m;
         }
-        f32x16 acc[2] = {zero16(), zero16()};
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dt = tap / 3 - 1, df = tap % 3 - 1;
-            const int shift = dt * W + df;
-            __syncthreads();  // previous tap's MFMA reads done
+        auto issue = [&](int tap) {
+            const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((vmask[u] >> tap) & 1u)
+                    ar[u] = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pxs + 16 * u + shift) * 64 + g4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wr[u] = reinterpret_cast<const float4*>(w9 + (size_t)tap * 4096)[tid + 256 * u];
+        };
+        auto commit = [&]() {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int px = pxs + 16 * u;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((vmask[u] >> tap) & 1u)
-                    v = *reinterpret_cast<const float4*>(x + (size_t)(p0 + px + shift) * 64 + g4);
-                As[(g4 + 0) * C64_LDA + px] = v.x;
-                As[(g4 + 1) * C64_LDA + px] = v.y;
-                As[(g4 + 2) * C64_LDA + px] = v.z;
-                As[(g4 + 3) * C64_LDA + px] = v.w;
+                As[(g4 + 0) * C64_LDA + px] = ar[u].x;
+                As[(g4 + 1) * C64_LDA + px] = ar[u].y;
+                As[(g4 + 2) * C64_LDA + px] = ar[u].z;
+                As[(g4 + 3) * C64_LDA + px] = ar[u].w;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = tid + 256 * u;
-                reinterpret_cast<float4*>(Wt)[idx] = reinterpret_cast<const float4*>(w9 + (size_t)tap * 4096)[idx];
-            }
-            __syncthreads();
+            for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(Wt)[tid + 256 * u] = wr[u];
+        };
+        issue(0);
+        lds_barrier();   // previous tile's readers are done
+        commit();
+        lds_barrier();
+        f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) issue(tap + 1);
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const int k = 2 * s + hi;
@@ -206,8 +271,12 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
                 acc[0] = MFMA_F32_32x32x2(a, b0, acc[0]);
                 acc[1] = MFMA_F32_32x32x2(a, b1, acc[1]);
             }
+            if (tap < 8) {
+                lds_barrier();
+                commit();
+                lds_barrier();
+            }
         }
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float bv = bias ? bias[c * 32 + li] : 0.f;
@@ -218,28 +287,26 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
                     const float v = acc[c][r] + bv;
                     z[(size_t)p * 64 + c * 32 + li] = v;
                     s1[c] += v;
-                    s2[c] += v * v;
+                    s2[c] = fmaf(v, v, s2[c]);
                 }
             }
         }
-        if (STATS) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                s1[c] += __shfl_xor(s1[c], 32);
-                s2[c] += __shfl_xor(s2[c], 32);
-            }
-            __syncthreads();  // red from the previous tile consumed
-            if (hi == 0) {
-                red[wave * 128 + li] = s1[0];
-                red[wave * 128 + 32 + li] = s1[1];
-                red[wave * 128 + 64 + li] = s2[0];
-                red[wave * 128 + 96 + li] = s2[1];
-            }
-            __syncthreads();
-            if (tid < 128) run += red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
-        }
     }
-    if (STATS && tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = run;
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (hi == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    }
 }
 
 int launch_conv64_fwd(hipStream_t st, const float* x, const float* w9, const float* bias, float* z,
@@ -271,6 +338,8 @@ int launch_flip_weights(hipStream_t st, const float* w, float* wt) {
 // ================================================================================================
 // first layer kernel/bias gradient
 // ================================================================================================
+// Pipeline per tile: [issue next tile's patch + dz loads -> registers] [MFMA over the current LDS tile]
+// [barrier] [commit registers to LDS] [barrier].
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                float* __restrict__ slab, int B, int H) {
@@ -287,35 +356,212 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
     const int kh = k / (3 * CIN);
     const int koff = (k < K) ? kh * ROWF + (k - kh * 3 * CIN) : 0;
     const float kone = (k == K) ? 1.f : 0.f;
+    const bool kreal = k < K;
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
-    f32x16 acc = zero16();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
-        __syncthreads();
-        stage_patch<CIN>(patch, x, b, t0, H, tid);
-        // dz tile: 4 rows x 64 px x 64 co, contiguous in memory when all rows are inside the image
+    PatchStage<CIN> stg;
+    float4 dzr[16];
+    auto issue_dz = [&](int b, int t0) {
+        const float4* src = reinterpret_cast<const float4*>(dz + (size_t)(b * H + t0) * 4096);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int idx = tid + 256 * u;       // float4 index, 4096 per tile
-            const int row = idx >> 10;           // 1024 float4 per image row
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + row < H) v = reinterpret_cast<const float4*>(dz + (size_t)(b * H + t0) * 4096)[idx];
-            reinterpret_cast<float4*>(dzl)[idx] = v;
+            const int idx = tid + 256 * u;   // float4 index; 1024 per image row
+            dzr[u] = (t0 + (idx >> 10) < H) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int s = 0; s < 128; ++s) {
+    };
+    auto commit_dz = [&]() {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) reinterpret_cast<float4*>(dzl)[tid + 256 * u] = dzr[u];
+    };
+    zero_patch<CIN>(patch, tid);
+    int tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
+        stg.issue(x, b, t0, H, tid);
+        issue_dz(b, t0);
+        stg.commit(patch, tid);
+        commit_dz();
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        const bool has_next = nxt < ntiles;
+        if (has_next) {
+            const int nb = nxt / tiles_per_img, nt0 = (nxt - nb * tiles_per_img) * 4;
+            stg.issue(x, nb, nt0, H, tid);
+            issue_dz(nb, nt0);
+        }
+        auto ld = [&](int s, float& a, float& bb) {
             const int px = 2 * s + hi;
             const int row = px >> 6, f = px & 63;
-            const float a = (k < K) ? patch[(row * 66 + f) * CIN + koff] : kone;
-            const float bb = dzl[px * 64 + ct * 32 + li];
+            a = kreal ? patch[(row * 66 + f) * CIN + koff] : kone;
+            bb = dzl[px * 64 + ct * 32 + li];
+        };
+        float a, bb;
+        ld(0, a, bb);
+#pragma unroll 8
+        for (int s = 0; s < 128; ++s) {
+            float na = 0.f, nb = 0.f;
+            if (s + 1 < 128) ld(s + 1, na, nb);
             acc = MFMA_F32_32x32x2(a, bb, acc);
+            a = na; bb = nb;
         }
+        lds_barrier();          // every wave is done reading this tile
+        if (has_next) {
+            stg.commit(patch, tid);
+            commit_dz();
+        }
+        lds_barrier();
     }
     float* out = slab + (size_t)blockIdx.x * 4096;
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[r];
+}
+
+// Fused first-layer backward: dz is never materialised.  The kernel reads the forward's pre-BN
+// activations z plus the pooled tensors (p, dp) and forms, while committing a tile to LDS,
+//   y = z*scale + shift;  dy = (y == p && p > 0) ? dp : 0      (maxpool + ReLU backward: y == p is exact,
+//   xhat = (z - mean)*invstd; dz = scale*(dy - c1 - xhat*c2)     the forward computed p with the same fmaf)
+// i.e. bn_pool_bwd_dz + conv_first_wgrad in one pass.  coef = [mean|invstd|scale|shift|c1|c2] x 64.
+// Each thread owns a 4-row x 4-pixel x 4-channel block of the tile, so it needs ONE pooled column
+// (PF = 4) and at most two pooled rows of p / dp.
+template <int CIN, int PT>
+__global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                                     const float* __restrict__ p, const float* __restrict__ dp,
+                                                                     const float* __restrict__ coef, float* __restrict__ slab,
+                                                                     int B, int H) {
+    using G = FirstGeom<CIN>;
+    constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
+    static_assert(KPAD == 64, "one 64x64 output (4 wave tiles) per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dzl = smem;                 // [256 px][64 co]
+    float* patch = smem + 256 * 64;    // [6][66][CIN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, li = lane & 31;
+    const int kt = wave >> 1, ct = wave & 1;
+    const int k = kt * 32 + li;
+    const int kh = k / (3 * CIN);
+    const int koff = (k < K) ? kh * ROWF + (k - kh * 3 * CIN) : 0;
+    const float kone = (k == K) ? 1.f : 0.f;
+    const bool kreal = k < K;
+    const int tiles_per_img = (H + 3) >> 2;
+    const int ntiles = B * tiles_per_img;
+    const int Hp = H / PT;
+    const int g = tid & 15, q = tid >> 4;        // channel group, pooled column of this thread's block
+    const float4 mu4 = reinterpret_cast<const float4*>(coef)[g], is4 = reinterpret_cast<const float4*>(coef + 64)[g];
+    const float4 sc4 = reinterpret_cast<const float4*>(coef + 128)[g], sh4 = reinterpret_cast<const float4*>(coef + 192)[g];
+    const float4 c14 = reinterpret_cast<const float4*>(coef + 256)[g], c24 = reinterpret_cast<const float4*>(coef + 320)[g];
+    PatchStage<CIN> stg;
+    float4 zr[16], pr[2], dpr[2];
+    int st_t0 = 0;     // t0 of the staged tile
+    auto issue_z = [&](int b, int t0) {
+        st_t0 = t0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int row = u >> 2, px = 4 * q + (u & 3);
+            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + row < H) zr[u] = *reinterpret_cast<const float4*>(z + ((size_t)(b * H + t0 + row) * 64 + px) * 64 + g * 4);
+        }
+        const int pr0 = t0 / PT;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int prow = min(pr0 + v, Hp - 1);
+            const size_t off = (((size_t)b * Hp + prow) * 16 + q) * 64 + g * 4;
+            pr[v] = *reinterpret_cast<const float4*>(p + off);
+            dpr[v] = *reinterpret_cast<const float4*>(dp + off);
+        }
+    };
+    auto commit_dz = [&]() {
+        const int pr0 = st_t0 / PT;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int row = u >> 2, px = 4 * q + (u & 3);
+            const int t = st_t0 + row;
+            const bool second = (t / PT) != pr0;
+            const float4 pv = second ? pr[1] : pr[0];
+            const float4 dv = second ? dpr[1] : dpr[0];
+            const float zz[4] = {zr[u].x, zr[u].y, zr[u].z, zr[u].w};
+            const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float c1[4] = {c14.x, c14.y, c14.z, c14.w}, c2[4] = {c24.x, c24.y, c24.z, c24.w};
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float y = fmaf(zz[c], sc[c], sh[c]);
+                const float dy = (y == pp[c] && pp[c] > 0.f) ? dd[c] : 0.f;
+                const float xh = (zz[c] - mu[c]) * is[c];
+                o[c] = (t < H) ? sc[c] * (dy - c1[c] - xh * c2[c]) : 0.f;
+            }
+            *reinterpret_cast<float4*>(dzl + (size_t)(row * 64 + px) * 64 + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    zero_patch<CIN>(patch, tid);
+    int tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
+        stg.issue(x, b, t0, H, tid);
+        issue_z(b, t0);
+        stg.commit(patch, tid);
+        commit_dz();
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        const bool has_next = nxt < ntiles;
+        if (has_next) {
+            const int nb = nxt / tiles_per_img, nt0 = (nxt - nb * tiles_per_img) * 4;
+            stg.issue(x, nb, nt0, H, tid);
+            issue_z(nb, nt0);
+        }
+        auto ld = [&](int s, float& a, float& bb) {
+            const int px = 2 * s + hi;
+            const int row = px >> 6, f = px & 63;
+            a = kreal ? patch[(row * 66 + f) * CIN + koff] : kone;
+            bb = dzl[px * 64 + ct * 32 + li];
+        };
+        float a, bb;
+        ld(0, a, bb);
+#pragma unroll 8
+        for (int s = 0; s < 128; ++s) {
+            float na = 0.f, nb = 0.f;
+            if (s + 1 < 128) ld(s + 1, na, nb);
+            acc = MFMA_F32_32x32x2(a, bb, acc);
+            a = na; bb = nb;
+        }
+        lds_barrier();
+        if (has_next) {
+            stg.commit(patch, tid);
+            commit_dz();
+        }
+        lds_barrier();
+    }
+    float* out = slab + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[r];
+}
+
+int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
+                                  const float* coef, float* slab, int* n_slab, int B, int H, int Cin, int pt, int pf) {
+    if (Cin != 7 || pf != 4 || H % pt) return -2;
+    const int ntiles = B * ((H + 3) / 4);
+    const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
+    const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH) * sizeof(float);
+#define LAUNCH_FUSED(PT)                                                                                          \
+    {                                                                                                             \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_fused_kernel<7, PT>),                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
+        hipLaunchKernelGGL((conv_first_wgrad_fused_kernel<7, PT>), dim3(grid), dim3(256), smem, st, x, z, p, dp,  \
+                           coef, slab, B, H);                                                                     \
+    }
+    if (pt == 5) LAUNCH_FUSED(5) else if (pt == 4) LAUNCH_FUSED(4) else if (pt == 2) LAUNCH_FUSED(2) else if (pt == 1) LAUNCH_FUSED(1) else return -2;
+#undef LAUNCH_FUSED
+    *n_slab = grid;
+    return 0;
 }
 
 int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,

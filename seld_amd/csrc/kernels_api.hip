@@ -72,6 +72,33 @@ int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, 
     return done();
 }
 
+int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, float* dw, float* db, float* dgamma, float* dbeta,
+                           int B, int H, int Cin, int pt, int pf) {
+    if (!x || !z || !dp || !mean || !invstd || !gamma || !beta || !dw || !db || !dgamma || !dbeta) return SELD_ERR_INVALID;
+    const int W = 64, C = 64;
+    if (H % pt || W % pf) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* coef = s.get(64 * 6);   // mean | invstd | scale | shift | c1 | c2
+    float* part = s.get((size_t)bn_partial_capacity() * 128);
+    float* pbuf = s.get((size_t)B * (H / pt) * (W / pf) * 64);
+    float* slab = s.get((size_t)conv_wgrad_slab_capacity() * 4096);
+    float* tmp = s.get(4096);
+    if (!coef || !part || !pbuf || !slab || !tmp) return SELD_ERR_NOMEM;
+    hipMemcpyAsync(coef, mean, 256, hipMemcpyDeviceToDevice, 0);
+    hipMemcpyAsync(coef + 64, invstd, 256, hipMemcpyDeviceToDevice, 0);
+    hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(64), 0, 0, mean, invstd, gamma, beta, coef + 128, coef + 192, C);
+    if (launch_bn_relu_pool_fwd(0, z, coef + 128, coef + 192, pbuf, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    int np = 0, ns = 0;
+    if (launch_bn_pool_bwd_reduce(0, z, pbuf, dp, coef, coef + 64, coef + 128, coef + 192, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    launch_bn_bwd_finalize(0, part, np, (double)B * H * W, dgamma, dbeta, coef + 256, C);
+    if (launch_conv_first_wgrad_fused(0, x, z, pbuf, dp, coef, slab, &ns, B, H, Cin, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    launch_reduce_slabs(0, slab, ns, 4096, tmp, 4096, 0);
+    hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
+    hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
+    return done();
+}
+
 int seld_k_bn_relu_pool_fwd(const float* z, const float* scale, const float* shift, float* p, int B, int H, int W, int C,
                             int pt, int pf) {
     if (!z || !scale || !shift || !p) return SELD_ERR_INVALID;
@@ -87,11 +114,13 @@ int seld_k_bn_relu_pool_bwd(const float* z, const float* dp, const float* mean, 
     Scratch s;
     float* coef = s.get(64 * 4);
     float* part = s.get((size_t)bn_partial_capacity() * 128);
-    if (!coef || !part) return SELD_ERR_NOMEM;
+    float* pbuf = s.get((size_t)B * (H / pt) * (W / pf) * 64);
+    if (!coef || !part || !pbuf) return SELD_ERR_NOMEM;
     float *scale = coef, *shift = coef + 64, *c1c2 = coef + 128;
     hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(64), 0, 0, mean, invstd, gamma, beta, scale, shift, C);
     int np = 0;
-    if (launch_bn_pool_bwd_reduce(0, z, dp, mean, invstd, scale, shift, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    if (launch_bn_relu_pool_fwd(0, z, scale, shift, pbuf, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    if (launch_bn_pool_bwd_reduce(0, z, pbuf, dp, mean, invstd, scale, shift, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
     launch_bn_bwd_finalize(0, part, np, (double)B * H * W, dgamma, dbeta, c1c2, C);
     launch_bn_pool_bwd_dz(0, z, dp, mean, invstd, scale, shift, c1c2, dz, B, H, W, C, pt, pf);
     return done();

@@ -74,6 +74,8 @@ def test_bn_relu_pool(seld_lib, B, H, W, pt, pf):
     z = rng.standard_normal((B, H, W, 64)).astype(np.float32)
     gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.2, -1, 1)).astype(np.float32)
     beta = rng.normal(0, 0.3, 64).astype(np.float32)
+    gamma[5], beta[5] = 0.0, 0.25    # degenerate channel: y constant > 0, argmax = first window element
+    gamma[9], beta[9] = 0.0, -0.25   # degenerate channel killed by the ReLU
     zt = torch.as_tensor(z, dtype=torch.float64, ).requires_grad_(True)
     g = torch.as_tensor(gamma, dtype=torch.float64).requires_grad_(True)
     bt = torch.as_tensor(beta, dtype=torch.float64).requires_grad_(True)
@@ -242,3 +244,42 @@ def test_adam(seld_lib):
     check("adam theta", td.cpu().numpy(), rt.numpy(), tol=1e-6)
     check("adam m", md.cpu().numpy(), rm.numpy(), tol=1e-6)
     check("adam v", vd.cpu().numpy(), rv.numpy(), tol=1e-6)
+
+
+@pytest.mark.parametrize("B,H", [(2, 50), (1, 20), (2, 15)])
+def test_conv1_bwd_fused(seld_lib, B, H):
+    """conv1 + BN(training) + ReLU + MaxPool(5,4) backward in one fused pass vs autograd (fp64)."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((B, H, 64, 7)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 7, 64)) / np.sqrt(63)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32) * 0.1
+    gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.2, -1, 1)).astype(np.float32)
+    beta = rng.normal(0, 0.3, 64).astype(np.float32)
+    # forward z on the GPU (so that y == p is evaluated on the same fp32 z the product would see)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    zd = torch.empty((B, H, 64, 64), device="cuda")
+    assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(zd), None, B, H, 64, 7, 64) == 0
+    z = zd.cpu().numpy()
+    # reference: autograd through conv -> BN(batch stats) -> relu -> pool in fp64, from the same fp32 inputs
+    tw = torch.as_tensor(w, dtype=torch.float64).requires_grad_(True)
+    tb = torch.as_tensor(b, dtype=torch.float64).requires_grad_(True)
+    tg = torch.as_tensor(gamma, dtype=torch.float64).requires_grad_(True)
+    tbe = torch.as_tensor(beta, dtype=torch.float64).requires_grad_(True)
+    zt = F.conv2d(torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), tw.permute(3, 2, 0, 1), tb, padding=1).permute(0, 2, 3, 1)
+    mean = zt.mean(dim=(0, 1, 2))
+    var = ((zt - mean) ** 2).mean(dim=(0, 1, 2))
+    invstd = torch.rsqrt(var + 1e-3)
+    y = (zt - mean) * invstd * tg + tbe
+    p = F.max_pool2d(torch.relu(y).permute(0, 3, 1, 2), (5, 4), (5, 4)).permute(0, 2, 3, 1)
+    dp = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+    gw, gb, gg, gbe = torch.autograd.grad(p, (tw, tb, tg, tbe), torch.as_tensor(dp, dtype=torch.float64))
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dw, db, dg, dbe = nan(3, 3, 7, 64), nan(64), nan(64), nan(64)
+    md, isd = dev(mean.detach().numpy()), dev(invstd.detach().numpy())
+    gd, bed, dpd = dev(gamma), dev(beta), dev(dp)
+    assert seld_lib.seld_k_conv1_bwd_fused(ptr(xd), ptr(zd), ptr(dpd), ptr(md), ptr(isd), ptr(gd), ptr(bed), ptr(dw), ptr(db),
+                                           ptr(dg), ptr(dbe), B, H, 7, 5, 4) == 0
+    check(f"conv1_bwd_fused dw {B,H}", dw.cpu().numpy(), gw.numpy())
+    check(f"conv1_bwd_fused dgamma {B,H}", dg.cpu().numpy(), gg.numpy())
+    check(f"conv1_bwd_fused dbeta {B,H}", dbe.cpu().numpy(), gbe.numpy())
+    assert np.abs(db.cpu().numpy()).max() <= 1e-3 * np.abs(gw.numpy()).max()   # exact-arithmetic zero (bias before BN)
