@@ -113,6 +113,24 @@ int seld_test_step(seld_ctx* ctx, const float* x, const float* y_sed, const floa
 /* sum(mask) of losses.MMSE for this batch (1 float, device) — for the DP denominator all-reduce */
 int seld_mmse_den(seld_ctx* ctx, const float* y_doa, float* den);
 
+/* ---- feature stage: replaces feature_extractor.extract_features (feature_extractor.py:53-88) and, for the
+ * in-loop variant, apply_normalizer + preprocess_features_labels (:117-149, :226-234).
+ * complex_spec (:153-173) = torchaudio spectrogram(hann(win_length) periodic, n_fft, hop, power=None, center, reflect);
+ * mode 0 'foa': 4 log-mel (top_db 80 over the clip) + 3 mel intensity vectors; mode 1 'mic': 4 log-mel + 6 GCC-PHAT.
+ * wav [4][n_samples] fp32 (device) -> out [1 + n_samples/hop][n_mels][7|10] fp32 (device), the reference's
+ * [time, freq, chan] layout.  `stream` is a hipStream_t (NULL = null stream). */
+typedef struct seld_feat seld_feat;
+int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length, int n_mels, int mode, int normalized,
+                     int device, seld_feat** out);
+void seld_feat_destroy(seld_feat* f);
+const char* seld_feat_last_error(const seld_feat* f);
+int64_t seld_feat_frames(const seld_feat* f, int64_t n_samples);
+int seld_feat_channels(const seld_feat* f);
+int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_samples, float* out, void* stream);
+/* (x - mean)/max(std, eps) per (freq, chan), rows trimmed / zero-padded (before normalising, as the reference does) to T_out */
+int seld_feat_normalize(const float* feat, const float* mean, const float* stdv, float* out, int64_t T_in, int64_t T_out,
+                        int FC, float eps, void* stream);
+
 /* ---- measurement: HIP-event timing of named kernels on the ctx stream (bench.py roofline) */
 int seld_profile_enable(seld_ctx* ctx, int on);
 int seld_profile_count(const seld_ctx* ctx);

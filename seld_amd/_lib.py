@@ -76,6 +76,13 @@ SIGNATURES = {
     "seld_train_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _F, _I, _P, _P, _P, _P]),
     "seld_test_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
     "seld_mmse_den": (_I, [_P, _P, _P]),
+    "seld_feat_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "seld_feat_destroy": (None, [_P]),
+    "seld_feat_last_error": (C.c_char_p, [_P]),
+    "seld_feat_frames": (_L, [_P, _L]),
+    "seld_feat_channels": (_I, [_P]),
+    "seld_feat_extract": (_I, [_P, _P, _I, _L, _P, _P]),
+    "seld_feat_normalize": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
     "seld_profile_enable": (_I, [_P, _I]),
     "seld_profile_count": (_I, [_P]),
     "seld_profile_get": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(C.c_double)]),

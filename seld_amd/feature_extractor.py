@@ -1,0 +1,86 @@
+"""Host-side mirror of the reference's feature_extractor.py for the on-device feature stage.
+
+`extract_features(wav, sample_rate, mode, n_mels, **kwargs)` keeps the reference's signature and
+return type (feature_extractor.py:53-57: np.ndarray [time, freq, chan]); the arithmetic runs in
+libseld_hip.so (features.hip).  `extract_features_device` returns the device tensor instead, and
+`FeatureExtractor` keeps the plan (window, twiddles, sparse mel filterbank) for repeated calls —
+the in-loop variant BASELINE.json's config 5 asks for.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_MODES = {"foa": 0, "mic": 1}
+
+
+class FeatureExtractor:
+    def __init__(self, sample_rate: int, mode: str = "foa", n_mels: int = 64, pad: int = 0, n_fft: int = 512,
+                 win_length=None, hop_length=None, normalized: bool = False, device: int | None = None):
+        if mode not in _MODES:
+            raise ValueError("invalid mode")           # feature_extractor.py:81-82
+        if pad != 0:
+            raise ValueError("pad != 0 has no kernel (the reference never passes it)")
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SeldLibraryError("no HIP device visible: seld_amd has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        win_length = n_fft if win_length is None else win_length
+        hop_length = win_length // 2 if hop_length is None else hop_length
+        h = C.c_void_p()
+        rc = self.lib.seld_feat_create(int(sample_rate), int(n_fft), int(win_length), int(hop_length), int(n_mels),
+                                       _MODES[mode], int(bool(normalized)), self.device, C.byref(h))
+        if rc:
+            raise ValueError(f"{_lib.ERR_NAMES.get(rc, rc)}: {self.lib.seld_feat_last_error(None).decode()}")
+        self.h = h
+        self.n_mels, self.hop = n_mels, hop_length
+        self.channels = int(self.lib.seld_feat_channels(h))
+        self._dev = torch.device("cuda", self.device)
+
+    def __call__(self, wav) -> torch.Tensor:
+        """wav [4, n] (torch / numpy) -> device tensor [1 + n//hop, n_mels, 7|10]"""
+        w = torch.as_tensor(np.asarray(wav) if not isinstance(wav, torch.Tensor) else wav)
+        w = w.to(self._dev, torch.float32).contiguous()
+        if w.dim() != 2:
+            raise ValueError("wav must be [channels, samples]")
+        T = int(self.lib.seld_feat_frames(self.h, w.shape[1]))
+        out = torch.empty((T, self.n_mels, self.channels), dtype=torch.float32, device=self._dev)
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        rc = self.lib.seld_feat_extract(self.h, w.data_ptr(), int(w.shape[0]), int(w.shape[1]), out.data_ptr(), st)
+        if rc:
+            raise _lib.SeldError(rc, self.lib.seld_feat_last_error(self.h).decode())
+        return out
+
+    def normalize(self, feat: torch.Tensor, mean, std, n_frames: int = 3000, eps: float = 1e-8) -> torch.Tensor:
+        """preprocess_features_labels (pad/trim to n_frames, :117-149) + apply_normalizer (:226-234)."""
+        FC = feat.shape[1] * feat.shape[2]
+        m = torch.as_tensor(np.asarray(mean, np.float32).reshape(-1)).to(self._dev)
+        s = torch.as_tensor(np.asarray(std, np.float32).reshape(-1)).to(self._dev)
+        if m.numel() != FC or s.numel() != FC:
+            raise ValueError("mean/std must have freq*chan elements")
+        out = torch.empty((n_frames, feat.shape[1], feat.shape[2]), dtype=torch.float32, device=self._dev)
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        _lib.check(self.lib.seld_feat_normalize(feat.data_ptr(), m.data_ptr(), s.data_ptr(), out.data_ptr(), int(feat.shape[0]),
+                                                int(n_frames), int(FC), float(eps), st))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.seld_feat_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def extract_features_device(wav, sample_rate, mode="foa", n_mels=64, **kwargs) -> torch.Tensor:
+    return FeatureExtractor(sample_rate, mode, n_mels, **kwargs)(wav)
+
+
+def extract_features(wav, sample_rate, mode="foa", n_mels=64, **kwargs) -> np.ndarray:
+    """reference feature_extractor.extract_features (feature_extractor.py:53-88)."""
+    return extract_features_device(wav, sample_rate, mode, n_mels, **kwargs).cpu().numpy()

@@ -1,0 +1,67 @@
+"""Feature-stage parity: HIP extract_features (through the C ABI) vs the CPU oracle (fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check
+
+pytestmark = pytest.mark.gpu
+
+
+def _wav(n, seed=0, scale=0.1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 24000.0
+    base = rng.standard_normal((4, n)) * scale
+    base[0] += 0.3 * np.sin(2 * np.pi * 440 * t)          # a tone on the omni channel
+    base[1] += 0.2 * np.sin(2 * np.pi * 440 * t + 0.4)
+    return base.astype(np.float32)
+
+
+@pytest.mark.parametrize("mode,sr,kw", [
+    ("foa", 24000, dict(win_length=960, hop_length=480, n_fft=1024)),     # feature_extractor.py:294-301
+    ("mic", 24000, dict(win_length=960, hop_length=480, n_fft=1024)),
+    ("foa", 16000, dict()),                                               # function defaults: n_fft 512, hop 256
+    ("mic", 16000, dict(n_fft=256)),
+])
+def test_extract_features(seld_lib, mode, sr, kw):
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    wav = _wav(sr * 2 + 123, seed=3)
+    ref = FO.extract_features(wav, sr, mode=mode, dtype=torch.float64, **kw)
+    got = FE.extract_features(wav, sr, mode=mode, **kw)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    check(f"{mode} log-mel [{sr}]", got[..., :4], ref[..., :4])
+    # IV / GCC channels are ratios of spectra: fp32 FFT rounding dominates where a bin is near-silent
+    check(f"{mode} spatial channels [{sr}]", got[..., 4:], ref[..., 4:], tol=5e-4)
+
+
+def test_zeros_like_reference_smoke(seld_lib):
+    """feature_extractor_test.py:24-34: zeros[4,32000] @16 kHz -> ndim 3, 7 | 10 channels."""
+    from seld_amd import feature_extractor as FE
+    wav = np.zeros((4, 32000), np.float32)
+    foa = FE.extract_features(wav, 16000, mode="foa")
+    assert foa.ndim == 3 and foa.shape == (126, 64, 7)
+    # zeros -> power 0 -> 10*log10(amin = 1e-10) = -100 dB (top_db clamp inactive); IV = 0
+    np.testing.assert_allclose(foa[..., :4], -100.0, atol=1e-4)
+    assert np.all(foa[..., 4:] == 0.0)
+    mic = FE.extract_features(wav, 16000, mode="mic")
+    assert mic.shape == (126, 64, 10)
+
+
+def test_full_clip_and_normalize(seld_lib):
+    """A full 60 s FOA clip [4, 1 440 000] -> [3001,64,7] -> pad/trim + normalise -> [3000,64,7]."""
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    wav = _wav(1440000, seed=5, scale=0.05)
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    fx = FE.FeatureExtractor(24000, "foa", 64, **kw)
+    dev = fx(wav)
+    assert tuple(dev.shape) == (3001, 64, 7)
+    ref = FO.extract_features(wav, 24000, "foa", dtype=torch.float32, **kw)   # fp32 oracle: seconds, not minutes
+    check("full clip log-mel", dev.cpu().numpy()[..., :4], ref[..., :4])
+    check("full clip IV", dev.cpu().numpy()[..., 4:], ref[..., 4:], tol=5e-4)
+    mean, std = FO.calculate_statistics([ref[:3000]])
+    out = fx.normalize(dev, mean, std, 3000)
+    check("normalised", out.cpu().numpy(), FO.apply_normalizer(ref[:3000], mean, std), tol=5e-4)
+    with pytest.raises(ValueError):
+        FE.FeatureExtractor(24000, "stereo")
