@@ -232,37 +232,38 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
             }
             vmask[u] = m;
         }
-        auto issue = [&](int tap) {
-            const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ar[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((vmask[u] >> tap) & 1u)
-                    ar[u] = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pxs + 16 * u + shift) * 64 + g4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) wr[u] = reinterpret_cast<const float4*>(w9 + (size_t)tap * 4096)[tid + 256 * u];
-        };
-        auto commit = [&]() {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int px = pxs + 16 * u;
-                As[(g4 + 0) * C64_LDA + px] = ar[u].x;
-                As[(g4 + 1) * C64_LDA + px] = ar[u].y;
-                As[(g4 + 2) * C64_LDA + px] = ar[u].z;
-                As[(g4 + 3) * C64_LDA + px] = ar[u].w;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(Wt)[tid + 256 * u] = wr[u];
-        };
-        issue(0);
+        // (macros, not lambdas: arrays captured by a lambda were demoted to scratch memory)
+#define C64_ISSUE(tap_)                                                                                         \
+    {                                                                                                           \
+        const int tp_ = (tap_);                                                                                 \
+        const int shift_ = (tp_ / 3 - 1) * W + (tp_ % 3 - 1);                                                   \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                         \
+            const bool ok_ = (vmask[u] >> tp_) & 1u;                                                            \
+            const float4 v_ = *reinterpret_cast<const float4*>(x + (size_t)(ok_ ? p0 + pxs + 16 * u + shift_ : 0) * 64 + g4); \
+            ar[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                           \
+            wr[u] = reinterpret_cast<const float4*>(w9 + (size_t)tp_ * 4096)[tid + 256 * u];                    \
+    }
+#define C64_COMMIT()                                                                       \
+    {                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                    \
+            const int px_ = pxs + 16 * u;                                                  \
+            As[(g4 + 0) * C64_LDA + px_] = ar[u].x;                                        \
+            As[(g4 + 1) * C64_LDA + px_] = ar[u].y;                                        \
+            As[(g4 + 2) * C64_LDA + px_] = ar[u].z;                                        \
+            As[(g4 + 3) * C64_LDA + px_] = ar[u].w;                                        \
+        }                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(Wt)[tid + 256 * u] = wr[u]; \
+    }
+        C64_ISSUE(0)
         lds_barrier();   // previous tile's readers are done
-        commit();
+        C64_COMMIT()
         lds_barrier();
         f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) issue(tap + 1);
+            C64_ISSUE(tap < 8 ? tap + 1 : 8)   // unconditional (tap 8 re-reads itself): no phi on the staged registers
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const int k = 2 * s + hi;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
             }
             if (tap < 8) {
                 lds_barrier();
-                commit();
+                C64_COMMIT()
                 lds_barrier();
             }
         }

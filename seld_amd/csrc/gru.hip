@@ -60,36 +60,41 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
     const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
-    float4 stg[3];
+    // staged chunk: three float4 per thread held in NAMED registers (an array captured by a lambda was
+    // demoted to scratch memory by the compiler, which put a vmcnt wait right behind the loads)
+    float4 stg0, stg1, stg2;
     // chunk c = processing steps [c*CH, c*CH+n); its rows are contiguous in memory from row tlo
-    auto chunk_rows = [&](int c, int& n, int& tlo) {
-        const int s0 = c * GRUF_CH;
-        n = min(GRUF_CH, S - s0);
-        tlo = dir ? S - s0 - n : s0;
-    };
-    auto issue = [&](int c) {
-        int n, tlo;
-        chunk_rows(c, n, tlo);
-        const float4* src = reinterpret_cast<const float4*>(gx + (size_t)tlo * GRU_G);
-#pragma unroll
-        for (int uu = 0; uu < 3; ++uu) {
-            const int idx = tid + 512 * uu;
-            stg[uu] = (idx < n * (GRU_G / 4)) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int uu = 0; uu < 3; ++uu) reinterpret_cast<float4*>(gxl[buf])[tid + 512 * uu] = stg[uu];
-    };
-    issue(0);
-    commit(0);
+#define GRUF_CHUNK_ROWS(c, n, tlo)                     \
+    {                                                  \
+        const int s0_ = (c) * GRUF_CH;                 \
+        n = min(GRUF_CH, S - s0_);                     \
+        tlo = dir ? S - s0_ - n : s0_;                 \
+    }
+#define GRUF_ISSUE(c)                                                                              \
+    {                                                                                              \
+        int n_, tlo_;                                                                              \
+        GRUF_CHUNK_ROWS(c, n_, tlo_)                                                               \
+        const float4* src_ = reinterpret_cast<const float4*>(gx + (size_t)tlo_ * GRU_G);           \
+        const int lim_ = n_ * (GRU_G / 4);                                                         \
+        stg0 = src_[tid < lim_ ? tid : 0];               /* rows past the chunk are never read */  \
+        stg1 = src_[tid + 512 < lim_ ? tid + 512 : 0];                                             \
+        stg2 = src_[tid + 1024 < lim_ ? tid + 1024 : 0];                                           \
+    }
+#define GRUF_COMMIT(buf)                                           \
+    {                                                              \
+        float4* d_ = reinterpret_cast<float4*>(gxl[buf]);          \
+        d_[tid] = stg0; d_[tid + 512] = stg1; d_[tid + 1024] = stg2; \
+    }
+    GRUF_ISSUE(0)
+    GRUF_COMMIT(0)
     __syncthreads();
     int step = 0;
     for (int c = 0; c < nchunks; ++c) {
         int n, tlo;
-        chunk_rows(c, n, tlo);
-        const bool has_next = c + 1 < nchunks;
-        if (has_next) issue(c + 1);
+        GRUF_CHUNK_ROWS(c, n, tlo)
+        // always issue (the last chunk re-reads itself, harmlessly): a conditional issue makes the staged
+        // registers a phi of old/new values and the compiler waits for the loads right at the merge
+        GRUF_ISSUE(min(c + 1, nchunks - 1))
         const float* gb = gxl[c & 1];
         auto do_step = [&](int i) {
             const int row = dir ? n - 1 - i : i;
@@ -124,11 +129,11 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         };
         for (int i = 0; i < n - 1; ++i) {
             do_step(i);
-            __syncthreads();
+            lds_barrier();   // LDS-only: __syncthreads() would also drain vmcnt, i.e. wait for this step's global stores
         }
         do_step(n - 1);
-        if (has_next) commit((c + 1) & 1);  // the only wait on the staged loads: one chunk after their issue
-        __syncthreads();
+        GRUF_COMMIT((c + 1) & 1)  // the only wait on the staged loads: one chunk after their issue
+        lds_barrier();
     }
 }
 
@@ -178,32 +183,41 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         n = min(GRUB_CH, S - s0);
         tlo = dir ? s0 : S - s0 - n;
     };
+    // Each staging slot (tid, uu) always reads the same array: resolve (base pointer, row stride, time shift,
+    // chunk row) ONCE, so that issuing a chunk is four independent, branch-free loads (a divergent
+    // if/else chain per slot made the compiler serialise them with vmcnt(0) between the branches).
+    const float* sbase[4];
+    int sstride[4], sshift[4], srow[4];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+        const int idx = tid + 512 * uu;           // float4 slot: row = idx / 224, col4 = idx % 224
+        const int row = idx / (GRUB_ROW / 4), c4 = idx - row * (GRUB_ROW / 4);
+        srow[uu] = row;                            // rows >= GRUB_CH never pass the `row < n` test
+        sshift[uu] = 0;
+        if (c4 < 32) { sbase[uu] = dO + c4 * 4; sstride[uu] = GRU_U; }
+        else if (c4 < 64) { sbase[uu] = Hoth + (c4 - 32) * 4; sstride[uu] = GRU_U; }
+        else if (c4 < 192) { sbase[uu] = sv + (c4 - 64) * 4; sstride[uu] = 4 * GRU_U; }
+        else { sbase[uu] = Hown + (c4 - 192) * 4; sstride[uu] = GRU_U; sshift[uu] = hshift; }
+    }
+    unsigned okmask = 0;
     auto issue = [&](int c) {
         int n, tlo;
         chunk_rows(c, n, tlo);
+        okmask = 0;
 #pragma unroll
         for (int uu = 0; uu < 4; ++uu) {
-            const int idx = tid + 512 * uu;           // float4 slot: row = idx / 224, col4 = idx % 224
-            const int row = idx / (GRUB_ROW / 4), c4 = idx - row * (GRUB_ROW / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < n) {
-                const int t = tlo + row;
-                if (c4 < 32) v = reinterpret_cast<const float4*>(dO + (size_t)t * GRU_U)[c4];
-                else if (c4 < 64) v = reinterpret_cast<const float4*>(Hoth + (size_t)t * GRU_U)[c4 - 32];
-                else if (c4 < 192) v = reinterpret_cast<const float4*>(sv + (size_t)t * 4 * GRU_U)[c4 - 64];
-                else {
-                    const int tp = t + hshift;
-                    if (tp >= 0 && tp < S) v = reinterpret_cast<const float4*>(Hown + (size_t)tp * GRU_U)[c4 - 192];
-                }
-            }
-            stg[uu] = v;
+            const int tt = tlo + srow[uu] + sshift[uu];
+            const bool ok = (srow[uu] < n) && (tt >= 0) && (tt < S);
+            okmask |= (ok ? 1u : 0u) << uu;
+            stg[uu] = *reinterpret_cast<const float4*>(sbase[uu] + (size_t)(ok ? tt : 0) * sstride[uu]);   // always in bounds
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int uu = 0; uu < 4; ++uu) {
             const int idx = tid + 512 * uu;
-            if (idx < GRUB_CH * (GRUB_ROW / 4)) reinterpret_cast<float4*>(stage + buf * GRUB_CH * GRUB_ROW)[idx] = stg[uu];
+            const float4 v = ((okmask >> uu) & 1u) ? stg[uu] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < GRUB_CH * (GRUB_ROW / 4)) reinterpret_cast<float4*>(stage + buf * GRUB_CH * GRUB_ROW)[idx] = v;
         }
     };
     issue(0);
@@ -214,8 +228,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     for (int c = 0; c < nchunks; ++c) {
         int n, tlo;
         chunk_rows(c, n, tlo);
-        const bool has_next = c + 1 < nchunks;
-        if (has_next) issue(c + 1);
+        issue(min(c + 1, nchunks - 1));   // unconditional: see gru_fwd_kernel
         const float* sb = stage + (c & 1) * GRUB_CH * GRUB_ROW;
         float dh = 0.f, c_zs = 0.f;
         float* gw = nullptr;
@@ -259,12 +272,12 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         };
         for (int i = 0; i < n - 1; ++i) {
             part1(i);
-            __syncthreads();
+            lds_barrier();   // LDS-only barrier: never wait for the dgx/dgh stores
             part2();
         }
         part1(n - 1);
-        if (has_next) commit((c + 1) & 1);  // the only wait on the staged loads
-        __syncthreads();
+        commit((c + 1) & 1);  // the only wait on the staged loads
+        lds_barrier();
         part2();
     }
 }
