@@ -133,16 +133,21 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             b0 = Wl[k * 64 + li];
             b1 = Wl[k * 64 + 32 + li];
         };
+        // LDS operand pipeline, pinned with sched_barrier: the reads of step s+1 are in flight while the 4
+        // MFMAs of step s (256 pipe cycles) issue; left alone, hipcc sinks each read next to its use and
+        // waits lgkmcnt(0) in front of every MFMA group (measured: 41% MFMA-pipe utilisation).
         float a0, a1, b0, b1;
         ld(0, a0, a1, b0, b1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
             if (s + 1 < NS) ld(s + 1, na0, na1, nb0, nb1);
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
             acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
             acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
             acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         const int t = t0 + wave;
@@ -264,13 +269,30 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             C64_ISSUE(tap < 8 ? tap + 1 : 8)   // unconditional (tap 8 re-reads itself): no phi on the staged registers
+            {
+                // 2-step operand ring pinned with sched_barrier (each step = 2 MFMAs = 128 pipe cycles)
+                float qa[2], qb0[2], qb1[2];
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const int k = 2 * s + hi;
-                const float a = As[k * C64_LDA + wave * 32 + li];
-                const float b0 = Wt[k * 64 + li], b1 = Wt[k * 64 + 32 + li];
-                acc[0] = MFMA_F32_32x32x2(a, b0, acc[0]);
-                acc[1] = MFMA_F32_32x32x2(a, b1, acc[1]);
+                for (int u = 0; u < 2; ++u) {
+                    const int k = 2 * u + hi;
+                    qa[u] = As[k * C64_LDA + wave * 32 + li];
+                    qb0[u] = Wt[k * 64 + li];
+                    qb1[u] = Wt[k * 64 + 32 + li];
+                }
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    const int u = s & 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0] = MFMA_F32_32x32x2(qa[u], qb0[u], acc[0]);
+                    acc[1] = MFMA_F32_32x32x2(qa[u], qb1[u], acc[1]);
+                    if (s + 2 < 32) {
+                        const int k = 2 * (s + 2) + hi;
+                        qa[u] = As[k * C64_LDA + wave * 32 + li];
+                        qb0[u] = Wt[k * 64 + li];
+                        qb1[u] = Wt[k * 64 + 32 + li];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (tap < 8) {
                 lds_barrier();
@@ -352,12 +374,16 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
     float* patch = smem + 256 * 64;    // [6][66][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
-    const int kt = wave >> 1, ct = wave & 1;
-    const int k = kt * 32 + li;  // this lane's im2col column (A-operand row)
-    const int kh = k / (3 * CIN);
-    const int koff = (k < K) ? kh * ROWF + (k - kh * 3 * CIN) : 0;
-    const float kone = (k == K) ? 1.f : 0.f;
-    const bool kreal = k < K;
+    // wave w owns pixel row w of the tile (64 px) and all 4 output tiles (k 0-31 / 32-63) x (co 0-31 / 32-63):
+    // 4 independent accumulator chains per wave (a single dependent chain ran the MFMA pipe at ~30%)
+    int koffs[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int k = kt * 32 + li;   // this lane's im2col column (A-operand row) in k-tile kt
+        const int kh = k / (3 * CIN);
+        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH]; k > K never occurs (KPAD == K+1)
+        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : -1;
+    }
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
     PatchStage<CIN> stg;
@@ -375,6 +401,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         for (int u = 0; u < 16; ++u) reinterpret_cast<float4*>(dzl)[tid + 256 * u] = dzr[u];
     };
     zero_patch<CIN>(patch, tid);
+    if (tid == 0) patch[G::PATCH] = 1.f;   // the bias row's A operand
     int tile = blockIdx.x;
     __syncthreads();
     if (tile < ntiles) {
@@ -385,7 +412,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         commit_dz();
     }
     __syncthreads();
-    f32x16 acc = zero16();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[kt][ct] = zero16();
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
         const bool has_next = nxt < ntiles;
@@ -394,20 +425,28 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
             stg.issue(x, nb, nt0, H, tid);
             issue_dz(nb, nt0);
         }
-        auto ld = [&](int s, float& a, float& bb) {
-            const int px = 2 * s + hi;
-            const int row = px >> 6, f = px & 63;
-            a = kreal ? patch[(row * 66 + f) * CIN + koff] : kone;
-            bb = dzl[px * 64 + ct * 32 + li];
+        // per step (2 pixels): 2 A reads (k-tiles) + 2 B reads (co-tiles) feed 4 MFMAs; one-step pipeline
+        auto ld = [&](int s, float& a0, float& a1, float& b0, float& b1) {
+            const int f = 2 * s + hi;                       // pixel column in this wave's row
+            a0 = patch[koffs[0] >= 0 ? koffs[0] + f * CIN : G::PATCH];
+            a1 = patch[koffs[1] >= 0 ? koffs[1] + f * CIN : G::PATCH];
+            const float* bp = dzl + (wave * 64 + f) * 64 + li;
+            b0 = bp[0];
+            b1 = bp[32];
         };
-        float a, bb;
-        ld(0, a, bb);
+        float a0, a1, b0, b1;
+        ld(0, a0, a1, b0, b1);
 #pragma unroll 8
-        for (int s = 0; s < 128; ++s) {
-            float na = 0.f, nb = 0.f;
-            if (s + 1 < 128) ld(s + 1, na, nb);
-            acc = MFMA_F32_32x32x2(a, bb, acc);
-            a = na; bb = nb;
+        for (int s = 0; s < 32; ++s) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (s + 1 < 32) ld(s + 1, na0, na1, nb0, nb1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
+            acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
+            acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
+            acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         lds_barrier();          // every wave is done reading this tile
         if (has_next) {
@@ -416,9 +455,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         }
         lds_barrier();
     }
-    float* out = slab + (size_t)blockIdx.x * 4096;
+    // combine the 4 waves' partial [64 k][64 co] sums through LDS (dzl is free now), fixed order
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[(kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[r];
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dzl[wave * 4096 + (kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[kt][ct][r];
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * 4096;
+    for (int i = tid; i < 4096; i += 256) out[i] = (dzl[i] + dzl[4096 + i]) + (dzl[8192 + i] + dzl[12288 + i]);
 }
 
 // Fused first-layer backward: dz is never materialised.  The kernel reads the forward's pre-BN
@@ -441,12 +489,16 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     float* patch = smem + 256 * 64;    // [6][66][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
-    const int kt = wave >> 1, ct = wave & 1;
-    const int k = kt * 32 + li;
-    const int kh = k / (3 * CIN);
-    const int koff = (k < K) ? kh * ROWF + (k - kh * 3 * CIN) : 0;
-    const float kone = (k == K) ? 1.f : 0.f;
-    const bool kreal = k < K;
+    // wave w owns pixel row w of the tile (64 px) and all 4 output tiles (k 0-31 / 32-63) x (co 0-31 / 32-63):
+    // 4 independent accumulator chains per wave (a single dependent chain ran the MFMA pipe at ~30%)
+    int koffs[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int k = kt * 32 + li;   // this lane's im2col column (A-operand row) in k-tile kt
+        const int kh = k / (3 * CIN);
+        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH]; k > K never occurs (KPAD == K+1)
+        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : -1;
+    }
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
     const int Hp = H / PT;
@@ -500,6 +552,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         }
     };
     zero_patch<CIN>(patch, tid);
+    if (tid == 0) patch[G::PATCH] = 1.f;   // the bias row's A operand
     int tile = blockIdx.x;
     __syncthreads();
     if (tile < ntiles) {
@@ -510,7 +563,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         commit_dz();
     }
     __syncthreads();
-    f32x16 acc = zero16();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[kt][ct] = zero16();
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
         const bool has_next = nxt < ntiles;
@@ -519,20 +576,28 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             stg.issue(x, nb, nt0, H, tid);
             issue_z(nb, nt0);
         }
-        auto ld = [&](int s, float& a, float& bb) {
-            const int px = 2 * s + hi;
-            const int row = px >> 6, f = px & 63;
-            a = kreal ? patch[(row * 66 + f) * CIN + koff] : kone;
-            bb = dzl[px * 64 + ct * 32 + li];
+        // per step (2 pixels): 2 A reads (k-tiles) + 2 B reads (co-tiles) feed 4 MFMAs; one-step pipeline
+        auto ld = [&](int s, float& a0, float& a1, float& b0, float& b1) {
+            const int f = 2 * s + hi;                       // pixel column in this wave's row
+            a0 = patch[koffs[0] >= 0 ? koffs[0] + f * CIN : G::PATCH];
+            a1 = patch[koffs[1] >= 0 ? koffs[1] + f * CIN : G::PATCH];
+            const float* bp = dzl + (wave * 64 + f) * 64 + li;
+            b0 = bp[0];
+            b1 = bp[32];
         };
-        float a, bb;
-        ld(0, a, bb);
+        float a0, a1, b0, b1;
+        ld(0, a0, a1, b0, b1);
 #pragma unroll 8
-        for (int s = 0; s < 128; ++s) {
-            float na = 0.f, nb = 0.f;
-            if (s + 1 < 128) ld(s + 1, na, nb);
-            acc = MFMA_F32_32x32x2(a, bb, acc);
-            a = na; bb = nb;
+        for (int s = 0; s < 32; ++s) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (s + 1 < 32) ld(s + 1, na0, na1, nb0, nb1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
+            acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
+            acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
+            acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         lds_barrier();
         if (has_next) {
@@ -541,9 +606,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         }
         lds_barrier();
     }
-    float* out = slab + (size_t)blockIdx.x * 4096;
+    // combine the 4 waves' partial [64 k][64 co] sums through LDS (dzl is free now), fixed order
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[(kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[r];
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dzl[wave * 4096 + (kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[kt][ct][r];
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * 4096;
+    for (int i = tid; i < 4096; i += 256) out[i] = (dzl[i] + dzl[4096 + i]) + (dzl[8192 + i] + dzl[12288 + i]);
 }
 
 int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
@@ -551,7 +625,7 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
     if (Cin != 7 || pf != 4 || H % pt) return -2;
     const int ntiles = B * ((H + 3) / 4);
     const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
-    const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH) * sizeof(float);
+    const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH + 4) * sizeof(float);
 #define LAUNCH_FUSED(PT)                                                                                          \
     {                                                                                                             \
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_fused_kernel<7, PT>),                  \
@@ -570,7 +644,7 @@ int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, flo
     const int ntiles = B * ((H + 3) / 4);
     const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
     if (Cin == 7) {
-        const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH) * sizeof(float);
+        const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH + 4) * sizeof(float);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_kernel<7>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(conv_first_wgrad_kernel<7>, dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);
@@ -630,16 +704,32 @@ __global__ __launch_bounds__(256) void conv64_wgrad_kernel(const float* __restri
             for (int px = 0; px < 128; ++px) s += dzl[px * 64 + tid];
             brun += s;
         }
-#pragma unroll 2
-        for (int s = 0; s < 64; ++s) {
-            const int px = 2 * s + hi;
-            const int r = px >> WLOG2, c = px & (W - 1);
-            const float bb = dzl[px * 64 + coh * 32 + li];
-            const float* ap = xr + (r * RW + c) * 64 + cih * 32 + li;
+        {
+            // one-step operand pipeline pinned with sched_barrier: the 10 LDS reads of step s+1 are in
+            // flight under the 9 MFMAs (576 pipe cycles) of step s
+            float ca[9], cb;
+            auto ldw = [&](int s, float (&a9)[9], float& bb) {
+                const int px = 2 * s + hi;
+                const int r = px >> WLOG2, c = px & (W - 1);
+                bb = dzl[px * 64 + coh * 32 + li];
+                const float* ap = xr + (r * RW + c) * 64 + cih * 32 + li;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float a = ap[((tap / 3) * RW + (tap % 3)) * 64];
-                acc[tap] = MFMA_F32_32x32x2(a, bb, acc[tap]);
+                for (int tap = 0; tap < 9; ++tap) a9[tap] = ap[((tap / 3) * RW + (tap % 3)) * 64];
+            };
+            ldw(0, ca, cb);
+#pragma unroll 2
+            for (int s = 0; s < 64; ++s) {
+                float na[9], nb = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) na[tap] = 0.f;
+                if (s + 1 < 64) ldw(s + 1, na, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[tap] = MFMA_F32_32x32x2(ca[tap], cb, acc[tap]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) ca[tap] = na[tap];
+                cb = nb;
             }
         }
     }

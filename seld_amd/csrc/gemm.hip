@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const bool a_vec = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && (TRANSB ? ((K & 3) == 0) : ((N & 3) == 0)) &&
                        ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
-    f32x16 acc = zero16();
+    f32x16 acc = zero16(), acc1 = zero16();   // two independent MFMA chains (a single dependent chain idles the pipe)
     for (int k0 = 0; k0 < K; k0 += 32) {
         // ---- stage A chunk [64 rows][32 k] -> As[k][row]
 #pragma unroll
@@ -89,11 +89,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             }
         }
         __syncthreads();
+        {
+            // 4-deep LDS operand ring pinned with sched_barrier (see conv.hip)
+            float ra[4], rb[4];
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float a = As[(kk + hi) * GT_LDA + wr * 32 + li];
-            const float b = Bs[(kk + hi) * LDB + wc * 32 + li];
-            acc = MFMA_F32_32x32x2(a, b, acc);
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = As[(2 * u + hi) * GT_LDA + wr * 32 + li];
+                rb[u] = Bs[(2 * u + hi) * LDB + wc * 32 + li];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int u = s & 3;
+                __builtin_amdgcn_sched_barrier(0);
+                if (s & 1) acc1 = MFMA_F32_32x32x2(ra[u], rb[u], acc1);
+                else acc = MFMA_F32_32x32x2(ra[u], rb[u], acc);
+                if (s + 4 < 16) {
+                    ra[u] = As[(2 * (s + 4) + hi) * GT_LDA + wr * 32 + li];
+                    rb[u] = Bs[(2 * (s + 4) + hi) * LDB + wc * 32 + li];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 32 + mfma_row(r, hi);
             if (row < M) {
-                float v = acc[r] + bv;
+                float v = (acc[r] + acc1[r]) + bv;
                 if (act == 1) v = 1.f / (1.f + expf(-v));
                 else if (act == 2) v = tanhf(v);
                 float* p = C + (size_t)row * ldc + col;
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int mend = min(M, mbeg + rows_per_split);
     const bool a_vec = ((lda & 3) == 0) && ((K1 & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
-    f32x16 acc = zero16();
+    f32x16 acc = zero16(), acc1 = zero16();
     float bsum = 0.f;  // tid < 64 of the k1-tile-0 blocks: column sum of B (bias gradient)
     const bool do_bias = want_bias && blockIdx.y == 0 && tid < 64;
     for (int mm0 = mbeg; mm0 < mend; mm0 += 32) {
@@ -193,11 +208,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 32; ++r) bsum += Bs[r * 64 + tid];
         }
+        {
+            float ra[4], rb[4];
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float a = As[(kk + hi) * 64 + wr * 32 + li];
-            const float b = Bs[(kk + hi) * 64 + wc * 32 + li];
-            acc = MFMA_F32_32x32x2(a, b, acc);
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = As[(2 * u + hi) * 64 + wr * 32 + li];
+                rb[u] = Bs[(2 * u + hi) * 64 + wc * 32 + li];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int u = s & 3;
+                __builtin_amdgcn_sched_barrier(0);
+                if (s & 1) acc1 = MFMA_F32_32x32x2(ra[u], rb[u], acc1);
+                else acc = MFMA_F32_32x32x2(ra[u], rb[u], acc);
+                if (s + 4 < 16) {
+                    ra[u] = As[(2 * (s + 4) + hi) * 64 + wr * 32 + li];
+                    rb[u] = Bs[(2 * (s + 4) + hi) * 64 + wc * 32 + li];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = k10 + wr * 32 + mfma_row(r, hi);
-            if (row < K1) out[(size_t)row * N + col] = acc[r];
+            if (row < K1) out[(size_t)row * N + col] = acc[r] + acc1[r];
         }
     }
 }
