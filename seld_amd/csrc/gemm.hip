@@ -9,6 +9,9 @@
 
 #define GT_LDA 65  // transposed A tile: [k][row], +1 pad (transposing b32 writes are <=2-way conflicted)
 
+// Software pipeline per K-chunk of 32: [commit the prefetched chunk to LDS] [LDS barrier] [issue the next
+// chunk's global loads -> registers] [16 MFMAs on two accumulator chains] [LDS barrier].  Barriers are
+// LDS-only so the prefetch stays in flight across them.
 template <int TRANSB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ Bm, int ldb,
@@ -24,71 +27,73 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const bool a_vec = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && (TRANSB ? ((K & 3) == 0) : ((N & 3) == 0)) &&
                        ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
-    f32x16 acc = zero16(), acc1 = zero16();   // two independent MFMA chains (a single dependent chain idles the pipe)
+    f32x16 acc = zero16(), acc1 = zero16();   // two independent MFMA chains
+    float va[2][4], vb[2][4];                  // prefetched chunk (indices are compile-time after unrolling)
+    // A element (row = idx>>3, k4 = (idx&7)*4); B element: TRANSB ? (n = idx>>3, k4) : (kk = idx>>4, n4 = (idx&15)*4)
+#define GEMM_LOAD(k0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+        const int idx = tid + 256 * u;                                                                   \
+        {                                                                                                \
+            const int row = idx >> 3, k4 = (idx & 7) * 4;                                                \
+            const int gm = m0 + row, gk = (k0_) + k4;                                                    \
+            va[u][0] = va[u][1] = va[u][2] = va[u][3] = 0.f;                                             \
+            if (gm < M) {                                                                                \
+                const float* p = A + (size_t)gm * lda + gk;                                              \
+                if (a_vec && gk + 3 < K) {                                                               \
+                    const float4 t = *reinterpret_cast<const float4*>(p);                                \
+                    va[u][0] = t.x; va[u][1] = t.y; va[u][2] = t.z; va[u][3] = t.w;                      \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) if (gk + j < K) va[u][j] = p[j];       \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+        vb[u][0] = vb[u][1] = vb[u][2] = vb[u][3] = 0.f;                                                 \
+        if (TRANSB == 0) {                                                                               \
+            const int kk = idx >> 4, n4 = (idx & 15) * 4;                                                \
+            const int gk = (k0_) + kk, gn = n0 + n4;                                                     \
+            if (gk < K) {                                                                                \
+                const float* p = Bm + (size_t)gk * ldb + gn;                                             \
+                if (b_vec && gn + 3 < N) {                                                               \
+                    const float4 t = *reinterpret_cast<const float4*>(p);                                \
+                    vb[u][0] = t.x; vb[u][1] = t.y; vb[u][2] = t.z; vb[u][3] = t.w;                      \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) if (gn + j < N) vb[u][j] = p[j];       \
+                }                                                                                        \
+            }                                                                                            \
+        } else {                                                                                         \
+            const int n = idx >> 3, k4 = (idx & 7) * 4;                                                  \
+            const int gn = n0 + n, gk = (k0_) + k4;                                                      \
+            if (gn < N) {                                                                                \
+                const float* p = Bm + (size_t)gn * ldb + gk;                                             \
+                if (b_vec && gk + 3 < K) {                                                               \
+                    const float4 t = *reinterpret_cast<const float4*>(p);                                \
+                    vb[u][0] = t.x; vb[u][1] = t.y; vb[u][2] = t.z; vb[u][3] = t.w;                      \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) if (gk + j < K) vb[u][j] = p[j];       \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+    }
+#define GEMM_COMMIT()                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+        const int idx = tid + 256 * u;                                                                   \
+        {                                                                                                \
+            const int row = idx >> 3, k4 = (idx & 7) * 4;                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) As[(k4 + j) * GT_LDA + row] = va[u][j];        \
+        }                                                                                                \
+        if (TRANSB == 0) {                                                                               \
+            const int kk = idx >> 4, n4 = (idx & 15) * 4;                                                \
+            *reinterpret_cast<float4*>(&Bs[kk * LDB + n4]) = make_float4(vb[u][0], vb[u][1], vb[u][2], vb[u][3]); \
+        } else {                                                                                         \
+            const int n = idx >> 3, k4 = (idx & 7) * 4;                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) Bs[(k4 + j) * LDB + n] = vb[u][j];             \
+        }                                                                                                \
+    }
+    GEMM_LOAD(0)
     for (int k0 = 0; k0 < K; k0 += 32) {
-        // ---- stage A chunk [64 rows][32 k] -> As[k][row]
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 256 * u;
-            const int row = idx >> 3, k4 = (idx & 7) * 4;
-            const int gm = m0 + row, gk = k0 + k4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (gm < M) {
-                const float* p = A + (size_t)gm * lda + gk;
-                if (a_vec && gk + 3 < K) {
-                    const float4 t = *reinterpret_cast<const float4*>(p);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gk + j < K) v[j] = p[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[(k4 + j) * GT_LDA + row] = v[j];
-        }
-        // ---- stage B chunk -> Bs[k][n]
-        if (TRANSB == 0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 256 * u;
-                const int kk = idx >> 4, n4 = (idx & 15) * 4;
-                const int gk = k0 + kk, gn = n0 + n4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gk < K) {
-                    const float* p = Bm + (size_t)gk * ldb + gn;
-                    if (b_vec && gn + 3 < N) {
-                        const float4 t = *reinterpret_cast<const float4*>(p);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gn + j < N) v[j] = p[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[kk * LDB + n4 + j] = v[j];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 256 * u;
-                const int n = idx >> 3, k4 = (idx & 7) * 4;
-                const int gn = n0 + n, gk = k0 + k4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gn < N) {
-                    const float* p = Bm + (size_t)gn * ldb + gk;
-                    if (b_vec && gk + 3 < K) {
-                        const float4 t = *reinterpret_cast<const float4*>(p);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gk + j < K) v[j] = p[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(k4 + j) * LDB + n] = v[j];
-            }
-        }
-        __syncthreads();
+        GEMM_COMMIT()
+        lds_barrier();
+        if (k0 + 32 < K) GEMM_LOAD(k0 + 32)
         {
             // 4-deep LDS operand ring pinned with sched_barrier (see conv.hip)
             float ra[4], rb[4];
@@ -110,8 +115,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        lds_barrier();
     }
+#undef GEMM_LOAD
+#undef GEMM_COMMIT
     const int col = n0 + wc * 32 + li;
     if (col < N) {
         const float bv = bias ? bias[col] : 0.f;
@@ -164,46 +171,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     f32x16 acc = zero16(), acc1 = zero16();
     float bsum = 0.f;  // tid < 64 of the k1-tile-0 blocks: column sum of B (bias gradient)
     const bool do_bias = want_bias && blockIdx.y == 0 && tid < 64;
+    float va[2][4], vb[2][4];
+#define TN_LOAD(mm0_)                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+        const int idx = tid + 256 * u;                                                                   \
+        const int r = idx >> 4, c4 = (idx & 15) * 4;                                                     \
+        const int gm = (mm0_) + r;                                                                       \
+        va[u][0] = va[u][1] = va[u][2] = va[u][3] = 0.f;                                                 \
+        vb[u][0] = vb[u][1] = vb[u][2] = vb[u][3] = 0.f;                                                 \
+        if (gm < mend) {                                                                                 \
+            int am = gm;                                                                                 \
+            bool ok = true;                                                                              \
+            if (shift != 0) {   /* A row with the time shift (H_prev for the recurrent-kernel gradient) */ \
+                const int t = gm % S;                                                                    \
+                ok = (t + shift >= 0) && (t + shift < S);                                                \
+                am = gm + shift;                                                                         \
+            }                                                                                            \
+            if (ok) {                                                                                    \
+                const float* p = A + (size_t)am * lda + k10 + c4;                                        \
+                if (a_vec && k10 + c4 + 3 < K1) {                                                        \
+                    const float4 t4 = *reinterpret_cast<const float4*>(p);                               \
+                    va[u][0] = t4.x; va[u][1] = t4.y; va[u][2] = t4.z; va[u][3] = t4.w;                  \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) if (k10 + c4 + j < K1) va[u][j] = p[j]; \
+                }                                                                                        \
+            }                                                                                            \
+            const float* q = Bm + (size_t)gm * ldb + n0 + c4;                                            \
+            if (b_vec && n0 + c4 + 3 < N) {                                                              \
+                const float4 t4 = *reinterpret_cast<const float4*>(q);                                   \
+                vb[u][0] = t4.x; vb[u][1] = t4.y; vb[u][2] = t4.z; vb[u][3] = t4.w;                      \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) if (n0 + c4 + j < N) vb[u][j] = q[j];      \
+            }                                                                                            \
+        }                                                                                                \
+    }
+#define TN_COMMIT()                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+        const int idx = tid + 256 * u;                                                                   \
+        const int r = idx >> 4, c4 = (idx & 15) * 4;                                                     \
+        *reinterpret_cast<float4*>(&As[r * 64 + c4]) = make_float4(va[u][0], va[u][1], va[u][2], va[u][3]); \
+        *reinterpret_cast<float4*>(&Bs[r * 64 + c4]) = make_float4(vb[u][0], vb[u][1], vb[u][2], vb[u][3]); \
+    }
+    TN_LOAD(mbeg)
     for (int mm0 = mbeg; mm0 < mend; mm0 += 32) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 256 * u;
-            const int r = idx >> 4, c4 = (idx & 15) * 4;
-            const int gm = mm0 + r;
-            // A row with the time shift (H_prev for the recurrent-kernel gradient)
-            float va[4] = {0.f, 0.f, 0.f, 0.f};
-            float vb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (gm < mend) {
-                int am = gm;
-                bool ok = true;
-                if (shift != 0) {
-                    const int t = gm % S;
-                    ok = (t + shift >= 0) && (t + shift < S);
-                    am = gm + shift;
-                }
-                if (ok) {
-                    const float* p = A + (size_t)am * lda + k10 + c4;
-                    if (a_vec && k10 + c4 + 3 < K1) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(p);
-                        va[0] = t4.x; va[1] = t4.y; va[2] = t4.z; va[3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (k10 + c4 + j < K1) va[j] = p[j];
-                    }
-                }
-                const float* q = Bm + (size_t)gm * ldb + n0 + c4;
-                if (b_vec && n0 + c4 + 3 < N) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(q);
-                    vb[0] = t4.x; vb[1] = t4.y; vb[2] = t4.z; vb[3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n0 + c4 + j < N) vb[j] = q[j];
-                }
-            }
-            *reinterpret_cast<float4*>(&As[r * 64 + c4]) = make_float4(va[0], va[1], va[2], va[3]);
-            *reinterpret_cast<float4*>(&Bs[r * 64 + c4]) = make_float4(vb[0], vb[1], vb[2], vb[3]);
-        }
-        __syncthreads();
+        TN_COMMIT()
+        lds_barrier();
+        if (mm0 + 32 < mend) TN_LOAD(mm0 + 32)
         if (do_bias) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) bsum += Bs[r * 64 + tid];
@@ -228,8 +241,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        lds_barrier();
     }
+#undef TN_LOAD
+#undef TN_COMMIT
     float* out = slab + (size_t)blockIdx.z * ((size_t)K1 * N + N);
     if (do_bias && n0 + tid < N) out[(size_t)K1 * N + n0 + tid] = bsum;
     const int col = n0 + wc * 32 + li;
