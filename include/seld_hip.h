@@ -131,6 +131,15 @@ int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_sample
 int seld_feat_normalize(const float* feat, const float* mean, const float* stdv, float* out, int64_t T_in, int64_t T_out,
                         int FC, float eps, void* stream);
 
+/* ---- sliding-window inference: the two tensor ops around model() in evaluator.ensemble_outputs
+ * (evaluator.py:16-50, trainv2.py:158-192).
+ * seld_frame_windows: tf.signal.frame(x [T,FC], win_size, step, axis=0)[first_window : first_window+n_windows]
+ *                     -> windows [n_windows, win_size, FC]   (FC = freq*chan, multiple of 4)
+ * seld_overlap_average: tf.signal.overlap_and_add(y [n_windows, L, D], frame_step=1) / window count -> [n_windows-1+L, D] */
+int seld_frame_windows(const float* x, float* windows, int T, int FC, int win_size, int step, int first_window, int n_windows,
+                       void* stream);
+int seld_overlap_average(const float* y, float* out, int n_windows, int L, int D, void* stream);
+
 /* ---- measurement: HIP-event timing of named kernels on the ctx stream (bench.py roofline) */
 int seld_profile_enable(seld_ctx* ctx, int on);
 int seld_profile_count(const seld_ctx* ctx);

@@ -10,7 +10,7 @@
 //   bn_pool_bwd_dz     dz = scale * (dy - c1 - xhat*c2)
 #include "common.h"
 
-#define BN_MAX_PARTIAL 1024
+#define BN_MAX_PARTIAL 512
 int bn_partial_capacity() { return BN_MAX_PARTIAL; }
 
 // sum the [npartial][2C] block partials: thread (v = tid & 127 value, part = tid >> 7) strides the partials,
@@ -18,7 +18,15 @@ int bn_partial_capacity() { return BN_MAX_PARTIAL; }
 __device__ __forceinline__ double reduce_partials_128(const float* __restrict__ partial, int npartial, double* red) {
     const int v = threadIdx.x & 127, part = threadIdx.x >> 7;
     double s = 0.0;
-    for (int i = part; i < npartial; i += 8) s += (double)partial[(size_t)i * 128 + v];
+    int i = part;
+    for (; i + 56 < npartial; i += 64) {   // 8 independent loads in flight per thread
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = partial[(size_t)(i + 8 * k) * 128 + v];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)t[k];
+    }
+    for (; i < npartial; i += 8) s += (double)partial[(size_t)i * 128 + v];
     red[threadIdx.x] = s;
     __syncthreads();
     double tot = 0.0;

@@ -11,7 +11,7 @@
 // Block partials go to slabs that reduce_slabs_kernel (gemm.hip) combines in a fixed order.
 #include "common.h"
 
-#define CONV_MAX_PERSISTENT 1024
+#define CONV_MAX_PERSISTENT 768
 int conv_stat_partial_capacity() { return CONV_MAX_PERSISTENT; }
 #define WGRAD_MAX_BLOCKS 512
 int conv_wgrad_slab_capacity() { return WGRAD_MAX_BLOCKS; }

@@ -293,35 +293,63 @@ int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nsla
     return 0;
 }
 
+// out[i] (+)= sum_z slab[z][i].  Block = 32 outputs x 8 slab groups: thread (o = tid & 31, g = tid >> 5) adds
+// slabs g, g+8, ... (independent, coalesced 128-B rows), the 8 group sums are combined through LDS in a
+// fixed order -> bit-reproducible and 8x the memory parallelism of one thread per output.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab,
                                                            int64_t stride, float* __restrict__ out, int64_t n,
                                                            int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    // fixed order, double accumulator: bit-reproducible and independent of the split count's rounding
+    __shared__ double red[256];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
     double s = 0.0;
-    for (int z = 0; z < nslab; ++z) s += (double)slab[(size_t)z * stride + i];
-    float v = (float)s;
-    if (accumulate) v += out[i];
-    out[i] = v;
+    if (i < n) {
+        int z = g;
+        for (; z + 24 < nslab; z += 32) {   // 4 independent loads in flight
+            const float v0 = slab[(size_t)z * stride + i], v1 = slab[(size_t)(z + 8) * stride + i];
+            const float v2 = slab[(size_t)(z + 16) * stride + i], v3 = slab[(size_t)(z + 24) * stride + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; z < nslab; z += 8) s += (double)slab[(size_t)z * stride + i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + o];
+        float v = (float)t;
+        if (accumulate) v += out[i];
+        out[i] = v;
+    }
 }
 
-// slab[z] = [n_w main | n_b tail]: out_w[i] = sum_z main, out_b[i] = sum_z tail
+// slab[z] = [n_w main | n_b tail]: out_w[i] = sum_z main, out_b[i] = sum_z tail (same block scheme)
 __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* __restrict__ slab, int nslab, int64_t stride,
                                                             float* __restrict__ out_w, int64_t n_w,
                                                             float* __restrict__ out_b, int64_t n_b) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_w + n_b) return;
+    __shared__ double red[256];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
+    const int64_t n = n_w + n_b;
     double s = 0.0;
-    for (int z = 0; z < nslab; ++z) s += (double)slab[(size_t)z * stride + i];
-    if (i < n_w) out_w[i] = (float)s;
-    else out_b[i - n_w] = (float)s;
+    if (i < n)
+        for (int z = g; z < nslab; z += 8) s += (double)slab[(size_t)z * stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + o];
+        if (i < n_w) out_w[i] = (float)t;
+        else out_b[i - n_w] = (float)t;
+    }
 }
 
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b) {
     const int64_t n = n_w + n_b;
-    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab, stride, out_w,
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slab, nslab, stride, out_w,
                        n_w, out_b, n_b);
     return 0;
 }
@@ -329,7 +357,7 @@ int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t s
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
                         int64_t n, int accumulate) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slab, nslab,
                        slab_stride, out, n, accumulate);
     return 0;
 }

@@ -151,3 +151,18 @@ def test_golden(spec, name):
     g = r["grad"][::997]
     assert np.abs(g - z["grad_sample"]).max() <= 1e-4 * np.abs(z["grad_sample"]).max()
     np.testing.assert_allclose(r["new_state"], z["new_state"], **tol)
+
+
+def test_frame_and_overlap_average_semantics():
+    """evaluator.py:16-50 on the clip geometry: [3000,64,7] -> 541 windows of 300 -> 600 label frames."""
+    from oracle import infer_oracle as IO
+    x = np.arange(3000, dtype=np.float32)[:, None]
+    f = IO.frame(x, 300, 5)
+    assert f.shape == (541, 300, 1) and f[7, 0, 0] == 35 and f[540, 299, 0] == 2999
+    y = np.ones((541, 60, 3))
+    y[:, :, 1] = np.arange(541)[:, None]
+    out = IO.overlap_average(y)
+    assert out.shape == (600, 3)
+    np.testing.assert_allclose(out[:, 0], 1.0)
+    np.testing.assert_allclose(out[0, 1], 0.0)
+    np.testing.assert_allclose(out[100, 1], np.mean(np.arange(41, 101)))
