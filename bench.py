@@ -52,7 +52,7 @@ def kernel_work(name, B, T, F=64, C=7):
         "gru_fwd": ("hbm", 2 * 4 * rows * (384 + 128 + 512)),
         "gru_bwd": ("hbm", 2 * 4 * rows * (128 + 128 + 512 + 128 + 768)),
         "gru_inproj_gemm": ("mfma", 2 * 2 * rows * 128 * 384),
-        "gru_bwd_gemms": ("mfma", 2 * 2 * 3 * rows * 128 * 384),
+        "gru_bwd_gemms": ("mfma", 2 * 2 * rows * 128 * 384),   # main stream: the two input-gradient GEMMs of a layer
         "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
         "adam": ("hbm", 4 * 7 * 513840),
     }
@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-level", type=int, default=1, help="1: major kernel groups (default), 2: every group")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -123,7 +124,7 @@ def main():
         train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
     timing = not args.no_kernel_timing
     model.lib.seld_profile_reset(model.ctx)
-    model.lib.seld_profile_enable(model.ctx, int(timing))
+    model.lib.seld_profile_enable(model.ctx, args.timing_level if timing else 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -52,12 +52,15 @@ struct seld_ctx {
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
-    float *dgx[2] = {nullptr, nullptr}, *dgh[2] = {nullptr, nullptr};
+    float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
+    float* tn_slab_side = nullptr;
+    hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     std::vector<void*> allocs;
     std::string err;
-    bool prof = false;
+    int prof = 0;   // 0 off, 1 major kernel groups, 2 every group
     std::vector<Timer> timers;
 };
 
@@ -102,8 +105,8 @@ void add_var(std::vector<Var>& v, int64_t& off, const std::string& name, std::in
 
 struct ProfScope {
     seld_ctx* c; int idx;
-    ProfScope(seld_ctx* c_, const char* name) : c(c_), idx(-1) {
-        if (!c->prof) return;
+    ProfScope(seld_ctx* c_, const char* name, int level = 1) : c(c_), idx(-1) {
+        if (c->prof < level) return;
         for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) { Timer t; t.name = name; c->timers.push_back(t); idx = (int)c->timers.size() - 1; }
         hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
@@ -116,7 +119,8 @@ struct ProfScope {
 };
 #define PROF_CAT2(a, b) a##b
 #define PROF_CAT(a, b) PROF_CAT2(a, b)
-#define PROF(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name)
+#define PROF(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name, 1)
+#define PROF2(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name, 2)
 
 int check_launch(seld_ctx* c, const char* what) {
     hipError_t e = hipGetLastError();
@@ -249,7 +253,15 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(G.out, rows * 128); ALLOC(G.din, rows * (size_t)G.in_feat);
     }
     ALLOC(c->feat_grad, rows * 128);
-    for (int d = 0; d < 2; ++d) { ALLOC(c->dgx[d], rows * 384); ALLOC(c->dgh[d], rows * 384); }
+    for (int i = 0; i < a->n_gru; ++i)
+        for (int d = 0; d < 2; ++d) { ALLOC(c->dgx[i][d], rows * 384); ALLOC(c->dgh[i][d], rows * 384); }
+    ALLOC(c->tn_slab_side, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        seld_destroy(c);
+        return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
+    }
     for (int hd = 0; hd < 2; ++hd)
         for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
     ALLOC(c->loss_scratch, (size_t)loss_scratch_floats((int)rows));
@@ -265,6 +277,9 @@ void seld_destroy(seld_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto& t : c->timers) for (auto e : t.ev) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
     delete c;
 }
@@ -361,7 +376,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                                   L.scale, L.shift, 64);
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
-            PROF(c, tn);
+            ProfScope pool_scope(c, tn, i == 0 ? 1 : 2);
             if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
@@ -371,7 +386,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     for (size_t i = 0; i < c->gru.size(); ++i) {
         GruL& G = c->gru[i];
         {
-            PROF(c, "gru_inproj_gemm");
+            PROF2(c, "gru_inproj_gemm");
             for (int d = 0; d < 2; ++d)
                 launch_gemm(st, feat, G.in_feat, c->params + G.k_off[d], 384, c->params + G.b_off[d], G.gx[d], 384, rows, 384,
                             G.in_feat, 0, 0, 0);
@@ -385,7 +400,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         feat = G.out;
     }
     {
-        PROF(c, "heads_fwd");
+        PROF2(c, "heads_fwd");
         for (int hd = 0; hd < 2; ++hd) {
             const float* a = feat;
             Head& Hd = c->heads[hd];
@@ -452,30 +467,43 @@ int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float*
 // ---------------------------------------------------------------------------------------------- backward
 // dW[K1,N] = A^T B via slabs, into grads at w_off; optional time shift on A rows
 // dW[K1,N] = A^T B and db[N] = colsum(B) in one TN launch + one fixed-order slab reduction
-static void wgrad_dense(seld_ctx* c, const float* A, int lda, const float* Bm, int ldb, int M, int K1, int N, int64_t w_off,
-                        int64_t b_off, int S, int shift) {
+static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A, int lda, const float* Bm, int ldb, int M,
+                        int K1, int N, int64_t w_off, int64_t b_off, int S, int shift) {
     int ns = 0;
-    launch_gemm_tn(c->stream, A, lda, Bm, ldb, c->tn_slab, &ns, M, K1, N, S, shift, 1);
-    launch_reduce_slabs2(c->stream, c->tn_slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
+    launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1);
+    launch_reduce_slabs2(st, slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
+}
+// side stream: everything enqueued on it after this call starts once the main stream has reached this point
+static void fork_side(seld_ctx* c) {
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->side, c->ev_fork, 0);
 }
 
 static int backward_impl(seld_ctx* c, const float* x) {
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S, rows = B * S;
     GruL& Glast = c->gru.back();
-    // ---- heads: gradient w.r.t. the last GRU output accumulates into feat_grad
+    // ---- heads: the input-gradient chain runs on the main stream; the weight/bias gradients only
+    // feed Adam, so they go to the side stream and overlap with the BPTT chain that follows
     {
-        PROF(c, "heads_bwd");
+        PROF2(c, "heads_bwd");
         float* dfeat = c->feat_grad;
         for (int hd = 0; hd < 2; ++hd) {
             Head& Hd = c->heads[hd];
             for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
                 DenseL& D = Hd.layers[j];
-                const float* ain = j == 0 ? Glast.out : Hd.layers[j - 1].y;
-                wgrad_dense(c, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, D.b_off, 0, 0);
                 float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
                 const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
                 launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
+            }
+        }
+        fork_side(c);
+        for (int hd = 0; hd < 2; ++hd) {
+            Head& Hd = c->heads[hd];
+            for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
+                DenseL& D = Hd.layers[j];
+                const float* ain = j == 0 ? Glast.out : Hd.layers[j - 1].y;
+                wgrad_dense(c, c->side, c->tn_slab_side, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, D.b_off, 0, 0);
             }
         }
     }
@@ -486,16 +514,22 @@ static int backward_impl(seld_ctx* c, const float* x) {
         const float* lin = i == 0 ? c->conv.back().p : c->gru[i - 1].out;
         {
             PROF(c, "gru_bwd");
-            launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[0],
-                           c->dgx[1], c->dgh[0], c->dgh[1], B, S);
+            launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
+                           c->dgx[i][1], c->dgh[i][0], c->dgh[i][1], B, S);
         }
-        PROF(c, "gru_bwd_gemms");
+        // weight gradients of this layer: side stream (they overlap with the next layer's BPTT, which uses 2B of the 256 CUs)
+        fork_side(c);
         for (int d = 0; d < 2; ++d) {
             // kernel + input bias (bias row 0)
-            wgrad_dense(c, lin, G.in_feat, c->dgx[d], 384, rows, G.in_feat, 384, G.k_off[d], G.b_off[d], 0, 0);
+            wgrad_dense(c, c->side, c->tn_slab_side, lin, G.in_feat, c->dgx[i][d], 384, rows, G.in_feat, 384, G.k_off[d], G.b_off[d], 0, 0);
             // recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction h[t+1]) + bias row 1
-            wgrad_dense(c, G.h[d], 128, c->dgh[d], 384, rows, 128, 384, G.u_off[d], G.b_off[d] + 384, S, d == 0 ? -1 : 1);
-            launch_gemm(st, c->dgx[d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
+            wgrad_dense(c, c->side, c->tn_slab_side, G.h[d], 128, c->dgh[i][d], 384, rows, 128, 384, G.u_off[d], G.b_off[d] + 384, S,
+                        d == 0 ? -1 : 1);
+        }
+        {
+            PROF(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
+            for (int d = 0; d < 2; ++d)
+                launch_gemm(st, c->dgx[i][d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
         }
         dout = G.din;
     }
@@ -507,7 +541,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
         char tn[32];
         snprintf(tn, sizeof tn, "pool%d_bwd_reduce", i + 1);
         {
-            PROF(c, tn);
+            PROF2(c, tn);
             if (launch_bn_pool_bwd_reduce(st, L.z, L.p, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
                                           L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
@@ -517,7 +551,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
         const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
         if (!fused_first) {
             snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
-            PROF(c, tn);
+            PROF2(c, tn);
             launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
         }
         if (i == 0) {
@@ -549,6 +583,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
             dp = c->conv[i - 1].dp;
         }
     }
+    // join: the side stream's weight gradients must be complete before Adam / the DP all-reduce
+    hipEventRecord(c->ev_join, c->side);
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
     return check_launch(c, "backward");
 }
 
@@ -569,7 +606,7 @@ int seld_adam_step(seld_ctx* c, float lr, float beta1, float beta2, float eps, i
     c->adam_step += 1;
     const double t = (double)c->adam_step;
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-    PROF(c, "adam");
+    PROF2(c, "adam");
     launch_adam(c->stream, c->params, c->grads, c->adam_m, c->adam_v, c->nparam, lr_t, beta1, beta2, eps);
     return check_launch(c, "adam");
 }
@@ -582,7 +619,7 @@ int seld_train_step(seld_ctx* c, const float* x, const float* y_sed, const float
 }
 
 // ---------------------------------------------------------------------------------------------- profiling
-int seld_profile_enable(seld_ctx* c, int on) { if (!c) return SELD_ERR_INVALID; c->prof = on != 0; return SELD_OK; }
+int seld_profile_enable(seld_ctx* c, int on) { if (!c) return SELD_ERR_INVALID; c->prof = on < 0 ? 0 : (on > 2 ? 2 : on); return SELD_OK; }
 int seld_profile_count(const seld_ctx* c) { return c ? (int)c->timers.size() : -1; }
 static void prof_resolve(seld_ctx* c) {
     hipStreamSynchronize(c->stream);
