@@ -59,13 +59,26 @@ def kernel_work(name, B, T, F=64, C=7):
     return table.get(name)
 
 
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(B, T, steps):
     """Oracle train step (PyTorch-CPU fp32 restatement) on the host cores: bounded sample."""
     from oracle import seldnet_oracle as O
     spec = O.Spec.from_config(SELDNET_CONFIG)
     w, st = O.random_weights(spec, 0)
     x, ys, yd = O.synthetic_batch(B, T)
-    cores = torch.get_num_threads()
+    cores = host_cores()
+    torch.set_num_threads(cores)
     O.train_step(spec, w, st, x, ys, yd)  # warm-up
     ts = []
     for _ in range(steps):
@@ -75,7 +88,7 @@ def cpu_baseline(B, T, steps):
     best = float(np.median(ts))
     return {"value": B / best, "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": f"oracle train_step, B={B} clips of [T={T},64,7], median of {steps} steps after 1 warm-up "
-                      f"({best:.2f} s/step); PyTorch-CPU restatement of the reference semantics, not the reference's TF"}
+                      f"({best:.2f} s/step, {cores} threads); PyTorch-CPU restatement of the reference semantics, not the reference's TF"}
 
 
 def main():

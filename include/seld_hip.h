@@ -141,7 +141,7 @@ int seld_frame_windows(const float* x, float* windows, int T, int FC, int win_si
 int seld_overlap_average(const float* y, float* out, int n_windows, int L, int D, void* stream);
 
 /* ---- measurement: HIP-event timing of named kernel groups on the ctx stream (bench.py roofline).
- * seld_profile_enable(ctx, level): 0 off, 1 major groups (conv / pool1 / GRU / GRU GEMMs), 2 every group */
+ * seld_profile_enable(ctx, level): 0 off, 1 the four largest groups (conv1 fwd / conv1 wgrad / GRU fwd / GRU BPTT), 2 every group */
 int seld_profile_enable(seld_ctx* ctx, int on);
 int seld_profile_count(const seld_ctx* ctx);
 int seld_profile_get(seld_ctx* ctx, int index, char* name, int name_cap, int64_t* launches, double* total_ms);

@@ -360,11 +360,11 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         char tn[32];
         snprintf(tn, sizeof tn, "conv%d_fwd", (int)i + 1);
         if (i == 0) {
-            PROF(c, tn);
+            PROF(c, tn);   // level 1
             if (launch_conv_first_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
         } else {
-            PROF(c, tn);
+            PROF2(c, tn);
             if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
@@ -376,7 +376,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                                   L.scale, L.shift, 64);
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
-            ProfScope pool_scope(c, tn, i == 0 ? 1 : 2);
+            PROF2(c, tn);
             if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
@@ -527,7 +527,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         d == 0 ? -1 : 1);
         }
         {
-            PROF(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
+            PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             for (int d = 0; d < 2; ++d)
                 launch_gemm(st, c->dgx[i][d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
         }
@@ -569,7 +569,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const float* lin = c->conv[i - 1].p;
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
             {
-                PROF(c, tn);
+                PROF2(c, tn);
                 if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
             }
@@ -577,7 +577,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_flip_weights(st, c->params + L.w_off, c->wflip);
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
-                PROF(c, tn);
+                PROF2(c, tn);
                 launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
             }
             dp = c->conv[i - 1].dp;

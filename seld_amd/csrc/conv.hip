@@ -506,6 +506,17 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     const float4 mu4 = reinterpret_cast<const float4*>(coef)[g], is4 = reinterpret_cast<const float4*>(coef + 64)[g];
     const float4 sc4 = reinterpret_cast<const float4*>(coef + 128)[g], sh4 = reinterpret_cast<const float4*>(coef + 192)[g];
     const float4 c14 = reinterpret_cast<const float4*>(coef + 256)[g], c24 = reinterpret_cast<const float4*>(coef + 320)[g];
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    float ka[4], kb[4];   // dz = z*ka + kb (+ scale*dp at the argmax): ka = -scale*c2*invstd, kb = -scale*c1 - ka*mean
+    {
+        const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+        const float c1[4] = {c14.x, c14.y, c14.z, c14.w}, c2[4] = {c24.x, c24.y, c24.z, c24.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ka[c] = -sc[c] * c2[c] * is[c];
+            kb[c] = -sc[c] * c1[c] - ka[c] * mu[c];
+        }
+    }
     PatchStage<CIN> stg;
     float4 zr[16], pr[2], dpr[2];
     int st_t0 = 0;     // t0 of the staged tile
@@ -537,16 +548,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             const float4 dv = second ? dpr[1] : dpr[0];
             const float zz[4] = {zr[u].x, zr[u].y, zr[u].z, zr[u].w};
             const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
-            const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-            const float c1[4] = {c14.x, c14.y, c14.z, c14.w}, c2[4] = {c24.x, c24.y, c24.z, c24.w};
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                // dz = scale*(dy - c1 - xhat*c2) = fma(z, ka, kb) + (argmax ? scale*dp : 0)
                 const float y = fmaf(zz[c], sc[c], sh[c]);
-                const float dy = (y == pp[c] && pp[c] > 0.f) ? dd[c] : 0.f;
-                const float xh = (zz[c] - mu[c]) * is[c];
-                o[c] = (t < H) ? sc[c] * (dy - c1[c] - xh * c2[c]) : 0.f;
+                const float g_sel = (y == pp[c] && pp[c] > 0.f) ? sc[c] * dd[c] : 0.f;
+                o[c] = (t < H) ? fmaf(zz[c], ka[c], kb[c]) + g_sel : 0.f;
             }
             *reinterpret_cast<float4*>(dzl + (size_t)(row * 64 + px) * 64 + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
