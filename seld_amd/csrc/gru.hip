@@ -19,6 +19,11 @@
 //   hh = tanh(gx_h + r * gh_h);  h' = z*h + (1-z)*hh
 #include "common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// v_pk_fma_f32: two fp32 FMAs per lane per instruction.  The scalar v_fma_f32 issues a wave64 in 4 cycles
+// on gfx950, so the mat-vec of the recurrence (the step's longest phase) runs twice as fast packed.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 #define GRU_U 128
 #define GRU_G 384
 #define GRUF_CH 16   // forward: steps per staged chunk
@@ -51,11 +56,14 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float gxl[2][GRUF_CH * GRU_G];
     // padded h vector: index k lives at k + 4*(k>>5) so the 4 quarters start in different bank groups
     __shared__ __attribute__((aligned(16))) float hl[2][144];
-    float u[3][32];
+    f32x2 u[3][16];   // u[g][p] = (U[32q+2p][g*128+j], U[32q+2p+1][g*128+j])
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) u[g][kk] = U[(size_t)(32 * q + kk) * GRU_G + g * GRU_U + j];
+        for (int p = 0; p < 16; ++p) {
+            u[g][p].x = U[(size_t)(32 * q + 2 * p) * GRU_G + g * GRU_U + j];
+            u[g][p].y = U[(size_t)(32 * q + 2 * p + 1) * GRU_G + g * GRU_U + j];
+        }
     const float bz = brec[j], br = brec[GRU_U + j], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
@@ -101,15 +109,15 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const int t = tlo + row;
             const float gxz = gb[row * GRU_G + j], gxr = gb[row * GRU_G + GRU_U + j], gxh = gb[row * GRU_G + 2 * GRU_U + j];
             const float* hp = &hl[step & 1][36 * q];
-            float az = 0.f, ar = 0.f, ah = 0.f;
+            f32x2 az2 = {0.f, 0.f}, ar2 = {0.f, 0.f}, ah2 = {0.f, 0.f};   // (even k, odd k) partial sums
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) {
                 const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * k4);
-                az = fmaf(hv.x, u[0][4 * k4 + 0], az); ar = fmaf(hv.x, u[1][4 * k4 + 0], ar); ah = fmaf(hv.x, u[2][4 * k4 + 0], ah);
-                az = fmaf(hv.y, u[0][4 * k4 + 1], az); ar = fmaf(hv.y, u[1][4 * k4 + 1], ar); ah = fmaf(hv.y, u[2][4 * k4 + 1], ah);
-                az = fmaf(hv.z, u[0][4 * k4 + 2], az); ar = fmaf(hv.z, u[1][4 * k4 + 2], ar); ah = fmaf(hv.z, u[2][4 * k4 + 2], ah);
-                az = fmaf(hv.w, u[0][4 * k4 + 3], az); ar = fmaf(hv.w, u[1][4 * k4 + 3], ar); ah = fmaf(hv.w, u[2][4 * k4 + 3], ah);
+                const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+                az2 = pk_fma(h01, u[0][2 * k4], az2); ar2 = pk_fma(h01, u[1][2 * k4], ar2); ah2 = pk_fma(h01, u[2][2 * k4], ah2);
+                az2 = pk_fma(h23, u[0][2 * k4 + 1], az2); ar2 = pk_fma(h23, u[1][2 * k4 + 1], ar2); ah2 = pk_fma(h23, u[2][2 * k4 + 1], ah2);
             }
+            float az = az2.x + az2.y, ar = ar2.x + ar2.y, ah = ah2.x + ah2.y;
             az = quad_sum(az); ar = quad_sum(ar); ah = quad_sum(ah);
             const float z = sigmoid_(gxz + az + bz);
             const float r = sigmoid_(gxr + ar + br);
@@ -151,7 +159,21 @@ int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const f
 //   dhh = dh*(1-z); dz = dh*(h_prev - hh); a_h = dhh*(1-hh^2); a_z = dz*z*(1-z); a_r = a_h*ghh*r*(1-r)
 //   dgx[t] = [a_z, a_r, a_h]   (input side)      dgh[t] = [a_z, a_r, a_h*r]   (recurrent side)
 //   carry  = dh*z + dgh[t] U^T
-// thread (j, q) holds U[j][96q .. 96q+95] and reduces its quarter of the 384-long dot product.
+// Register blocking of the 384 -> 128 mat-vec: lane (grp = lane>>4, cp = lane&15) of wave w owns the 4
+// outputs j0..j0+3 (j0 = 4*(4w+grp)) over the 24 columns [24cp, 24cp+24): each staged gradient value is
+// read from LDS once per 4 outputs (6 ds_read_b128 per step instead of 24 — the one-output-per-lane
+// layout was LDS-bandwidth-bound), then an all-reduce over the 16 lanes of the row (quad_perm + row_ror
+// DPP) leaves the 4 sums in every lane.  Gate gradients of unit j0 + (cp&3) are computed by the same lane.
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
+    return v;
+}
+
+#define GRUB_GL 448   // padded gate-gradient vector: column c lives at 28*(c/24) + c%24 (16 parts, conflict-free b128 reads)
+
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ h_f,
                                                       const float* __restrict__ h_b, const float* __restrict__ sv_f,
                                                       const float* __restrict__ sv_b, const float* __restrict__ U_f,
@@ -166,13 +188,21 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const float* U = dir ? U_b : U_f;
     float* dgx = (dir ? dgx_b : dgx_f) + (size_t)b * S * GRU_G;
     float* dgh = (dir ? dgh_b : dgh_f) + (size_t)b * S * GRU_G;
-    const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cp = lane & 15;                       // column part of the mat-vec
+    const int j0 = 4 * (4 * wave + (lane >> 4));    // first of this lane's 4 outputs
+    const int jm = j0 + (cp & 3), qr = cp >> 2;     // unit / role (z, r, h, -) of this lane in the gate stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* stage = smem;                          // [2][GRUB_CH][GRUB_ROW]
-    float* gl = smem + 2 * GRUB_CH * GRUB_ROW;    // [2][400] padded gate-gradient vector: c -> c + 4*(c/96)
-    float ut[96];
+    float* gl = smem + 2 * GRUB_CH * GRUB_ROW;    // [2][GRUB_GL]
+    f32x2 ut[4][12];   // ut[a][p] = U[j0+a][24cp + 2p .. +1]
 #pragma unroll
-    for (int cc = 0; cc < 96; ++cc) ut[cc] = U[(size_t)j * GRU_G + 96 * q + cc];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {
+            ut[a][p].x = U[(size_t)(j0 + a) * GRU_G + 24 * cp + 2 * p];
+            ut[a][p].y = U[(size_t)(j0 + a) * GRU_G + 24 * cp + 2 * p + 1];
+        }
     // the forward pass consumed t = 0..S-1 (dir 0) / S-1..0 (dir 1); BPTT walks that order backwards:
     // BPTT step s is time t = S-1-s (dir 0) or s (dir 1); h_prev(t) = H[t-1] (dir 0) / H[t+1] (dir 1)
     const int hshift = dir ? 1 : -1;
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     issue(0);
     commit(0);
     __syncthreads();
-    float carry = 0.f;
+    float carry = 0.f;    // carry of unit jm
     int step = 0;
     for (int c = 0; c < nchunks; ++c) {
         int n, tlo;
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         auto part1 = [&](int i) {   // gate gradients of step i -> LDS vector + global
             const int row = dir ? i : n - 1 - i;
             const int t = tlo + row;
-            const float* rp = sb + row * GRUB_ROW + j;
+            const float* rp = sb + row * GRUB_ROW + jm;
             const float c_do = rp[0] * rp[128];
             const float c_z = rp[256], c_r = rp[384], c_hh = rp[512], c_gh = rp[640], hp = rp[768];
             dh = c_do + carry;
@@ -246,28 +276,37 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             const float a_z = dzg * c_z * (1.f - c_z);
             const float a_r = a_h * c_gh * c_r * (1.f - c_r);
             const float a_hr = a_h * c_r;
-            gw = gl + (step & 1) * 400;
-            if (q < 3) {
-                const int cidx = q * GRU_U + j;
-                const float vx = q == 0 ? a_z : (q == 1 ? a_r : a_h);
-                const float vh = q == 0 ? a_z : (q == 1 ? a_r : a_hr);
-                gw[cidx + 4 * (cidx / 96)] = vh;
+            gw = gl + (step & 1) * GRUB_GL;
+            if (qr < 3) {
+                const int cidx = qr * GRU_U + jm;
+                const float vx = qr == 0 ? a_z : (qr == 1 ? a_r : a_h);
+                const float vh = qr == 0 ? a_z : (qr == 1 ? a_r : a_hr);
+                gw[28 * (cidx / 24) + cidx % 24] = vh;
                 dgx[(size_t)t * GRU_G + cidx] = vx;
                 dgh[(size_t)t * GRU_G + cidx] = vh;
             }
         };
         auto part2 = [&]() {        // carry = dh*z + dgh U^T
-            const float* gp = gw + 100 * q;
-            float s0 = 0.f, s1 = 0.f;
+            const float* gp = gw + 28 * cp;
+            f32x2 s2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int c4 = 0; c4 < 24; ++c4) {
+            for (int c4 = 0; c4 < 6; ++c4) {
                 const float4 gv = *reinterpret_cast<const float4*>(gp + 4 * c4);
-                s0 = fmaf(gv.x, ut[4 * c4 + 0], s0);
-                s1 = fmaf(gv.y, ut[4 * c4 + 1], s1);
-                s0 = fmaf(gv.z, ut[4 * c4 + 2], s0);
-                s1 = fmaf(gv.w, ut[4 * c4 + 3], s1);
+                const f32x2 g01 = {gv.x, gv.y}, g23 = {gv.z, gv.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    s2[a] = pk_fma(g01, ut[a][2 * c4], s2[a]);
+                    s2[a] = pk_fma(g23, ut[a][2 * c4 + 1], s2[a]);
+                }
             }
-            carry = dh * c_zs + quad_sum(s0 + s1);
+            float s[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a] = s2[a].x + s2[a].y;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a] = row16_allsum(s[a]);
+            const int sel = cp & 3;
+            const float mine = sel == 0 ? s[0] : (sel == 1 ? s[1] : (sel == 2 ? s[2] : s[3]));
+            carry = dh * c_zs + mine;
             ++step;
         };
         for (int i = 0; i < n - 1; ++i) {
@@ -285,7 +324,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S) {
-    const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * 400) * sizeof(float);
+    const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * GRUB_GL) * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);
