@@ -142,7 +142,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     if (a->n_conv < 1 || a->n_conv > SELD_MAX_LAYERS || a->n_gru < 1 || a->n_gru > SELD_MAX_LAYERS ||
         a->n_sed_dense < 0 || a->n_sed_dense > SELD_MAX_LAYERS || a->n_doa_dense < 0 || a->n_doa_dense > SELD_MAX_LAYERS)
         return fail(nullptr, SELD_ERR_INVALID, "layer counts out of range");
-    if (a->in_ch != 7) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for in_ch = 7 (foa)");
+    if (a->in_ch != 7 && a->in_ch != 10)
+        return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernels are built for in_ch = 7 (foa) and 10 (mic)");
     if (a->n_freq != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for n_freq = 64");
     if (a->n_classes <= 0) return fail(nullptr, SELD_ERR_INVALID, "n_classes must be positive");
     int H = T, W = a->n_freq;
@@ -563,8 +564,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
                     : launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin);
                 if (rc) return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
             }
-            // slab rows 0..62 = kernel [9*7][64], row 63 = bias: contiguous with the flat layout
-            launch_reduce_slabs(st, c->wgrad_slab, ns, 4096, c->grads + L.w_off, 4096, 0);
+            // slab rows 0..9*Cin-1 = kernel [9*Cin][64], row 9*Cin = bias: contiguous with the flat layout
+            launch_reduce_slabs(st, c->wgrad_slab, ns, conv_first_wgrad_slab_stride(L.Cin), c->grads + L.w_off,
+                                (int64_t)(9 * L.Cin + 1) * 64, 0);
         } else {
             const float* lin = c->conv[i - 1].p;
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);

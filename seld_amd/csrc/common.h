@@ -43,6 +43,7 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
 int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
                         int B, int H, int W);
 int conv_wgrad_slab_capacity();
+int conv_first_wgrad_slab_stride(int Cin);   // floats per first-layer wgrad slab: rows 0..9*Cin-1 kernel, row 9*Cin bias
 int launch_flip_weights(hipStream_t st, const float* w, float* wt);  // [3,3,64,64] -> dgrad weights
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
                         int64_t n, int accumulate);

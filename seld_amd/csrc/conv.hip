@@ -25,7 +25,10 @@ struct FirstGeom {
     static constexpr int KPAD = (K + 2) & ~1;      // + bias row, even
     static constexpr int ROWF = 66 * CIN;          // floats per patch row
     static constexpr int PATCH = 6 * ROWF;
+    static constexpr int NKT = (KPAD + 31) / 32;   // 32-row k-tiles of the weight gradient
+    static constexpr int WG_SLAB = NKT * 32 * 64;  // floats per wgrad slab: rows 0..K-1 kernel, row K bias
 };
+int conv_first_wgrad_slab_stride(int Cin) { return (((9 * Cin + 2) & ~1) + 31) / 32 * 32 * 64; }
 
 // The halo patch of a 4x64-pixel tile: patch[r][c][ci] for image rows t0-1..t0+4, cols -1..64.
 // Global side: each image row is 64*CIN contiguous floats -> float4 loads (PatchStage::NV per row).
@@ -192,6 +195,8 @@ int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const 
     const int grid = ntiles < CONV_MAX_PERSISTENT ? ntiles : CONV_MAX_PERSISTENT;
     if (Cin == 7)
         hipLaunchKernelGGL(conv_first_fwd_kernel<7>, dim3(grid), dim3(256), 0, st, x, w, bias, z, stat_partial, B, H);
+    else if (Cin == 10)
+        hipLaunchKernelGGL(conv_first_fwd_kernel<10>, dim3(grid), dim3(256), 0, st, x, w, bias, z, stat_partial, B, H);
     else
         return -2;
     if (n_partial) *n_partial = grid;
@@ -368,7 +373,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
                                                                float* __restrict__ slab, int B, int H) {
     using G = FirstGeom<CIN>;
     constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
-    static_assert(KPAD == 64, "one 64x64 output (4 wave tiles) per block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                 // [256 px][64 co]
     float* patch = smem + 256 * 64;    // [6][66][CIN]
@@ -376,13 +380,15 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
     const int hi = lane >> 5, li = lane & 31;
     // wave w owns pixel row w of the tile (64 px) and all 4 output tiles (k 0-31 / 32-63) x (co 0-31 / 32-63):
     // 4 independent accumulator chains per wave (a single dependent chain ran the MFMA pipe at ~30%)
-    int koffs[2];
+    constexpr int NKT = G::NKT;
+    int koffs[NKT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
         const int k = kt * 32 + li;   // this lane's im2col column (A-operand row) in k-tile kt
         const int kh = k / (3 * CIN);
-        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH]; k > K never occurs (KPAD == K+1)
-        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : -1;
+        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH];
+        // k > K (padding of the last k-tile) reads the 0.0 parked at patch[PATCH + 1]
+        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : (k == K ? -1 : -2);
     }
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         for (int u = 0; u < 16; ++u) reinterpret_cast<float4*>(dzl)[tid + 256 * u] = dzr[u];
     };
     zero_patch<CIN>(patch, tid);
-    if (tid == 0) patch[G::PATCH] = 1.f;   // the bias row's A operand
+    if (tid == 0) { patch[G::PATCH] = 1.f; patch[G::PATCH + 1] = 0.f; }   // A operands of the bias row / k padding
     int tile = blockIdx.x;
     __syncthreads();
     if (tile < ntiles) {
@@ -412,9 +418,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         commit_dz();
     }
     __syncthreads();
-    f32x16 acc[2][2];
+    f32x16 acc[NKT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[kt][ct] = zero16();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -426,27 +432,32 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
             issue_dz(nb, nt0);
         }
         // per step (2 pixels): 2 A reads (k-tiles) + 2 B reads (co-tiles) feed 4 MFMAs; one-step pipeline
-        auto ld = [&](int s, float& a0, float& a1, float& b0, float& b1) {
+        auto ld = [&](int s, float (&a)[NKT], float& b0, float& b1) {
             const int f = 2 * s + hi;                       // pixel column in this wave's row
-            a0 = patch[koffs[0] >= 0 ? koffs[0] + f * CIN : G::PATCH];
-            a1 = patch[koffs[1] >= 0 ? koffs[1] + f * CIN : G::PATCH];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) a[kt] = patch[koffs[kt] >= 0 ? koffs[kt] + f * CIN : G::PATCH - 1 - koffs[kt]];
             const float* bp = dzl + (wave * 64 + f) * 64 + li;
             b0 = bp[0];
             b1 = bp[32];
         };
-        float a0, a1, b0, b1;
-        ld(0, a0, a1, b0, b1);
+        float a[NKT], b0, b1;
+        ld(0, a, b0, b1);
 #pragma unroll 8
         for (int s = 0; s < 32; ++s) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (s + 1 < 32) ld(s + 1, na0, na1, nb0, nb1);
+            float na[NKT], nb0 = 0.f, nb1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) na[kt] = 0.f;
+            if (s + 1 < 32) ld(s + 1, na, nb0, nb1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                acc[kt][0] = MFMA_F32_32x32x2(a[kt], b0, acc[kt][0]);
+                acc[kt][1] = MFMA_F32_32x32x2(a[kt], b1, acc[kt][1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) a[kt] = na[kt];
+            b0 = nb0; b1 = nb1;
         }
         lds_barrier();          // every wave is done reading this tile
         if (has_next) {
@@ -455,18 +466,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         }
         lds_barrier();
     }
-    // combine the 4 waves' partial [64 k][64 co] sums through LDS (dzl is free now), fixed order
-    __syncthreads();
+    // combine the 4 waves' partial sums through LDS (dzl is free now), one 32-row k-tile at a time, fixed order
+    float* out = slab + (size_t)blockIdx.x * G::WG_SLAB;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+        __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dzl[wave * 4096 + (kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[kt][ct][r];
-    __syncthreads();
-    float* out = slab + (size_t)blockIdx.x * 4096;
-    for (int i = tid; i < 4096; i += 256) out[i] = (dzl[i] + dzl[4096 + i]) + (dzl[8192 + i] + dzl[12288 + i]);
+            for (int r = 0; r < 16; ++r) dzl[wave * 2048 + mfma_row(r, hi) * 64 + ct * 32 + li] = acc[kt][ct][r];
+        __syncthreads();
+        for (int i = tid; i < 2048; i += 256) out[kt * 2048 + i] = (dzl[i] + dzl[2048 + i]) + (dzl[4096 + i] + dzl[6144 + i]);
+    }
 }
 
 // Fused first-layer backward: dz is never materialised.  The kernel reads the forward's pre-BN
@@ -483,7 +494,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
                                                                      int B, int H) {
     using G = FirstGeom<CIN>;
     constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
-    static_assert(KPAD == 64, "one 64x64 output (4 wave tiles) per block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                 // [256 px][64 co]
     float* patch = smem + 256 * 64;    // [6][66][CIN]
@@ -491,13 +501,15 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     const int hi = lane >> 5, li = lane & 31;
     // wave w owns pixel row w of the tile (64 px) and all 4 output tiles (k 0-31 / 32-63) x (co 0-31 / 32-63):
     // 4 independent accumulator chains per wave (a single dependent chain ran the MFMA pipe at ~30%)
-    int koffs[2];
+    constexpr int NKT = G::NKT;
+    int koffs[NKT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
         const int k = kt * 32 + li;   // this lane's im2col column (A-operand row) in k-tile kt
         const int kh = k / (3 * CIN);
-        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH]; k > K never occurs (KPAD == K+1)
-        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : -1;
+        // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH];
+        // k > K (padding of the last k-tile) reads the 0.0 parked at patch[PATCH + 1]
+        koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : (k == K ? -1 : -2);
     }
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         }
     };
     zero_patch<CIN>(patch, tid);
-    if (tid == 0) patch[G::PATCH] = 1.f;   // the bias row's A operand
+    if (tid == 0) { patch[G::PATCH] = 1.f; patch[G::PATCH + 1] = 0.f; }   // A operands of the bias row / k padding
     int tile = blockIdx.x;
     __syncthreads();
     if (tile < ntiles) {
@@ -571,9 +583,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         commit_dz();
     }
     __syncthreads();
-    f32x16 acc[2][2];
+    f32x16 acc[NKT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[kt][ct] = zero16();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -585,27 +597,32 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             issue_z(nb, nt0);
         }
         // per step (2 pixels): 2 A reads (k-tiles) + 2 B reads (co-tiles) feed 4 MFMAs; one-step pipeline
-        auto ld = [&](int s, float& a0, float& a1, float& b0, float& b1) {
+        auto ld = [&](int s, float (&a)[NKT], float& b0, float& b1) {
             const int f = 2 * s + hi;                       // pixel column in this wave's row
-            a0 = patch[koffs[0] >= 0 ? koffs[0] + f * CIN : G::PATCH];
-            a1 = patch[koffs[1] >= 0 ? koffs[1] + f * CIN : G::PATCH];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) a[kt] = patch[koffs[kt] >= 0 ? koffs[kt] + f * CIN : G::PATCH - 1 - koffs[kt]];
             const float* bp = dzl + (wave * 64 + f) * 64 + li;
             b0 = bp[0];
             b1 = bp[32];
         };
-        float a0, a1, b0, b1;
-        ld(0, a0, a1, b0, b1);
+        float a[NKT], b0, b1;
+        ld(0, a, b0, b1);
 #pragma unroll 8
         for (int s = 0; s < 32; ++s) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (s + 1 < 32) ld(s + 1, na0, na1, nb0, nb1);
+            float na[NKT], nb0 = 0.f, nb1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) na[kt] = 0.f;
+            if (s + 1 < 32) ld(s + 1, na, nb0, nb1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = MFMA_F32_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA_F32_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA_F32_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA_F32_32x32x2(a1, b1, acc[1][1]);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                acc[kt][0] = MFMA_F32_32x32x2(a[kt], b0, acc[kt][0]);
+                acc[kt][1] = MFMA_F32_32x32x2(a[kt], b1, acc[kt][1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) a[kt] = na[kt];
+            b0 = nb0; b1 = nb1;
         }
         lds_barrier();
         if (has_next) {
@@ -614,34 +631,38 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         }
         lds_barrier();
     }
-    // combine the 4 waves' partial [64 k][64 co] sums through LDS (dzl is free now), fixed order
-    __syncthreads();
+    // combine the 4 waves' partial sums through LDS (dzl is free now), one 32-row k-tile at a time, fixed order
+    float* out = slab + (size_t)blockIdx.x * G::WG_SLAB;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+        __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dzl[wave * 4096 + (kt * 32 + mfma_row(r, hi)) * 64 + ct * 32 + li] = acc[kt][ct][r];
-    __syncthreads();
-    float* out = slab + (size_t)blockIdx.x * 4096;
-    for (int i = tid; i < 4096; i += 256) out[i] = (dzl[i] + dzl[4096 + i]) + (dzl[8192 + i] + dzl[12288 + i]);
+            for (int r = 0; r < 16; ++r) dzl[wave * 2048 + mfma_row(r, hi) * 64 + ct * 32 + li] = acc[kt][ct][r];
+        __syncthreads();
+        for (int i = tid; i < 2048; i += 256) out[kt * 2048 + i] = (dzl[i] + dzl[2048 + i]) + (dzl[4096 + i] + dzl[6144 + i]);
+    }
 }
 
 int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
                                   const float* coef, float* slab, int* n_slab, int B, int H, int Cin, int pt, int pf) {
-    if (Cin != 7 || pf != 4 || H % pt) return -2;
+    if ((Cin != 7 && Cin != 10) || pf != 4 || H % pt) return -2;
     const int ntiles = B * ((H + 3) / 4);
     const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
-    const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH + 4) * sizeof(float);
-#define LAUNCH_FUSED(PT)                                                                                          \
+#define LAUNCH_FUSED(CI, PT)                                                                                      \
     {                                                                                                             \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_fused_kernel<7, PT>),                  \
+        const size_t smem = (size_t)(256 * 64 + FirstGeom<CI>::PATCH + 4) * sizeof(float);                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_fused_kernel<CI, PT>),                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
-        hipLaunchKernelGGL((conv_first_wgrad_fused_kernel<7, PT>), dim3(grid), dim3(256), smem, st, x, z, p, dp,  \
+        hipLaunchKernelGGL((conv_first_wgrad_fused_kernel<CI, PT>), dim3(grid), dim3(256), smem, st, x, z, p, dp, \
                            coef, slab, B, H);                                                                     \
     }
-    if (pt == 5) LAUNCH_FUSED(5) else if (pt == 4) LAUNCH_FUSED(4) else if (pt == 2) LAUNCH_FUSED(2) else if (pt == 1) LAUNCH_FUSED(1) else return -2;
+#define LAUNCH_FUSED_PT(CI)                                                                                       \
+    if (pt == 5) LAUNCH_FUSED(CI, 5) else if (pt == 4) LAUNCH_FUSED(CI, 4) else if (pt == 2) LAUNCH_FUSED(CI, 2)  \
+    else if (pt == 1) LAUNCH_FUSED(CI, 1) else return -2;
+    if (Cin == 7) { LAUNCH_FUSED_PT(7) } else { LAUNCH_FUSED_PT(10) }
+#undef LAUNCH_FUSED_PT
 #undef LAUNCH_FUSED
     *n_slab = grid;
     return 0;
@@ -651,13 +672,15 @@ int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, flo
                             int B, int H, int Cin) {
     const int ntiles = B * ((H + 3) / 4);
     const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
-    if (Cin == 7) {
-        const size_t smem = (size_t)(256 * 64 + FirstGeom<7>::PATCH + 4) * sizeof(float);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_kernel<7>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(conv_first_wgrad_kernel<7>, dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);
-    } else
-        return -2;
+#define LAUNCH_WG1(CI)                                                                                   \
+    {                                                                                                    \
+        const size_t smem = (size_t)(256 * 64 + FirstGeom<CI>::PATCH + 4) * sizeof(float);               \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_kernel<CI>),                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                      \
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<CI>, dim3(grid), dim3(256), smem, st, x, dz, slab, B, H); \
+    }
+    if (Cin == 7) LAUNCH_WG1(7) else if (Cin == 10) LAUNCH_WG1(10) else return -2;
+#undef LAUNCH_WG1
     *n_slab = grid;
     return 0;
 }

@@ -65,7 +65,7 @@ int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, 
         hipMemcpyAsync(db, tmp + 9 * 4096, 64 * 4, hipMemcpyDeviceToDevice, 0);
     } else if (W == 64) {
         if (launch_conv_first_wgrad(0, x, dz, slab, &ns, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
-        launch_reduce_slabs(0, slab, ns, 4096, tmp, 4096, 0);
+        launch_reduce_slabs(0, slab, ns, conv_first_wgrad_slab_stride(Cin), tmp, (int64_t)(9 * Cin + 1) * 64, 0);
         hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
         hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
     } else return SELD_ERR_UNSUPPORTED;
@@ -82,8 +82,8 @@ int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, cons
     float* coef = s.get(64 * 6);   // mean | invstd | scale | shift | c1 | c2
     float* part = s.get((size_t)bn_partial_capacity() * 128);
     float* pbuf = s.get((size_t)B * (H / pt) * (W / pf) * 64);
-    float* slab = s.get((size_t)conv_wgrad_slab_capacity() * 4096);
-    float* tmp = s.get(4096);
+    float* slab = s.get((size_t)conv_wgrad_slab_capacity() * conv_first_wgrad_slab_stride(Cin));
+    float* tmp = s.get(conv_first_wgrad_slab_stride(Cin));
     if (!coef || !part || !pbuf || !slab || !tmp) return SELD_ERR_NOMEM;
     hipMemcpyAsync(coef, mean, 256, hipMemcpyDeviceToDevice, 0);
     hipMemcpyAsync(coef + 64, invstd, 256, hipMemcpyDeviceToDevice, 0);
@@ -93,7 +93,7 @@ int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, cons
     if (launch_bn_pool_bwd_reduce(0, z, pbuf, dp, coef, coef + 64, coef + 128, coef + 192, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
     launch_bn_bwd_finalize(0, part, np, (double)B * H * W, dgamma, dbeta, coef + 256, C);
     if (launch_conv_first_wgrad_fused(0, x, z, pbuf, dp, coef, slab, &ns, B, H, Cin, pt, pf)) return SELD_ERR_UNSUPPORTED;
-    launch_reduce_slabs(0, slab, ns, 4096, tmp, 4096, 0);
+    launch_reduce_slabs(0, slab, ns, conv_first_wgrad_slab_stride(Cin), tmp, (int64_t)(9 * Cin + 1) * 64, 0);
     hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
     hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
     return done();

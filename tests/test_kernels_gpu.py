@@ -19,7 +19,7 @@ def _conv_ref(x, w, b):
     return F.conv2d(xt, wt, torch.as_tensor(b, dtype=torch.float64), padding=1).permute(0, 2, 3, 1).numpy()
 
 
-@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
 def test_conv_fwd(seld_lib, B, H, W, Cin):
     rng = np.random.default_rng(1)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -51,7 +51,7 @@ def test_conv_dgrad(seld_lib, B, H, W):
     check(f"conv_dgrad {B,H,W}", dx.cpu().numpy(), g.numpy())
 
 
-@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
 def test_conv_wgrad(seld_lib, B, H, W, Cin):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -246,19 +246,19 @@ def test_adam(seld_lib):
     check("adam v", vd.cpu().numpy(), rv.numpy(), tol=1e-6)
 
 
-@pytest.mark.parametrize("B,H", [(2, 50), (1, 20), (2, 15)])
-def test_conv1_bwd_fused(seld_lib, B, H):
+@pytest.mark.parametrize("B,H,CIN", [(2, 50, 7), (1, 20, 7), (2, 15, 7), (2, 25, 10)])
+def test_conv1_bwd_fused(seld_lib, B, H, CIN):
     """conv1 + BN(training) + ReLU + MaxPool(5,4) backward in one fused pass vs autograd (fp64)."""
     rng = np.random.default_rng(12)
-    x = rng.standard_normal((B, H, 64, 7)).astype(np.float32)
-    w = (rng.standard_normal((3, 3, 7, 64)) / np.sqrt(63)).astype(np.float32)
+    x = rng.standard_normal((B, H, 64, CIN)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, CIN, 64)) / np.sqrt(9 * CIN)).astype(np.float32)
     b = rng.standard_normal(64).astype(np.float32) * 0.1
     gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.2, -1, 1)).astype(np.float32)
     beta = rng.normal(0, 0.3, 64).astype(np.float32)
     # forward z on the GPU (so that y == p is evaluated on the same fp32 z the product would see)
     xd, wd, bd = dev(x), dev(w), dev(b)
     zd = torch.empty((B, H, 64, 64), device="cuda")
-    assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(zd), None, B, H, 64, 7, 64) == 0
+    assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(zd), None, B, H, 64, CIN, 64) == 0
     z = zd.cpu().numpy()
     # reference: autograd through conv -> BN(batch stats) -> relu -> pool in fp64, from the same fp32 inputs
     tw = torch.as_tensor(w, dtype=torch.float64).requires_grad_(True)
@@ -274,11 +274,11 @@ def test_conv1_bwd_fused(seld_lib, B, H):
     dp = rng.standard_normal(tuple(p.shape)).astype(np.float32)
     gw, gb, gg, gbe = torch.autograd.grad(p, (tw, tb, tg, tbe), torch.as_tensor(dp, dtype=torch.float64))
     nan = lambda *s: torch.full(s, float("nan"), device="cuda")
-    dw, db, dg, dbe = nan(3, 3, 7, 64), nan(64), nan(64), nan(64)
+    dw, db, dg, dbe = nan(3, 3, CIN, 64), nan(64), nan(64), nan(64)
     md, isd = dev(mean.detach().numpy()), dev(invstd.detach().numpy())
     gd, bed, dpd = dev(gamma), dev(beta), dev(dp)
     assert seld_lib.seld_k_conv1_bwd_fused(ptr(xd), ptr(zd), ptr(dpd), ptr(md), ptr(isd), ptr(gd), ptr(bed), ptr(dw), ptr(db),
-                                           ptr(dg), ptr(dbe), B, H, 7, 5, 4) == 0
+                                           ptr(dg), ptr(dbe), B, H, CIN, 5, 4) == 0
     check(f"conv1_bwd_fused dw {B,H}", dw.cpu().numpy(), gw.numpy())
     check(f"conv1_bwd_fused dgamma {B,H}", dg.cpu().numpy(), gg.numpy())
     check(f"conv1_bwd_fused dbeta {B,H}", dbe.cpu().numpy(), gbe.numpy())
