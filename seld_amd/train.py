@@ -81,3 +81,80 @@ def teststep(model: SeldNet, x, y, sed_loss, doa_loss):
     _lib.check(model.lib.seld_test_step(model.ctx, x.data_ptr(), ys.data_ptr(), yd.data_ptr(), C.byref(cfg),
                                         sed.data_ptr(), doa.data_ptr(), sloss.data_ptr(), dloss.data_ptr()), model.ctx)
     return [sed, doa], sloss, dloss
+
+
+# ---------------------------------------------------------------------------------------------------
+def get_dataset(config, mode: str = 'train'):
+    """reference train.get_dataset (train.py:150-176) without the augmentation branches."""
+    import os
+    from . import data_loader as dl
+    path = os.path.join(config.abspath, 'DCASE2021/feat_label/')
+    x, y = dl.load_seldnet_data(os.path.join(path, 'foa_dev_norm'), os.path.join(path, 'foa_dev_label'), mode=mode, n_freq_bins=64)
+    return dl.seldnet_data_to_dataloader(x, y, train=mode == 'train', label_window_size=60, batch_size=config.batch,
+                                         loop_time=config.loop_time)
+
+
+def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, config, optimizer=None, mode='train', process_group=None):
+    """The step loop of reference train.iterloop (train.py:74-76) -> mean (sed loss, doa loss).
+    SELD metrics, csv dumps and tensorboard (train.py:82-145) are outside the accelerated path; the
+    per-step `.numpy()` host sync of the reference is replaced by one sync per epoch."""
+    loss_weight = [int(i) for i in config.loss_weight.split(',')]
+    tot_s = torch.zeros((), device=model._dev)
+    tot_d = torch.zeros((), device=model._dev)
+    n = 0
+    for x, y in dataset:
+        if mode == 'train':
+            _, sloss, dloss = trainstep(model, x, y, sed_loss, doa_loss, loss_weight, optimizer, config.agc, process_group)
+        else:
+            _, sloss, dloss = teststep(model, x, y, sed_loss, doa_loss)
+        tot_s += sloss
+        tot_d += dloss.mean()
+        n += 1
+    return float(tot_s.item()) / max(n, 1), float(tot_d.item()) / max(n, 1)
+
+
+def main(config, model_config=None, max_epochs=None):
+    """reference train.main (train.py:264-390) around the accelerated steps: datasets, model with
+    n_classes forced to 12, Adam, BCE + MSE|MMSE, and the epoch loop with best-model save, LR decay on
+    plateau and early stopping.  The plateau score is the validation loss (the reference's SELD score
+    needs its metrics/csv tooling, which is out of scope)."""
+    import os
+    from . import models
+    if isinstance(config, tuple):
+        config, model_config = config
+    trainset, valset = get_dataset(config, 'train'), get_dataset(config, 'val')
+    x, y = next(iter(trainset.take(1)))
+    input_shape = (max(config.batch, valset.batch_size),) + tuple(x.shape[1:])
+    model_config = dict(model_config)
+    model_config['n_classes'] = 12                                  # train.py:306-307
+    model = getattr(models, config.model)(input_shape, model_config)
+    model.summary()
+    optimizer = Adam(config.lr)
+    sed_loss = losses.BinaryCrossentropy()
+    doa_loss = losses.get_doa_loss(config.doa_loss)
+    model_path = os.path.join('./saved_model', config.name)
+    os.makedirs(model_path, exist_ok=True)
+    best, early, lr_pat, history = 99999.0, 0, 0, []
+    for epoch in range(config.epoch if max_epochs is None else min(config.epoch, max_epochs)):
+        tr = iterloop(model, trainset, sed_loss, doa_loss, config, optimizer, 'train')
+        va = iterloop(model, valset, sed_loss, doa_loss, config, mode='val')
+        lw = [int(i) for i in config.loss_weight.split(',')]
+        score = va[0] * lw[0] + va[1] * lw[1]
+        history.append({'epoch': epoch, 'train': tr, 'val': va, 'score': score, 'lr': optimizer.learning_rate})
+        print(f'epoch {epoch}: train sed/doa {tr[0]:.4f}/{tr[1]:.5f}  val {va[0]:.4f}/{va[1]:.5f}')
+        if best > score:                                            # train.py:372-380
+            old = os.path.join(model_path, f'bestscore_{best}.npz')
+            if os.path.exists(old):
+                os.remove(old)
+            best, early, lr_pat = score, 0, 0
+            model.save_weights(os.path.join(model_path, f'bestscore_{best}.npz'))
+        else:                                                       # train.py:381-390
+            if lr_pat == config.lr_patience and config.decay != 1:
+                optimizer.learning_rate *= config.decay
+                lr_pat = 0
+            if early == config.patience:
+                print(f'Early Stopping at {epoch}, score is {score}')
+                break
+            early += 1
+            lr_pat += 1
+    return model, history

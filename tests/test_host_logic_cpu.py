@@ -1,0 +1,63 @@
+"""Host-side mirrors of the reference's flag surface and data boundary (no GPU needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import labels_oracle as L
+
+
+def test_get_param_defaults_match_reference(tmp_path, seldnet_config):
+    """params.py:10-51 flag names and defaults; params.py:53-66 model_config resolution and run name."""
+    from seld_amd import params
+    d = tmp_path / "model_config"
+    d.mkdir()
+    (d / "seldnet.json").write_text(json.dumps(seldnet_config))
+    config, mc = params.get_param(["--name", "x"], model_config_dir=str(d))
+    assert (config.lr, config.decay, config.batch, config.agc, config.epoch) == (0.001, 0.5, 256, False, 1000)
+    assert (config.loss_weight, config.lr_patience, config.patience, config.loop_time) == ("1,1000", 80, 100, 5)
+    assert (config.doa_loss, config.model, config.sed_loss, config.lad_doa_thresh) == ("MSE", "seldnet", "BCE", 20)
+    assert config.name == "seldnet_seldnet_MSE_x_v_0" and mc["FIRST"] == "simple_conv_block"
+    with pytest.raises(ValueError):
+        params.get_param(["--name", "x", "--model", "nope"], model_config_dir=str(d))
+    with pytest.raises(ValueError):
+        params.get_param(["--name", "x", "--doa_loss", "MAE"], model_config_dir=str(d))
+    assert params.get_param(["--name", "x", "--agc", "False"], model_config_dir=str(d))[0].agc is True   # type=bool quirk
+
+
+def _write_dataset(root, n_per_fold=1):
+    feat, lab = root / "foa_dev_norm", root / "foa_dev_label"
+    feat.mkdir(parents=True), lab.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for fold in range(1, 7):
+        for k in range(n_per_fold):
+            name = f"fold{fold}_room1_mix{k:03d}.npy"           # 5th character = fold digit (data_loader.py:72-80)
+            np.save(feat / name, rng.standard_normal((3000, 64, 7)).astype(np.float32))
+            y = np.zeros((600, 48), np.float32)
+            y[:, fold] = 1.0
+            np.save(lab / name, y)
+    return str(feat), str(lab)
+
+
+def test_load_and_window(tmp_path):
+    from seld_amd import data_loader as dl
+    feat, lab = _write_dataset(tmp_path, 2)
+    x, y = dl.load_seldnet_data(feat, lab, mode="train")
+    assert len(x) == 8 and x[0].shape == (3000, 64, 7) and y[0].shape == (600, 48)
+    assert len(dl.load_seldnet_data(feat, lab, mode="val")[0]) == 2
+    with pytest.raises(ValueError):
+        dl.load_seldnet_data(str(tmp_path / "missing"), lab)
+    ds = dl.seldnet_data_to_dataloader(x, y, train=True, batch_size=32, loop_time=2, seed=0)
+    batches = list(ds)
+    assert len(batches) == len(ds) == 5                       # 80 windows * 2 loops / 32
+    xb, (sed, doa) = batches[0]
+    assert xb.shape == (32, 300, 64, 7) and sed.shape == (32, 60, 12) and doa.shape == (32, 60, 36)
+    assert sum(b[0].shape[0] for b in batches) == 160
+    # windowing agrees with the oracle restatement of data_loader.py:132-156
+    fw, lw = L.window(x, y)
+    ds1 = dl.seldnet_data_to_dataloader(x, y, train=False)
+    xb, (sed, doa) = next(iter(ds1))
+    assert xb.shape == (10, 300, 64, 7)                        # eval: one file per batch
+    np.testing.assert_array_equal(xb, fw[:10])
+    np.testing.assert_array_equal(np.concatenate([sed, doa], -1), lw[:10])
