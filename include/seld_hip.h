@@ -140,6 +140,15 @@ int seld_frame_windows(const float* x, float* windows, int T, int FC, int win_si
                        void* stream);
 int seld_overlap_average(const float* y, float* out, int n_windows, int L, int D, void* stream);
 
+/* ---- SELD metrics on the device: SELDMetrics.update_states (metrics.py:60-154), which the reference runs in TF
+ * eager mode on the host after every step (train.py:82-83).  `state` = seld_metrics_state_size(nc) doubles
+ * (device, zero to reset): TP FP TN FN S D I Nref Nsys total_DE DE_TP, then class_tp|fp|tn|fn [nc] each;
+ * `scratch` = seld_metrics_scratch_floats(...) floats (device).  y_true / y_pred = (sed [B,S,nc], doa [B,S,3nc]). */
+int seld_metrics_state_size(int n_classes);
+int64_t seld_metrics_scratch_floats(int B, int S, int n_classes, int block_size);
+int seld_metrics_update(const float* sed_true, const float* doa_true, const float* sed_pred, const float* doa_pred, int B, int S,
+                        int n_classes, int block_size, float doa_threshold, double* state, float* scratch, void* stream);
+
 /* ---- measurement: HIP-event timing of named kernel groups on the ctx stream (bench.py roofline).
  * seld_profile_enable(ctx, level): 0 off, 1 the four largest groups (conv1 fwd / conv1 wgrad / GRU fwd / GRU BPTT), 2 every group */
 int seld_profile_enable(seld_ctx* ctx, int on);

@@ -7,6 +7,6 @@ Mirrors the interface of the reference IRIS-AUDIO/SELD for this path:
 PyTorch is used for device buffers, streams and torch.distributed only.
 """
 from . import _lib  # noqa: F401
-from . import losses, models, parallel, train  # noqa: F401
+from . import losses, metrics, models, parallel, train  # noqa: F401
 
 __all__ = ["models", "losses", "train"]

@@ -426,6 +426,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
 
 int seld_forward(seld_ctx* c, const float* x, float* sed, float* doa, int training) {
     if (!c || !x) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     return forward_impl(c, x, sed, doa, training, false);
 }
 
@@ -453,6 +454,7 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
 
 int seld_mmse_den(seld_ctx* c, const float* y_doa, float* den) {
     if (!c || !y_doa || !den) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     launch_mmse_den(c->stream, y_doa, den, c->loss_scratch, c->B * c->S, c->arch.n_classes);
     return check_launch(c, "mmse_den");
 }
@@ -460,6 +462,7 @@ int seld_mmse_den(seld_ctx* c, const float* y_doa, float* den) {
 int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
                    float* sed, float* doa, float* sloss, float* dloss) {
     if (!c || !x || !y_sed || !y_doa || !cfg) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     int rc = forward_impl(c, x, sed, doa, 0, false);
     if (rc) return rc;
     return run_losses(c, y_sed, y_doa, cfg, sloss, dloss, false);
@@ -594,6 +597,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
 int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
                        float* sed, float* doa, float* sloss, float* dloss) {
     if (!c || !x || !y_sed || !y_doa || !cfg) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     int rc = forward_impl(c, x, sed, doa, 1, true);
     if (rc) return rc;
     rc = run_losses(c, y_sed, y_doa, cfg, sloss, dloss, true);
@@ -603,6 +607,7 @@ int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const fl
 
 int seld_adam_step(seld_ctx* c, float lr, float beta1, float beta2, float eps, int agc) {
     if (!c) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     if (agc)
         for (auto& v : c->tr) launch_agc(c->stream, c->params, c->grads, v.off, v.rank, v.shape, nullptr);
     c->adam_step += 1;

@@ -94,31 +94,38 @@ def get_dataset(config, mode: str = 'train'):
                                          loop_time=config.loop_time)
 
 
-def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, config, optimizer=None, mode='train', process_group=None):
-    """The step loop of reference train.iterloop (train.py:74-76) -> mean (sed loss, doa loss).
-    SELD metrics, csv dumps and tensorboard (train.py:82-145) are outside the accelerated path; the
-    per-step `.numpy()` host sync of the reference is replaced by one sync per epoch."""
+def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, metric_class, config, optimizer=None, mode='train',
+             process_group=None):
+    """The step loop of reference train.iterloop (train.py:47-147) -> (mean sed loss, mean doa loss, seld score).
+    `metric_class` (seld_amd.metrics.SELDMetrics or None) is updated on the device after every step, as the
+    reference does on the host (train.py:82-83); csv dumps / DCASE official metrics / tensorboard
+    (train.py:85-145) are outside the accelerated path.  One host sync per epoch instead of one per step."""
+    from . import metrics as _metrics
     loss_weight = [int(i) for i in config.loss_weight.split(',')]
     tot_s = torch.zeros((), device=model._dev)
     tot_d = torch.zeros((), device=model._dev)
     n = 0
     for x, y in dataset:
         if mode == 'train':
-            _, sloss, dloss = trainstep(model, x, y, sed_loss, doa_loss, loss_weight, optimizer, config.agc, process_group)
+            preds, sloss, dloss = trainstep(model, x, y, sed_loss, doa_loss, loss_weight, optimizer, config.agc, process_group)
         else:
-            _, sloss, dloss = teststep(model, x, y, sed_loss, doa_loss)
+            preds, sloss, dloss = teststep(model, x, y, sed_loss, doa_loss)
+        if metric_class is not None:
+            metric_class.update_states(y, preds)
         tot_s += sloss
         tot_d += dloss.mean()
         n += 1
-    return float(tot_s.item()) / max(n, 1), float(tot_d.item()) / max(n, 1)
+    score = _metrics.calculate_seld_score(metric_class.result()) if metric_class is not None else float('nan')
+    return float(tot_s.item()) / max(n, 1), float(tot_d.item()) / max(n, 1), score
 
 
 def main(config, model_config=None, max_epochs=None):
     """reference train.main (train.py:264-390) around the accelerated steps: datasets, model with
-    n_classes forced to 12, Adam, BCE + MSE|MMSE, and the epoch loop with best-model save, LR decay on
-    plateau and early stopping.  The plateau score is the validation loss (the reference's SELD score
-    needs its metrics/csv tooling, which is out of scope)."""
+    n_classes forced to 12, Adam, BCE + MSE|MMSE, SELDMetrics, and the epoch loop with best-model save, LR
+    decay on plateau and early stopping on the validation SELD score (block-wise metrics.SELDMetrics score;
+    the reference's csv-based DCASE scorer is out of scope)."""
     import os
+    from . import metrics as _metrics
     from . import models
     if isinstance(config, tuple):
         config, model_config = config
@@ -126,22 +133,25 @@ def main(config, model_config=None, max_epochs=None):
     x, y = next(iter(trainset.take(1)))
     input_shape = (max(config.batch, valset.batch_size),) + tuple(x.shape[1:])
     model_config = dict(model_config)
-    model_config['n_classes'] = 12                                  # train.py:306-307
+    n_classes = 12                                                  # train.py:306-307
+    model_config['n_classes'] = n_classes
     model = getattr(models, config.model)(input_shape, model_config)
     model.summary()
     optimizer = Adam(config.lr)
     sed_loss = losses.BinaryCrossentropy()
     doa_loss = losses.get_doa_loss(config.doa_loss)
+    metric_class = _metrics.SELDMetrics(doa_threshold=config.lad_doa_thresh, n_classes=n_classes)
     model_path = os.path.join('./saved_model', config.name)
     os.makedirs(model_path, exist_ok=True)
     best, early, lr_pat, history = 99999.0, 0, 0, []
     for epoch in range(config.epoch if max_epochs is None else min(config.epoch, max_epochs)):
-        tr = iterloop(model, trainset, sed_loss, doa_loss, config, optimizer, 'train')
-        va = iterloop(model, valset, sed_loss, doa_loss, config, mode='val')
-        lw = [int(i) for i in config.loss_weight.split(',')]
-        score = va[0] * lw[0] + va[1] * lw[1]
+        metric_class.reset_states()
+        tr = iterloop(model, trainset, sed_loss, doa_loss, metric_class, config, optimizer, 'train')
+        metric_class.reset_states()
+        va = iterloop(model, valset, sed_loss, doa_loss, metric_class, config, mode='val')
+        score = va[2]
         history.append({'epoch': epoch, 'train': tr, 'val': va, 'score': score, 'lr': optimizer.learning_rate})
-        print(f'epoch {epoch}: train sed/doa {tr[0]:.4f}/{tr[1]:.5f}  val {va[0]:.4f}/{va[1]:.5f}')
+        print(f'epoch {epoch}: train sed/doa/seld {tr[0]:.4f}/{tr[1]:.5f}/{tr[2]:.4f}  val {va[0]:.4f}/{va[1]:.5f}/{va[2]:.4f}')
         if best > score:                                            # train.py:372-380
             old = os.path.join(model_path, f'bestscore_{best}.npz')
             if os.path.exists(old):

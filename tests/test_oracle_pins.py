@@ -166,3 +166,26 @@ def test_frame_and_overlap_average_semantics():
     np.testing.assert_allclose(out[:, 0], 1.0)
     np.testing.assert_allclose(out[0, 1], 0.0)
     np.testing.assert_allclose(out[100, 1], np.mean(np.arange(41, 101)))
+
+
+def test_metrics_oracle_hand_worked_case():
+    """metrics.py:60-154 on a case small enough to work by hand: 1 clip, 1 block of 2 frames, 3 classes.
+    class 0: active + detected, prediction 10 deg off -> TP;  class 1: active, missed -> FN;
+    class 2: inactive, predicted -> FP.  => S = min(FP=1, FN=1) = 1, D = I = 0, ER = 1/2, F = 1/2... """
+    from oracle import metrics_oracle as MO
+    m = MO.SELDMetrics(doa_threshold=20, block_size=10, n_classes=3)
+    sed_t = np.array([[[1, 1, 0], [1, 0, 0]]], float)
+    sed_p = np.array([[[0.9, 0.1, 0.8], [0.7, 0.2, 0.1]]], float)
+    v = lambda az: [np.cos(np.deg2rad(az)), np.sin(np.deg2rad(az)), 0.0]
+    doa_t = np.zeros((1, 2, 3, 3)); doa_p = np.zeros((1, 2, 3, 3))
+    for f in range(2):
+        doa_t[0, f, :, 0] = v(30); doa_p[0, f, :, 0] = v(40)
+    doa_t[0, 0, :, 1] = v(100)
+    doa_p[0, 0, :, 2] = v(-50)
+    m.update_states((sed_t, doa_t.reshape(1, 2, 9)), (sed_p, doa_p.reshape(1, 2, 9)))
+    assert (m.TP, m.FP, m.FN, m.TN) == (1, 1, 1, 0)
+    assert (m.S, m.D, m.I, m.Nref, m.Nsys, m.DE_TP) == (1, 0, 0, 2, 2, 1)
+    np.testing.assert_allclose(m.total_DE, 10.0, atol=1e-9)
+    ER, F, DE, DE_F = m.result()
+    np.testing.assert_allclose([ER, F, DE, DE_F], [0.5, 0.5, 10.0, 0.5], atol=1e-9)
+    np.testing.assert_allclose(MO.calculate_seld_score((ER, F, DE, DE_F)), (0.5 + 0.5 + 10 / 180 + 0.5) / 4)
