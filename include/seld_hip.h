@@ -73,6 +73,10 @@ int seld_set_stream(seld_ctx* ctx, void* hip_stream);
  * accepts any batch; data_loader.batch(drop_remainder=False) yields a short last batch) */
 int seld_set_batch(seld_ctx* ctx, int B);
 int seld_sync(seld_ctx* ctx);
+/* compute options.  "conv64_split_bf16" (default 1): conv2/conv3 forward and input gradient run on the bf16 matrix
+ * cores with every fp32 operand split exactly into three bf16 values and six partial products (fp32-level accuracy);
+ * 0 selects the f32-input MFMA kernels. */
+int seld_set_option(seld_ctx* ctx, const char* key, int value);
 
 /* ---- variables: replaces model.trainable_variables / get_weights / set_weights
  * (train.py:31-34, evaluator.py:57).  Flat fp32, Keras creation order; seld_variable_info
@@ -159,6 +163,7 @@ int seld_profile_reset(seld_ctx* ctx);
 /* ---- per-kernel entry points (unit parity tests; all device pointers, null stream) --------
  * Each cites what it computes in the reference.  Shapes are checked; SELD_ERR_UNSUPPORTED if
  * the build has no kernel for them. */
+int seld_k_set_option(const char* key, int value); /* same keys as seld_set_option, for the seld_k_* entry points */
 /* Conv2D(64, 3, padding='same', use_bias=True) on NHWC (layers.py:27-32); x [B,H,W,Cin], w HWIO, z [B,H,W,64].
  * stats (may be NULL): [2*64] = per-channel sum(z), sum(z^2) over B*H*W (BatchNormalization batch statistics). */
 int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float* z, float* stats,

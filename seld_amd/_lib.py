@@ -57,6 +57,8 @@ SIGNATURES = {
     "seld_set_stream": (_I, [_P, _P]),
     "seld_set_batch": (_I, [_P, _I]),
     "seld_sync": (_I, [_P]),
+    "seld_set_option": (_I, [_P, C.c_char_p, _I]),
+    "seld_k_set_option": (_I, [C.c_char_p, _I]),
     "seld_param_count": (_L, [_P]),
     "seld_state_count": (_L, [_P]),
     "seld_variable_count": (_I, [_P, _I]),

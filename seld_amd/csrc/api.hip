@@ -54,6 +54,8 @@ struct seld_ctx {
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
+    unsigned short* wsplit = nullptr;      // [9][3][64][64] bf16 planes of the current conv64 weights (split-bf16 mode)
+    int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
@@ -247,6 +249,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
+    ALLOC(c->wsplit, 9 * 3 * 4096);
     const size_t rows = (size_t)B * S;
     for (int i = 0; i < a->n_gru; ++i) {
         GruL& G = c->gru[i];
@@ -291,6 +294,11 @@ int seld_set_batch(seld_ctx* c, int B) {
     if (B < 1 || B > c->Bmax) return fail(c, SELD_ERR_INVALID, "batch exceeds the size given to seld_create");
     c->B = B;
     return SELD_OK;
+}
+int seld_set_option(seld_ctx* c, const char* key, int value) {
+    if (!c || !key) return SELD_ERR_INVALID;
+    if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
+    return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 int seld_sync(seld_ctx* c) {
     if (!c) return SELD_ERR_INVALID;
@@ -366,7 +374,11 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
         } else {
             PROF2(c, tn);
-            if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
+            if (c->conv64_split_bf16) {
+                launch_split_weights(st, c->params + L.w_off, c->wsplit);
+                if (launch_conv64_fwd_sb(st, in, c->wsplit, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
+                    return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd_sb");
+            } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
         if (training)
@@ -583,7 +595,11 @@ static int backward_impl(seld_ctx* c, const float* x) {
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
                 PROF2(c, tn);
-                launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+                if (c->conv64_split_bf16) {
+                    launch_split_weights(st, c->wflip, c->wsplit);
+                    launch_conv64_fwd_sb(st, c->dzbuf, c->wsplit, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+                } else
+                    launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
             }
             dp = c->conv[i - 1].dp;
         }

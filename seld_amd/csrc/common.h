@@ -44,7 +44,12 @@ int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* 
                         int B, int H, int W);
 int conv_wgrad_slab_capacity();
 int conv_first_wgrad_slab_stride(int Cin);   // floats per first-layer wgrad slab: rows 0..9*Cin-1 kernel, row 9*Cin bias
-int launch_flip_weights(hipStream_t st, const float* w, float* wt);  // [3,3,64,64] -> dgrad weights
+int launch_flip_weights(hipStream_t st, const float* w, float* wt);
+// split-bf16 conv (conv_sb.hip): w [9][in][out] fp32 -> planes [9][3][out][in] bf16; conv with 6 bf16 MFMAs per product
+int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp);
+int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
+                         float* stat_partial, int* n_partial, int B, int H, int W);
+int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
                         int64_t n, int accumulate);
 

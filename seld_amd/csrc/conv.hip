@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             C64_ISSUE(tap < 8 ? tap + 1 : 8)   // unconditional (tap 8 re-reads itself): no phi on the staged registers
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA loop
             {
                 // 2-step operand ring pinned with sched_barrier (each step = 2 MFMAs = 128 pipe cycles)
                 float qa[2], qb0[2], qb1[2];
@@ -299,11 +300,11 @@ __global__ __launch_bounds__(256) void conv64_fwd_kernel(const float* __restrict
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (tap < 8) {
-                lds_barrier();
-                C64_COMMIT()
-                lds_barrier();
-            }
+            // unconditional commit (tap 8 re-commits itself): with the staged registers used only inside an
+            // `if (tap < 8)` block the compiler sank the global loads behind the barrier
+            lds_barrier();
+            C64_COMMIT()
+            lds_barrier();
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {

@@ -1,0 +1,410 @@
+// conv_sb.hip — Cin = Cout = 64 3x3 'same' convolution (layers.py:27-32) on the bf16 matrix cores at fp32
+// accuracy: "split-bf16" operands.
+//
+// Every fp32 operand is split EXACTLY into three bf16 values by truncation, x = hi + mid + lo (8 + 8 + 8
+// significant bits), and a product a*b is accumulated in fp32 from the six partial products
+//   hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid
+// on v_mfma_f32_32x32x16_bf16.  The three dropped terms (mid*lo, lo*mid, lo*lo) are <= 2^-24 relative, the
+// same size as one fp32 rounding, so the result meets the fp32 parity bar, while the MFMA work per MAC is
+// 6/16 of v_mfma_f32_32x32x2_f32 (the f32-input MFMA runs at 1/16 of the bf16 rate).
+//
+// Tile: 256 pixels x 64 output channels per 512-thread block (8 waves, wave w = pixel rows 32w..32w+31 x both
+// co-tiles).  Per tap: the fp32 A tile [256 px][64 ci] is prefetched into registers during the previous tap's
+// MFMAs, split at commit time into three bf16 planes in LDS (row stride 144 B: conflict-free 16-B fragment
+// reads); the tap's weights come pre-split and pre-transposed ([co][ci]) from split_weights_kernel.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define SB_LD 72                    // bf16 elements per LDS row: 64 + 8 pad (144 B)
+#define SB_A_ELEMS (3 * 256 * SB_LD)
+#define SB_W_ELEMS (3 * 64 * SB_LD)
+#define SB_MAX_PERSISTENT 512
+
+int conv_sb_partial_capacity() { return SB_MAX_PERSISTENT; }
+
+// exact 3-way truncation split of two floats, packed as bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+
+// w [9][in 64][out 64] fp32 -> planes [9][3][out 64][in 64] bf16 (transposed so a B fragment is 8 contiguous k)
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 9 * 4096) return;
+    const int tap = idx >> 12, rem = idx & 4095, out = rem >> 6, in = rem & 63;
+    const float x = w[tap * 4096 + in * 64 + out];
+    const unsigned u = __float_as_uint(x);
+    const float r = x - __uint_as_float(u & 0xffff0000u);
+    const unsigned v = __float_as_uint(r);
+    const float s = r - __uint_as_float(v & 0xffff0000u);
+    unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;
+    o[0] = (unsigned short)(u >> 16);
+    o[4096] = (unsigned short)(v >> 16);
+    o[2 * 4096] = (unsigned short)(__float_as_uint(s) >> 16);
+}
+
+int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp) {
+    hipLaunchKernelGGL(split_weights_kernel, dim3(9 * 4096 / 256), dim3(256), 0, st, w, wsp);
+    return 0;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(512) void conv64_fwd_sb_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wsp,
+                                                            const float* __restrict__ bias, float* __restrict__ z,
+                                                            float* __restrict__ stat_partial, int npix, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
+    unsigned short* Ap = sb_smem;                  // [3][256][SB_LD]
+    unsigned short* Wp = sb_smem + SB_A_ELEMS;     // [3][64][SB_LD]
+    float* red = reinterpret_cast<float*>(sb_smem + SB_A_ELEMS + SB_W_ELEMS);   // [8][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, li = lane & 31;
+    const int ntiles = (npix + 255) >> 8;
+    const int g4 = (tid & 15) * 4;   // channel group of this thread's staging loads
+    const int pxs = tid >> 4;        // staging pixel slot (0..31), pixels pxs + 32u
+    const int wrow = tid >> 3, wchunk = (tid & 7) * 8;   // weight staging: row co, 8 bf16 per uint4
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float4 ar[8];
+    uint4 wr[3];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p0 = tile << 8;
+        unsigned vmask[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + pxs + 32 * u;
+            unsigned m = 0;
+            if (p < npix) {
+                const int f = p % W, t = (p / W) % H;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dt = tap / 3 - 1, df = tap % 3 - 1;
+                    if (t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W) m |= 1u << tap;
+                }
+            }
+            vmask[u] = m;
+        }
+#define SB_ISSUE(tap_)                                                                                          \
+    {                                                                                                           \
+        const int tp_ = (tap_);                                                                                 \
+        const int shift_ = (tp_ / 3 - 1) * W + (tp_ % 3 - 1);                                                   \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                         \
+            const bool ok_ = (vmask[u] >> tp_) & 1u;                                                            \
+            const float4 v_ = *reinterpret_cast<const float4*>(x + (size_t)(ok_ ? p0 + pxs + 32 * u + shift_ : 0) * 64 + g4); \
+            ar[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                        \
+            wr[pl] = reinterpret_cast<const uint4*>(wsp + ((size_t)tp_ * 3 + pl) * 4096)[tid];                  \
+    }
+#define SB_COMMIT()                                                                                             \
+    {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                         \
+            unsigned h0, m0, l0, h1, m1, l1;                                                                    \
+            split3_pair(ar[u].x, ar[u].y, h0, m0, l0);                                                          \
+            split3_pair(ar[u].z, ar[u].w, h1, m1, l1);                                                          \
+            unsigned short* d_ = Ap + (pxs + 32 * u) * SB_LD + g4;                                              \
+            *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                                 \
+            *reinterpret_cast<uint2*>(d_ + 256 * SB_LD) = make_uint2(m0, m1);                                   \
+            *reinterpret_cast<uint2*>(d_ + 2 * 256 * SB_LD) = make_uint2(l0, l1);                               \
+        }                                                                                                       \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                        \
+            *reinterpret_cast<uint4*>(Wp + pl * 64 * SB_LD + wrow * SB_LD + wchunk) = wr[pl];                   \
+    }
+        SB_ISSUE(0)
+        lds_barrier();   // previous tile's readers are done
+        SB_COMMIT()
+        lds_barrier();
+        f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            SB_ISSUE(tap < 8 ? tap + 1 : 8)   // unconditional (tap 8 re-reads itself): no phi on the staged registers
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short* arow = Ap + (wave * 32 + li) * SB_LD + 8 * hi;
+            const unsigned short* wrow0 = Wp + li * SB_LD + 8 * hi;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[3], b[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * 256 * SB_LD + 16 * s);
+                    b[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 16 * s);
+                    b[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 32 * SB_LD + 16 * s);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][c], acc[c], 0, 0, 0);   // hi*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][c], acc[c], 0, 0, 0);   // hi*mid
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][c], acc[c], 0, 0, 0);   // mid*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][c], acc[c], 0, 0, 0);   // hi*lo
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][c], acc[c], 0, 0, 0);   // lo*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][c], acc[c], 0, 0, 0);   // mid*mid
+                }
+            }
+            lds_barrier();      // unconditional commit (see conv64_fwd_sbr_kernel): tap 8 re-commits itself
+            SB_COMMIT()
+            lds_barrier();
+        }
+#undef SB_ISSUE
+#undef SB_COMMIT
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float bv = bias ? bias[c * 32 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + wave * 32 + mfma_row(r, hi);
+                if (p < npix) {
+                    const float v = acc[c][r] + bv;
+                    z[(size_t)p * 64 + c * 32 + li] = v;
+                    s1[c] += v;
+                    s2[c] = fmaf(v, v, s2[c]);
+                }
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        __syncthreads();
+        if (hi == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) t += red[w8 * 128 + tid];
+            stat_partial[(size_t)blockIdx.x * 128 + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Halo-region variant: a tile is R full image rows x W columns (TP = R*W pixels, one wave per 32 pixels).
+// The (R+2) x (W+2) input region is loaded ONCE per tile (prefetched into registers under the previous
+// tile's MFMAs), split into the three bf16 planes once, and all 9 taps read their A fragments from it at
+// shifted pixel rows; only the 27 KB of pre-split weights change per tap.
+template <int WLOG2, int R, bool STATS>
+__global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
+    float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
+    constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
+    constexpr int RW = W + 2, RR = R + 2, NPIX = RR * RW;
+    constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
+    constexpr int NW4 = 3 * 64 * 8, NWF = (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
+    static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
+    unsigned short* Rp = sb_smem;                          // [3][NPIX][SB_LD]
+    unsigned short* Wp = sb_smem + 3 * NPIX * SB_LD;       // [3][64][SB_LD]
+    float* red = reinterpret_cast<float*>(Wp + SB_W_ELEMS);   // [NW][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, li = lane & 31;
+    const int tiles_per_img = (H + R - 1) / R;
+    const int ntiles = B * tiles_per_img;
+    // static part of this thread's region slots
+    int roff[NPF];        // float offset relative to the tile's first pixel (may be negative: halo)
+    int rrow[NPF];  // region row (image row = t0 - 1 + rrow), -1 = slot unused / outside the image columns
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = tid + NT * u;
+        const int pix = idx >> 4, g = idx & 15;
+        const int rr = pix / RW, cc = pix - rr * RW;
+        const bool ok = idx < NREG4 && cc >= 1 && cc <= W;
+        rrow[u] = ok ? rr : -1;
+        roff[u] = ((rr - 1) * W + (cc - 1)) * 64 + g * 4;
+    }
+    float4 rreg[NPF];
+    static_assert(NWF == 4, "weight staging is four named registers");
+    u32x4 wreg0, wreg1, wreg2, wreg3;      // named (an indexed array of these was demoted to scratch)
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#define SBR_ISSUE_REGION(tile_)                                                                         \
+    {                                                                                                   \
+        const int tb_ = (tile_) / tiles_per_img, tt0_ = ((tile_) - tb_ * tiles_per_img) * R;            \
+        const float* org_ = x + (size_t)(tb_ * H + tt0_) * W * 64;                                      \
+        _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                               \
+            const int t_ = tt0_ - 1 + rrow[u];                                                          \
+            const bool ok_ = rrow[u] >= 0 && t_ >= 0 && t_ < H;                                         \
+            const float4 v_ = *reinterpret_cast<const float4*>(ok_ ? org_ + roff[u] : x);               \
+            rreg[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+        }                                                                                               \
+    }
+#define SBR_COMMIT_REGION()                                                                             \
+    _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                   \
+        const int idx = tid + NT * u;                                                                   \
+        if (idx < NREG4) {                                                                              \
+            unsigned h0, m0, l0, h1, m1, l1;                                                            \
+            split3_pair(rreg[u].x, rreg[u].y, h0, m0, l0);                                              \
+            split3_pair(rreg[u].z, rreg[u].w, h1, m1, l1);                                              \
+            unsigned short* d_ = Rp + (idx >> 4) * SB_LD + (idx & 15) * 4;                              \
+            *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                         \
+            *reinterpret_cast<uint2*>(d_ + NPIX * SB_LD) = make_uint2(m0, m1);                          \
+            *reinterpret_cast<uint2*>(d_ + 2 * NPIX * SB_LD) = make_uint2(l0, l1);                      \
+        }                                                                                               \
+    }
+#define SBR_W_SRC(tap_, u_) \
+    reinterpret_cast<const u32x4*>(wsp + (size_t)(tap_) * 3 * 4096)[(tid + NT * (u_)) < NW4 ? (tid + NT * (u_)) : 0]
+#define SBR_ISSUE_W(tap_)                                                                               \
+    {                                                                                                   \
+        wreg0 = SBR_W_SRC(tap_, 0);                                                                     \
+        wreg1 = SBR_W_SRC(tap_, 1);                                                                     \
+        wreg2 = SBR_W_SRC(tap_, 2);                                                                     \
+        wreg3 = SBR_W_SRC(tap_, 3);                                                                     \
+    }
+#define SBR_W_DST(u_, v_)                                                                               \
+    {                                                                                                   \
+        const int idx = tid + NT * (u_);                                                                \
+        if (idx < NW4) {                                                                                \
+            const int pl = idx >> 9, rem = idx & 511;      /* 512 uint4 per plane: row = rem>>3 */      \
+            *reinterpret_cast<u32x4*>(Wp + pl * 64 * SB_LD + (rem >> 3) * SB_LD + (rem & 7) * 8) = v_;  \
+        }                                                                                               \
+    }
+#define SBR_COMMIT_W()                                                                                  \
+    {                                                                                                   \
+        SBR_W_DST(0, wreg0)                                                                             \
+        SBR_W_DST(1, wreg1)                                                                             \
+        SBR_W_DST(2, wreg2)                                                                             \
+        SBR_W_DST(3, wreg3)                                                                             \
+    }
+    int tile = blockIdx.x;
+    // region row of this lane's pixel for tap (0,0): pixel p = 32*wave + li of the tile -> (r, c)
+    const int pl_ = wave * 32 + li;
+    const int rbase = ((pl_ >> WLOG2) * RW + (pl_ & (W - 1))) * SB_LD + 8 * hi;
+    if (tile < ntiles) {
+        SBR_ISSUE_REGION(tile)
+        SBR_ISSUE_W(0)
+        SBR_COMMIT_REGION()
+        SBR_COMMIT_W()
+    }
+    lds_barrier();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * R;
+        const int nxt = tile + gridDim.x;
+        SBR_ISSUE_REGION(nxt < ntiles ? nxt : tile)     // unconditional: no phi on the staged registers
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2] = {zero16(), zero16()};
+        const unsigned short* wrow0 = Wp + li * SB_LD + 8 * hi;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            SBR_ISSUE_W(tap < 8 ? tap + 1 : 0)          // tap 8 prefetches tap 0 of the next tile
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads ahead of the MFMA steps
+            const unsigned short* arow = Rp + rbase + ((tap / 3) * RW + (tap % 3)) * SB_LD;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[3], bb[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * NPIX * SB_LD + 16 * s);
+                    bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 16 * s);
+                    bb[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 32 * SB_LD + 16 * s);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0][c], acc[c], 0, 0, 0);   // hi*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1][c], acc[c], 0, 0, 0);   // hi*mid
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0][c], acc[c], 0, 0, 0);   // mid*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2][c], acc[c], 0, 0, 0);   // hi*lo
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0][c], acc[c], 0, 0, 0);   // lo*hi
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1][c], acc[c], 0, 0, 0);   // mid*mid
+                }
+            }
+            // The commit is UNCONDITIONAL (after tap 8 it stores tap 0 of the next tile): when the staged
+            // registers were only used inside an `if (tap < 8)` block the compiler sank the global loads
+            // into that block, i.e. behind the barrier, and every tap paid a full L2 round trip.
+            lds_barrier();
+            SBR_COMMIT_W()
+            lds_barrier();
+        }
+        SBR_COMMIT_REGION()     // next tile's region (every wave passed the barrier after tap 8's reads)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float bv = bias ? bias[c * 32 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 32 + mfma_row(r, hi);          // pixel of the tile
+                const int t = t0 + (p >> WLOG2);
+                if (t < H) {
+                    const float v = acc[c][r] + bv;
+                    z[((size_t)(b * H + t) * W + (p & (W - 1))) * 64 + c * 32 + li] = v;
+                    s1[c] += v;
+                    s2[c] = fmaf(v, v, s2[c]);
+                }
+            }
+        }
+        lds_barrier();          // the committed region is visible to every wave
+    }
+#undef SBR_ISSUE_REGION
+#undef SBR_COMMIT_REGION
+#undef SBR_ISSUE_W
+#undef SBR_COMMIT_W
+#undef SBR_W_SRC
+#undef SBR_W_DST
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        __syncthreads();
+        if (hi == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * 128 + tid];
+            stat_partial[(size_t)blockIdx.x * 128 + tid] = t;
+        }
+    }
+}
+
+template <int WLOG2, int R>
+static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
+                      float* stat_partial, int* n_partial, int B, int H) {
+    constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * (W + 2);
+    const int ntiles = B * ((H + R - 1) / R);
+    const int grid = ntiles < 256 ? ntiles : 256;      // one block per CU (LDS-limited), persistent
+    const size_t smem = (size_t)(3 * NPIX * SB_LD + SB_W_ELEMS) * sizeof(unsigned short) + (size_t)NW * 128 * sizeof(float);
+    if (stat_partial) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, false>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+    }
+    if (n_partial) *n_partial = grid;
+    return 0;
+}
+
+int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
+                         float* stat_partial, int* n_partial, int B, int H, int W) {
+    if (W == 16) return launch_sbr<4, 14>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);
+    if (W == 4) return launch_sbr<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);
+    const int npix = B * H * W;
+    const int ntiles = (npix + 255) / 256;
+    const int grid = ntiles < SB_MAX_PERSISTENT ? ntiles : SB_MAX_PERSISTENT;
+    const size_t smem = (size_t)(SB_A_ELEMS + SB_W_ELEMS) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
+    if (stat_partial) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sb_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(conv64_fwd_sb_kernel<true>, dim3(grid), dim3(512), smem, st, x, wsp, bias, z, stat_partial, npix, H, W);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sb_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(conv64_fwd_sb_kernel<false>, dim3(grid), dim3(512), smem, st, x, wsp, bias, z, stat_partial, npix, H, W);
+    }
+    if (n_partial) *n_partial = grid;
+    return 0;
+}

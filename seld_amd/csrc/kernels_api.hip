@@ -5,8 +5,10 @@
 #include "../../include/seld_hip.h"
 #include <vector>
 #include <math.h>
+#include <string.h>
 
 namespace {
+int g_conv64_split_bf16 = 1;
 struct Scratch {
     std::vector<void*> p;
     float* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, n * sizeof(float) + 256) != hipSuccess) return nullptr; p.push_back(q); return (float*)q; }
@@ -26,6 +28,12 @@ __global__ void coeffs_kernel(const float* mean, const float* invstd, const floa
 
 extern "C" {
 
+int seld_k_set_option(const char* key, int value) {
+    if (!key) return SELD_ERR_INVALID;
+    if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
+    return SELD_ERR_INVALID;
+}
+
 int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float* z, float* stats, int B, int H, int W,
                        int Cin, int Cout) {
     if (!x || !w || !z || Cout != 64) return SELD_ERR_UNSUPPORTED;
@@ -33,7 +41,12 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
     float* part = stats ? s.get((size_t)conv_stat_partial_capacity() * 128) : nullptr;
     if (stats && !part) return SELD_ERR_NOMEM;
     int np = 0, rc;
-    if (Cin == 64) rc = launch_conv64_fwd(0, x, w, bias, z, part, &np, B, H, W);
+    if (Cin == 64 && g_conv64_split_bf16) {
+        unsigned short* wsp = reinterpret_cast<unsigned short*>(s.get(9 * 3 * 4096 / 2 + 16));
+        if (!wsp) return SELD_ERR_NOMEM;
+        launch_split_weights(0, w, wsp);
+        rc = launch_conv64_fwd_sb(0, x, wsp, bias, z, part, &np, B, H, W);
+    } else if (Cin == 64) rc = launch_conv64_fwd(0, x, w, bias, z, part, &np, B, H, W);
     else if (W == 64) rc = launch_conv_first_fwd(0, x, w, bias, z, part, &np, B, H, Cin);
     else return SELD_ERR_UNSUPPORTED;
     if (rc) return SELD_ERR_UNSUPPORTED;
@@ -47,7 +60,13 @@ int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int 
     float* wt = s.get(9 * 4096);
     if (!wt) return SELD_ERR_NOMEM;
     launch_flip_weights(0, w, wt);
-    launch_conv64_fwd(0, dz, wt, nullptr, dx, nullptr, nullptr, B, H, W);
+    if (g_conv64_split_bf16) {
+        unsigned short* wsp = reinterpret_cast<unsigned short*>(s.get(9 * 3 * 4096 / 2 + 16));
+        if (!wsp) return SELD_ERR_NOMEM;
+        launch_split_weights(0, wt, wsp);
+        launch_conv64_fwd_sb(0, dz, wsp, nullptr, dx, nullptr, nullptr, B, H, W);
+    } else
+        launch_conv64_fwd(0, dz, wt, nullptr, dx, nullptr, nullptr, B, H, W);
     return done();
 }
 

@@ -26,17 +26,20 @@ def test_conv_fwd(seld_lib, B, H, W, Cin):
     w = (rng.standard_normal((3, 3, Cin, 64)) / np.sqrt(9 * Cin)).astype(np.float32)
     b = rng.standard_normal(64).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
-    z = torch.full((B, H, W, 64), float("nan"), device="cuda")
-    st = torch.zeros(128, device="cuda")
-    assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(z), ptr(st), B, H, W, Cin, 64) == 0
     ref = _conv_ref(x, w, b)
-    check(f"conv_fwd z {B,H,W,Cin}", z.cpu().numpy(), ref)
-    s = st.cpu().numpy()
-    check("conv_fwd sum(z)", s[:64], ref.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref.size / 64))
-    check("conv_fwd sum(z^2)", s[64:], (ref ** 2).sum(axis=(0, 1, 2)))
+    for mode in ((1, 0) if Cin == 64 else (1,)):     # Cin = 64: split-bf16 (default) and f32-MFMA kernels
+        assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
+        z = torch.full((B, H, W, 64), float("nan"), device="cuda")
+        st = torch.zeros(128, device="cuda")
+        assert seld_lib.seld_k_conv3x3_fwd(ptr(xd), ptr(wd), ptr(bd), ptr(z), ptr(st), B, H, W, Cin, 64) == 0
+        check(f"conv_fwd z {B,H,W,Cin} mode{mode}", z.cpu().numpy(), ref, tol=2e-6)
+        s = st.cpu().numpy()
+        check("conv_fwd sum(z)", s[:64], ref.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref.size / 64))
+        check("conv_fwd sum(z^2)", s[64:], (ref ** 2).sum(axis=(0, 1, 2)))
+    seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16)])
+@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16), (4, 100, 16)])
 def test_conv_dgrad(seld_lib, B, H, W):
     rng = np.random.default_rng(2)
     dz = rng.standard_normal((B, H, W, 64)).astype(np.float32)
@@ -45,10 +48,13 @@ def test_conv_dgrad(seld_lib, B, H, W):
     wt = torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)
     y = F.conv2d(x.permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
     (g,) = torch.autograd.grad(y, x, torch.as_tensor(dz, dtype=torch.float64))
-    dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
     dzd, wd = dev(dz), dev(w)
-    assert seld_lib.seld_k_conv3x3_dgrad(ptr(dzd), ptr(wd), ptr(dx), B, H, W, 64, 64) == 0
-    check(f"conv_dgrad {B,H,W}", dx.cpu().numpy(), g.numpy())
+    for mode in (1, 0):
+        assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
+        dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
+        assert seld_lib.seld_k_conv3x3_dgrad(ptr(dzd), ptr(wd), ptr(dx), B, H, W, 64, 64) == 0
+        check(f"conv_dgrad {B,H,W} mode{mode}", dx.cpu().numpy(), g.numpy(), tol=2e-6)
+    seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
 
 
 @pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
