@@ -55,6 +55,7 @@ struct seld_ctx {
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
     unsigned short* wsplit = nullptr;      // [9][3][64][64] bf16 planes of the current conv64 weights (split-bf16 mode)
+    int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -298,6 +299,7 @@ int seld_set_batch(seld_ctx* c, int B) {
 int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!c || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 int seld_sync(seld_ctx* c) {
@@ -368,7 +370,16 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         float* stat = training ? c->stat_partial : nullptr;
         char tn[32];
         snprintf(tn, sizeof tn, "conv%d_fwd", (int)i + 1);
-        if (i == 0) {
+        // first block with the seldnet.json (5,4) pool: the conv epilogue reduces every pooling window of z
+        // (conv_pool.hip), BN+ReLU+MaxPool becomes an elementwise pass over 1/20 of the data, z is stored
+        // only when the backward pass will read it
+        const bool fused_pool = i == 0 && c->conv1_pool_fused && L.pt == 5 && L.pf == 4 && L.W == 64;
+        if (fused_pool) {
+            PROF(c, tn);   // level 1
+            if (launch_conv_first_fwd_pool(st, in, c->params + L.w_off, c->params + L.b_off, c->params + L.g_off,
+                                           save ? L.z : nullptr, L.p, stat, &npart, B, L.H, L.Cin))
+                return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd_pool");
+        } else if (i == 0) {
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
@@ -390,7 +401,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
             PROF2(c, tn);
-            if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
+            if (fused_pool)
+                launch_bn_relu_ext(st, L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);   // in place over zext
+            else if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
         in = L.p;

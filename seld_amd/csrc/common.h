@@ -32,6 +32,10 @@ struct ConvFirstArgs { const float* x; const float* w; const float* bias; float*
 
 int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* z,
                           float* stat_partial, int* n_partial, int B, int H, int Cin);
+int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
+                               float* z, float* zext, float* stat_partial, int* n_partial, int B, int H, int Cin);
+int conv_pool_stat_capacity();
+int launch_bn_relu_ext(hipStream_t st, const float* zext, const float* scale, const float* shift, float* p, int64_t n);
 int launch_conv64_fwd(hipStream_t st, const float* x, const float* w9, const float* bias, float* z,
                       float* stat_partial, int* n_partial, int B, int H, int W);
 int conv_stat_partial_capacity();  // max blocks writing stat partials

@@ -54,6 +54,24 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
     return done();
 }
 
+int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias, const float* gamma, float* z, float* zext,
+                               float* stats, int B, int H, int Cin) {
+    if (!x || !w || !gamma || !zext) return SELD_ERR_INVALID;
+    Scratch s;
+    float* part = stats ? s.get((size_t)conv_pool_stat_capacity() * 128) : nullptr;
+    if (stats && !part) return SELD_ERR_NOMEM;
+    int np = 0;
+    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, z, zext, part, &np, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    if (stats) launch_reduce_slabs(0, part, np, 128, stats, 128, 0);
+    return done();
+}
+
+int seld_k_bn_relu_ext(const float* zext, const float* scale, const float* shift, float* p, int64_t n) {
+    if (!zext || !scale || !shift || !p) return SELD_ERR_INVALID;
+    if (launch_bn_relu_ext(0, zext, scale, shift, p, n)) return SELD_ERR_UNSUPPORTED;
+    return done();
+}
+
 int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int H, int W, int Cin, int Cout) {
     if (!dz || !w || !dx || Cin != 64 || Cout != 64) return SELD_ERR_UNSUPPORTED;
     Scratch s;

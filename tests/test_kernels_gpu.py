@@ -74,6 +74,48 @@ def test_conv_wgrad(seld_lib, B, H, W, Cin):
     check(f"conv_wgrad db {B,H,W,Cin}", db.cpu().numpy(), gb.numpy())
 
 
+@pytest.mark.parametrize("B,H,Cin", [(2, 50, 7), (1, 5, 7), (3, 35, 7), (2, 30, 10), (20, 300, 7)])
+def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
+    """conv_pool.hip: the conv whose epilogue reduces the (5,4) pooling windows.  z and the statistics as the
+    plain conv; zext against the window max/min of the kernel's OWN z (bit-exact: it is a selection), and
+    bn_relu_ext(zext) bit-identical to the unfused bn_relu_pool_fwd(z) — including gamma < 0 and gamma = 0."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, H, 64, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, 64)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.3, -1, 1)).astype(np.float32)
+    gamma[5] = 0.0
+    xd, wd, bd, gd = dev(x), dev(w), dev(b), dev(gamma)
+    z = torch.full((B, H, 64, 64), float("nan"), device="cuda")
+    ze = torch.full((B, H // 5, 16, 64), float("nan"), device="cuda")
+    st = torch.zeros(128, device="cuda")
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(z), ptr(ze), ptr(st), B, H, Cin) == 0
+    ref = _conv_ref(x, w, b)
+    zh = z.cpu().numpy()
+    check(f"conv_first_fwd_pool z {B,H,Cin}", zh, ref, tol=2e-6)
+    s = st.cpu().numpy()
+    check("conv_first_fwd_pool sum(z)", s[:64], ref.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref.size / 64))
+    check("conv_first_fwd_pool sum(z^2)", s[64:], (ref ** 2).sum(axis=(0, 1, 2)))
+    win = zh.reshape(B, H // 5, 5, 16, 4, 64)
+    want = np.where(gamma < 0, win.min(axis=(2, 4)), win.max(axis=(2, 4)))
+    np.testing.assert_array_equal(ze.cpu().numpy(), want)
+    # z not stored (inference): same zext
+    ze2 = torch.full_like(ze, float("nan"))
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, B, H, Cin) == 0
+    assert torch.equal(ze, ze2)
+    # pooled activation: elementwise over zext == BN+ReLU+MaxPool over z, bit for bit
+    mean, var = zh.mean(axis=(0, 1, 2), dtype=np.float64), zh.var(axis=(0, 1, 2), dtype=np.float64)
+    scale = (gamma / np.sqrt(var + 1e-3)).astype(np.float32)
+    shift = (rng.normal(0, 0.3, 64) - mean * scale).astype(np.float32)
+    sc, sh = dev(scale), dev(shift)
+    p_ref = torch.full((B, H // 5, 16, 64), float("nan"), device="cuda")
+    assert seld_lib.seld_k_bn_relu_pool_fwd(ptr(z), ptr(sc), ptr(sh), ptr(p_ref), B, H, 64, 64, 5, 4) == 0
+    assert seld_lib.seld_k_bn_relu_ext(ptr(ze), ptr(sc), ptr(sh), ptr(ze), ze.numel()) == 0     # in place
+    assert torch.equal(ze, p_ref)
+    # H not a multiple of the pooling height is refused, not mis-tiled
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, B, H - 1, Cin) != 0
+
+
 @pytest.mark.parametrize("B,H,W,pt,pf", [(2, 50, 64, 5, 4), (2, 10, 16, 1, 4), (3, 10, 4, 1, 2)])
 def test_bn_relu_pool(seld_lib, B, H, W, pt, pf):
     rng = np.random.default_rng(4)
