@@ -43,9 +43,11 @@ def kernel_work(name, B, T, F=64, C=7):
         "conv1_fwd": ("mfma", 2 * mac["conv1"]), "conv1_wgrad": ("mfma", 2 * mac["conv1"]),
         "conv2_fwd": ("mfma", 2 * mac["conv2"]), "conv2_wgrad": ("mfma", 2 * mac["conv2"]), "conv2_dgrad": ("mfma", 2 * mac["conv2"]),
         "conv3_fwd": ("mfma", 2 * mac["conv3"]), "conv3_wgrad": ("mfma", 2 * mac["conv3"]), "conv3_dgrad": ("mfma", 2 * mac["conv3"]),
-        "pool1_fwd": ("hbm", 4 * (px1 * 64 + px1 * 64 // 20)), "pool2_fwd": ("hbm", 4 * (px2 * 64 + px2 * 64 // 4)),
+        # first block: the conv epilogue already reduced the (5,4) windows; what is left reads zext and writes p
+        "pool1_fwd": ("hbm", 4 * 2 * (px1 * 64 // 20)), "pool2_fwd": ("hbm", 4 * (px2 * 64 + px2 * 64 // 4)),
         "pool3_fwd": ("hbm", 4 * (px3 * 64 + px3 * 64 // 2)),
-        "pool1_bwd_reduce": ("hbm", 4 * (px1 * 64 + px1 * 64 // 20)), "pool1_bwd_dz": ("hbm", 4 * (2 * px1 * 64 + px1 * 64 // 20)),
+        "pool1_bwd_reduce": ("hbm", 4 * 2 * (px1 * 64 // 20)),   # pooled-only statistics pass: reads p and dp
+        "pool1_bwd_dz": ("hbm", 4 * (2 * px1 * 64 + px1 * 64 // 20)),
         "pool2_bwd_reduce": ("hbm", 4 * (px2 * 64 + px2 * 64 // 4)), "pool2_bwd_dz": ("hbm", 4 * (2 * px2 * 64 + px2 * 64 // 4)),
         "pool3_bwd_reduce": ("hbm", 4 * (px3 * 64 + px3 * 64 // 2)), "pool3_bwd_dz": ("hbm", 4 * (2 * px3 * 64 + px3 * 64 // 2)),
         # GRU recurrence (both directions of one layer): read gx [rows,384] + write h [rows,128] + saved gates [rows,512]
