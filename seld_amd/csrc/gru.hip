@@ -67,6 +67,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const float bz = brec[j], br = brec[GRU_U + j], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
+    const unsigned sel0 = q == 0 ? ~0u : 0u, sel1 = q == 1 ? ~0u : 0u, sel2 = q == 2 ? ~0u : 0u, sel3 = q == 3 ? ~0u : 0u;
     const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
     // staged chunk: three float4 per thread held in NAMED registers (an array captured by a lambda was
     // demoted to scratch memory by the compiler, which put a vmcnt wait right behind the loads)
@@ -130,8 +131,11 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 H[(size_t)t * GRU_U + j] = hn;
             }
             if (sv) {
-                const float val = q == 0 ? z : (q == 1 ? r : (q == 2 ? hh : ghh));
-                sv[((size_t)t * 4 + q) * GRU_U + j] = val;
+                // lane q of a quad saves gate q (z | r | hh | gh): AND/OR with per-lane one-hot masks — the nested
+                // ternary became three exec-mask branches per step
+                const unsigned vb = (__float_as_uint(z) & sel0) | (__float_as_uint(r) & sel1) | (__float_as_uint(hh) & sel2) |
+                                    (__float_as_uint(ghh) & sel3);
+                sv[((size_t)t * 4 + q) * GRU_U + j] = __uint_as_float(vb);
             }
             ++step;
         };

@@ -1,0 +1,34 @@
+"""GRU recurrence kernels at the headline shape (B=32, S=600) through seld_k_gru_fwd, with and without the
+saved-gates output; meant to run under `rocprofv3 --kernel-trace` (durations come from the trace)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from seld_amd import _lib
+
+lib = _lib.load()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+B, S = 32, 600
+g = torch.Generator(device="cuda").manual_seed(0)
+gx = [torch.randn(B, S, 384, device="cuda", generator=g) for _ in range(2)]
+U = [torch.randn(128, 384, device="cuda", generator=g) * 0.1 for _ in range(2)]
+br = [torch.randn(384, device="cuda", generator=g) * 0.1 for _ in range(2)]
+h = [torch.empty(B, S, 128, device="cuda") for _ in range(2)]
+sv = [torch.empty(B, S, 4, 128, device="cuda") for _ in range(2)]
+for save in (1, 0, 1, 0):
+    for _ in range(5):
+        rc = lib.seld_k_gru_fwd(P(gx[0]), P(gx[1]), P(U[0]), P(U[1]), P(br[0]), P(br[1]), P(h[0]), P(h[1]),
+                                P(sv[0]) if save else None, P(sv[1]) if save else None, None, B, S, 128)
+        assert rc == 0, rc
+print("ok")
+dout = torch.randn(B, S, 128, device="cuda", generator=g)
+dgx = [torch.empty(B, S, 384, device="cuda") for _ in range(2)]
+dgh = [torch.empty(B, S, 384, device="cuda") for _ in range(2)]
+for _ in range(5):
+    rc = lib.seld_k_gru_bwd(P(dout), P(h[0]), P(h[1]), P(sv[0]), P(sv[1]), P(U[0]), P(U[1]), P(dgx[0]), P(dgx[1]), P(dgh[0]), P(dgh[1]),
+                            B, S, 128)
+    assert rc == 0, rc
+print("bwd ok")
