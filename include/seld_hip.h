@@ -170,11 +170,12 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
                        int B, int H, int W, int Cin, int Cout);
 /* First conv block forward with the (5,4) MaxPooling2D reduction folded into the convolution (layers.py:27-37,
  * seldnet.json FIRST_ARGS pool_size[0]): x [B,H,64,Cin] (Cin 7 or 10, H % 5 == 0) -> z [B,H,64,64] (may be NULL:
- * not stored), zext [B,H/5,16,64] = per pooling window max(z) where gamma >= 0 / min(z) where gamma < 0, and the
- * batch statistics as in seld_k_conv3x3_fwd.  BN+ReLU is monotone in z, so MaxPool(ReLU(BN(z))) ==
- * seld_k_bn_relu_ext(zext) bit for bit. */
+ * not stored), zext [B,H/5,16,64] = per pooling window max(z) where gamma >= 0 / min(z) where gamma < 0, amax
+ * [B,H/5,16,64] bytes = position row*4+col of that extreme inside its window (what MaxPoolGrad routes to; the first
+ * in column-then-row scan order on ties; NULL exactly when z is NULL), and the batch statistics as in
+ * seld_k_conv3x3_fwd.  BN+ReLU is monotone in z, so MaxPool(ReLU(BN(z))) == seld_k_bn_relu_ext(zext) bit for bit. */
 int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias, const float* gamma, float* z, float* zext,
-                               float* stats, int B, int H, int Cin);
+                               unsigned char* amax, float* stats, int B, int H, int Cin);
 /* p = max(0, zext * scale[c] + shift[c]) (fused multiply-add), n elements, 64 channels innermost */
 int seld_k_bn_relu_ext(const float* zext, const float* scale, const float* shift, float* p, int64_t n);
 /* input gradient of the same conv (tape.gradient through Conv2D): dz [B,H,W,64] -> dx [B,H,W,Cin=64] */

@@ -95,7 +95,7 @@ SIGNATURES = {
     "seld_profile_get": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(C.c_double)]),
     "seld_profile_reset": (_I, [_P]),
     "seld_k_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
-    "seld_k_conv_first_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    "seld_k_conv_first_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_bn_relu_ext": (_I, [_P, _P, _P, _P, _L]),
     "seld_k_conv3x3_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -20,6 +20,7 @@ struct ConvL {
     int64_t w_off, b_off, g_off, be_off;   // trainable offsets
     int64_t mm_off, mv_off;           // state offsets
     float *z = nullptr, *p = nullptr, *dp = nullptr;
+    unsigned char* amax = nullptr;    // first block only: position of each pooling window's extreme [B,H/pt,W/pf,64]
     float *mean, *invstd, *scale, *shift, *c1c2;   // into small buffer
 };
 
@@ -239,6 +240,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         const size_t nz = (size_t)B * L.H * L.W * 64;
         const size_t np = (size_t)B * (L.H / L.pt) * (L.W / L.pf) * 64;
         ALLOC(L.z, nz); ALLOC(L.p, np); ALLOC(L.dp, np);
+        if (i == 0) { float* am = nullptr; ALLOC(am, (np + 3) / 4); L.amax = reinterpret_cast<unsigned char*>(am); }
         if (nz > zmax) zmax = nz;
         float* sm = c->small + (size_t)i * 64 * 6;
         L.mean = sm; L.invstd = sm + 64; L.scale = sm + 128; L.shift = sm + 192; L.c1c2 = sm + 256;
@@ -377,12 +379,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         if (fused_pool) {
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd_pool(st, in, c->params + L.w_off, c->params + L.b_off, c->params + L.g_off,
-                                           save ? L.z : nullptr, L.p, stat, &npart, B, L.H, L.Cin))
+                                           save ? L.z : nullptr, L.p, save ? L.amax : nullptr, stat, &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd_pool");
         } else if (i == 0) {
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd");
+            if (save && L.pf == 4) launch_pool_argext(st, L.z, c->params + L.g_off, L.amax, B, L.H, L.W, L.pt, L.pf);   // for the fused backward
         } else {
             PROF2(c, tn);
             if (c->conv64_split_bf16) {
@@ -588,7 +591,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 PROF(c, "conv1_wgrad");
                 // fused: dz = BN/ReLU/pool backward formed inside the wgrad kernel (L.mean.. are contiguous: 6 x 64)
                 const int rc = fused_first
-                    ? launch_conv_first_wgrad_fused(st, x, L.z, L.p, dp, L.mean, c->wgrad_slab, &ns, B, L.H, L.Cin, L.pt, L.pf)
+                    ? launch_conv_first_wgrad_fused(st, x, L.z, L.p, dp, L.amax, L.mean, c->wgrad_slab, &ns, B, L.H, L.Cin, L.pt, L.pf)
                     : launch_conv_first_wgrad(st, x, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.Cin);
                 if (rc) return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_wgrad");
             }

@@ -33,7 +33,10 @@ struct ConvFirstArgs { const float* x; const float* w; const float* bias; float*
 int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const float* bias, float* z,
                           float* stat_partial, int* n_partial, int B, int H, int Cin);
 int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
-                               float* z, float* zext, float* stat_partial, int* n_partial, int B, int H, int Cin);
+                               float* z, float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H,
+                               int Cin);
+int launch_pool_argext(hipStream_t st, const float* z, const float* gamma, unsigned char* amax, int B, int H, int W, int pt,
+                       int pf);
 int conv_pool_stat_capacity();
 int launch_bn_relu_ext(hipStream_t st, const float* zext, const float* scale, const float* shift, float* p, int64_t n);
 int launch_conv64_fwd(hipStream_t st, const float* x, const float* w9, const float* bias, float* z,
@@ -43,7 +46,8 @@ int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, flo
                             int B, int H, int Cin);
 // fused BN/ReLU/pool backward + first-layer wgrad; coef = [mean|invstd|scale|shift|c1|c2] x 64 (contiguous)
 int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
-                                  const float* coef, float* slab, int* n_slab, int B, int H, int Cin, int pt, int pf);
+                                  const unsigned char* amax, const float* coef, float* slab, int* n_slab, int B, int H,
+                                  int Cin, int pt, int pf);
 int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
                         int B, int H, int W);
 int conv_wgrad_slab_capacity();

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 template <int CIN, int PT>
 __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                                      const float* __restrict__ p, const float* __restrict__ dp,
+                                                                     const unsigned char* __restrict__ amax,
                                                                      const float* __restrict__ coef, float* __restrict__ slab,
                                                                      int B, int H) {
     using G = FirstGeom<CIN>;
@@ -519,7 +520,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     const float4 mu4 = reinterpret_cast<const float4*>(coef)[g], is4 = reinterpret_cast<const float4*>(coef + 64)[g];
     const float4 sc4 = reinterpret_cast<const float4*>(coef + 128)[g], sh4 = reinterpret_cast<const float4*>(coef + 192)[g];
     const float4 c14 = reinterpret_cast<const float4*>(coef + 256)[g], c24 = reinterpret_cast<const float4*>(coef + 320)[g];
-    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+    (void)sh4;
     float ka[4], kb[4];   // dz = z*ka + kb (+ scale*dp at the argmax): ka = -scale*c2*invstd, kb = -scale*c1 - ka*mean
     {
         const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     }
     PatchStage<CIN> stg;
     float4 zr[16], pr[2], dpr[2];
+    unsigned ar[2];    // window positions of the extreme, 4 channels packed (amax bytes)
     int st_t0 = 0;     // t0 of the staged tile
     auto issue_z = [&](int b, int t0) {
         st_t0 = t0;
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             const size_t off = (((size_t)b * Hp + prow) * 16 + q) * 64 + g * 4;
             pr[v] = *reinterpret_cast<const float4*>(p + off);
             dpr[v] = *reinterpret_cast<const float4*>(dp + off);
+            ar[v] = *reinterpret_cast<const unsigned*>(amax + off);
         }
     };
     auto commit_dz = [&]() {
@@ -559,14 +563,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             const bool second = (t / PT) != pr0;
             const float4 pv = second ? pr[1] : pr[0];
             const float4 dv = second ? dpr[1] : dpr[0];
+            const unsigned av = second ? ar[1] : ar[0];
+            const unsigned pos = (unsigned)((t - (t / PT) * PT) * 4 + (u & 3));    // this pixel's position in its window
             const float zz[4] = {zr[u].x, zr[u].y, zr[u].z, zr[u].w};
             const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                // dz = scale*(dy - c1 - xhat*c2) = fma(z, ka, kb) + (argmax ? scale*dp : 0)
-                const float y = fmaf(zz[c], sc[c], sh[c]);
-                const float g_sel = (y == pp[c] && pp[c] > 0.f) ? sc[c] * dd[c] : 0.f;
+                // dz = scale*(dy - c1 - xhat*c2) = fma(z, ka, kb) + (argmax ? scale*dp : 0).  The argmax is the ONE
+                // position the forward recorded (MaxPoolGrad routes to a single element): testing y == p instead
+                // double-counts dp whenever two pixels of a window round to the same fp32 y — a few windows per
+                // step at B = 32, each worth ~1e-3 of a kernel gradient's scale.
+                const float g_sel = (((av >> (8 * c)) & 255u) == pos && pp[c] > 0.f) ? sc[c] * dd[c] : 0.f;
                 o[c] = (t < H) ? fmaf(zz[c], ka[c], kb[c]) + g_sel : 0.f;
             }
             *reinterpret_cast<float4*>(dzl + (size_t)(row * 64 + px) * 64 + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -647,8 +655,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
 }
 
 int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
-                                  const float* coef, float* slab, int* n_slab, int B, int H, int Cin, int pt, int pf) {
-    if ((Cin != 7 && Cin != 10) || pf != 4 || H % pt) return -2;
+                                  const unsigned char* amax, const float* coef, float* slab, int* n_slab, int B, int H,
+                                  int Cin, int pt, int pf) {
+    if ((Cin != 7 && Cin != 10) || pf != 4 || H % pt || !amax) return -2;
     const int ntiles = B * ((H + 3) / 4);
     const int grid = ntiles < WGRAD_MAX_BLOCKS ? ntiles : WGRAD_MAX_BLOCKS;
 #define LAUNCH_FUSED(CI, PT)                                                                                      \
@@ -657,7 +666,7 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wgrad_fused_kernel<CI, PT>),                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
         hipLaunchKernelGGL((conv_first_wgrad_fused_kernel<CI, PT>), dim3(grid), dim3(256), smem, st, x, z, p, dp, \
-                           coef, slab, B, H);                                                                     \
+                           amax, coef, slab, B, H);                                                                     \
     }
 #define LAUNCH_FUSED_PT(CI)                                                                                       \
     if (pt == 5) LAUNCH_FUSED(CI, 5) else if (pt == 4) LAUNCH_FUSED(CI, 4) else if (pt == 2) LAUNCH_FUSED(CI, 2)  \

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma, float* __restrict__ z,
                                                                      float* __restrict__ zext,
+                                                                     unsigned char* __restrict__ amax,
                                                                      float* __restrict__ stat_partial, int B, int H) {
     using G = PoolGeom<CIN>;
     constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF, NS = KPAD / 2, NV = G::NV, SLOTS = G::SLOTS, PER = G::PER_THREAD;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         Wl[idx] = (k < K) ? w[idx] : (k == K ? (bias ? bias[co] : 0.f) : 0.f);
     }
     for (int idx = tid; idx < 2 * G::PATCH; idx += 256) patch0[idx] = 0.f;   // halo columns stay zero
-    const bool use_min[2] = {gamma[li] < 0.f, gamma[32 + li] < 0.f};
+    // gamma < 0: the window extreme that survives BN+ReLU+MaxPool is the minimum of z -> flip the sign, take the maximum
+    const unsigned smask[2] = {gamma[li] < 0.f ? 0x80000000u : 0u, gamma[32 + li] < 0.f ? 0x80000000u : 0u};
     const int tiles_per_img = (H + 9) / 10;
     const int ntiles = B * tiles_per_img;
     const int HP = H / 5;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         B0 = wlh[128 * (s_) + 32 * (c_)];                                                               \
     }
     // drain accumulator register r_ of one channel half (Y0..Y4 = the 5 image rows): 5 z stores, statistics,
-    // running window extreme; the window's zext value goes out with its fourth register
+    // running window extreme (and its position); the window's zext / amax go out with its fourth register
 #define CP_DRAIN(r_, c_, Y0, Y1, Y2, Y3, Y4)                                                            \
     {                                                                                                   \
         const float v0 = Y0[r_], v1 = Y1[r_], v2 = Y2[r_], v3 = Y3[r_], v4 = Y4[r_];                    \
@@ -125,12 +127,22 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         }                                                                                               \
         s1[c_] += (v0 + v1) + (v2 + v3) + v4;                                                           \
         s2[c_] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, fmaf(v4, v4, s2[c_])))));          \
-        const float hi5 = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), v4);                               \
-        const float lo5 = fminf(fminf(fminf(v0, v1), fminf(v2, v3)), v4);                               \
-        mx = ((r_) & 3) ? fmaxf(mx, hi5) : hi5;                                                         \
-        mn = ((r_) & 3) ? fminf(mn, lo5) : lo5;                                                         \
-        if (((r_) & 3) == 3)                                                                            \
-            (zext + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = use_min[c_] ? mn : mx; \
+        const float w0 = __uint_as_float(__float_as_uint(v0) ^ smask[c_]), w1 = __uint_as_float(__float_as_uint(v1) ^ smask[c_]); \
+        const float w2 = __uint_as_float(__float_as_uint(v2) ^ smask[c_]), w3 = __uint_as_float(__float_as_uint(v3) ^ smask[c_]); \
+        const float w4 = __uint_as_float(__float_as_uint(v4) ^ smask[c_]);                              \
+        const float hi5 = fmaxf(fmaxf(fmaxf(w0, w1), fmaxf(w2, w3)), w4);                               \
+        const bool take_ = ((r_) & 3) == 0 || hi5 > best;     /* strict: the first extreme in scan order wins ties */ \
+        if (WRITE_Z) {       /* training: remember WHERE the extreme is: position row * 4 + column of the window */ \
+            int row_ = 4;                                                                               \
+            row_ = (w3 == hi5) ? 3 : row_; row_ = (w2 == hi5) ? 2 : row_;                               \
+            row_ = (w1 == hi5) ? 1 : row_; row_ = (w0 == hi5) ? 0 : row_;                               \
+            bpos = take_ ? row_ * 4 + ((r_) & 3) : bpos;                                                \
+        }                                                                                               \
+        best = take_ ? hi5 : best;                                                                      \
+        if (((r_) & 3) == 3) {                                                                          \
+            (zext + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = __uint_as_float(__float_as_uint(best) ^ smask[c_]); \
+            if (WRITE_Z) (amax + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = (unsigned char)bpos; \
+        }                                                                                               \
     }
     static_assert(NS >= 32, "the drain of half a tile is spread over 32 k-steps");
 #ifdef CPOOL_TIMING
@@ -150,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         const bool live = tg < H;                // H % 5 == 0: a pooling row is entirely inside or outside
         const size_t zr = ((size_t)(b * H + tg) * 64 + 32 * strip) * 64;
         const size_t er = ((size_t)(b * HP + tg / 5) * 16 + 8 * strip) * 64;
-        float mx = 0.f, mn = 0.f;
+        float best = 0.f;
+        int bpos = 0;
 #ifdef CPOOL_TIMING
         const long long c1 = clock64();
 #endif
@@ -255,28 +268,31 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
 
 template <int CIN>
 static int launch_cpool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma, float* z,
-                        float* zext, float* stat_partial, int* n_partial, int B, int H) {
+                        float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H) {
     using G = PoolGeom<CIN>;
     const int ntiles = B * ((H + 9) / 10);
     const int grid = ntiles < CPOOL_MAX_PERSISTENT ? ntiles : CPOOL_MAX_PERSISTENT;
     if (z) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_kernel<CIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, true>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, stat_partial, B, H);
+        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, true>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, amax, stat_partial, B, H);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_kernel<CIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, false>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, stat_partial, B, H);
+        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, false>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, amax, stat_partial, B, H);
     }
     if (n_partial) *n_partial = grid;
     return 0;
 }
 
-// x [B,H,64,Cin] -> z [B,H,64,64] (optional: nullptr skips the store), zext [B,H/5,16,64] (per (5,4) window the
-// max of z where gamma >= 0, the min where gamma < 0), BN statistics partials [n_partial][128].
+// x [B,H,64,Cin] -> z [B,H,64,64] and amax [B,H/5,16,64] (bytes: position row*4+col of the window's extreme, the first
+// in column-then-row scan order on ties) — both optional, stored together for the backward pass —, zext
+// [B,H/5,16,64] (per (5,4) window the max of z where gamma >= 0, the min where gamma < 0), BN statistics partials
+// [n_partial][128].
 int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
-                               float* z, float* zext, float* stat_partial, int* n_partial, int B, int H, int Cin) {
-    if (H % 5 || H <= 0 || B <= 0) return -2;
-    if (Cin == 7) return launch_cpool<7>(st, x, w, bias, gamma, z, zext, stat_partial, n_partial, B, H);
-    if (Cin == 10) return launch_cpool<10>(st, x, w, bias, gamma, z, zext, stat_partial, n_partial, B, H);
+                               float* z, float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H,
+                               int Cin) {
+    if (H % 5 || H <= 0 || B <= 0 || (z != nullptr) != (amax != nullptr)) return -2;   // z and amax are stored together
+    if (Cin == 7) return launch_cpool<7>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
+    if (Cin == 10) return launch_cpool<10>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
     return -2;
 }
 
@@ -301,5 +317,39 @@ int launch_bn_relu_ext(hipStream_t st, const float* zext, const float* scale, co
     if (n % 64) return -2;
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(bn_relu_ext_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, zext, scale, shift, p, n4);
+    return 0;
+}
+
+// Position (row * PF + col) of each pooling window's extreme of z — max where gamma >= 0, min where gamma < 0, the
+// first in column-then-row scan order on ties — for forward paths that did not produce it (unfused first block,
+// per-kernel test entry).  Same rule as the epilogue of conv_first_fwd_pool_kernel.
+__global__ __launch_bounds__(256) void pool_argext_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                          unsigned char* __restrict__ amax, int64_t npool, int H, int W, int PT,
+                                                          int PF) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npool * 64) return;
+    const int c = (int)(gid & 63);
+    const int64_t pp = gid >> 6;
+    const int Wp = W / PF, Hp = H / PT;
+    const int fp = (int)(pp % Wp);
+    const int tp = (int)((pp / Wp) % Hp);
+    const int b = (int)(pp / ((int64_t)Wp * Hp));
+    const unsigned sm = gamma[c] < 0.f ? 0x80000000u : 0u;
+    const float* base = z + (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + c;
+    float best = 0.f;
+    int bpos = 0;
+    for (int j = 0; j < PF; ++j)
+        for (int i = 0; i < PT; ++i) {
+            const float w = __uint_as_float(__float_as_uint(base[((size_t)i * W + j) * 64]) ^ sm);
+            if ((i == 0 && j == 0) || w > best) { best = w; bpos = i * PF + j; }
+        }
+    amax[gid] = (unsigned char)bpos;
+}
+
+int launch_pool_argext(hipStream_t st, const float* z, const float* gamma, unsigned char* amax, int B, int H, int W, int pt,
+                       int pf) {
+    if (H % pt || W % pf || pt * pf > 255) return -2;
+    const int64_t n = (int64_t)B * (H / pt) * (W / pf) * 64;
+    hipLaunchKernelGGL(pool_argext_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, gamma, amax, n / 64, H, W, pt, pf);
     return 0;
 }

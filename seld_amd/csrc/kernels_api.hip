@@ -55,13 +55,13 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
 }
 
 int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias, const float* gamma, float* z, float* zext,
-                               float* stats, int B, int H, int Cin) {
-    if (!x || !w || !gamma || !zext) return SELD_ERR_INVALID;
+                               unsigned char* amax, float* stats, int B, int H, int Cin) {
+    if (!x || !w || !gamma || !zext || (z != nullptr) != (amax != nullptr)) return SELD_ERR_INVALID;
     Scratch s;
     float* part = stats ? s.get((size_t)conv_pool_stat_capacity() * 128) : nullptr;
     if (stats && !part) return SELD_ERR_NOMEM;
     int np = 0;
-    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, z, zext, part, &np, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, z, zext, amax, part, &np, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
     if (stats) launch_reduce_slabs(0, part, np, 128, stats, 128, 0);
     return done();
 }
@@ -121,7 +121,8 @@ int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, cons
     float* pbuf = s.get((size_t)B * (H / pt) * (W / pf) * 64);
     float* slab = s.get((size_t)conv_wgrad_slab_capacity() * conv_first_wgrad_slab_stride(Cin));
     float* tmp = s.get(conv_first_wgrad_slab_stride(Cin));
-    if (!coef || !part || !pbuf || !slab || !tmp) return SELD_ERR_NOMEM;
+    unsigned char* amax = reinterpret_cast<unsigned char*>(s.get(((size_t)B * (H / pt) * (W / pf) * 64 + 3) / 4));
+    if (!coef || !part || !pbuf || !slab || !tmp || !amax) return SELD_ERR_NOMEM;
     hipMemcpyAsync(coef, mean, 256, hipMemcpyDeviceToDevice, 0);
     hipMemcpyAsync(coef + 64, invstd, 256, hipMemcpyDeviceToDevice, 0);
     hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(64), 0, 0, mean, invstd, gamma, beta, coef + 128, coef + 192, C);
@@ -129,7 +130,8 @@ int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, cons
     int np = 0, ns = 0;
     if (launch_bn_pool_bwd_reduce(0, z, pbuf, dp, coef, coef + 64, coef + 128, coef + 192, part, &np, B, H, W, C, pt, pf)) return SELD_ERR_UNSUPPORTED;
     launch_bn_bwd_finalize(0, part, np, (double)B * H * W, dgamma, dbeta, coef + 256, C);
-    if (launch_conv_first_wgrad_fused(0, x, z, pbuf, dp, coef, slab, &ns, B, H, Cin, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    if (launch_pool_argext(0, z, gamma, amax, B, H, W, pt, pf)) return SELD_ERR_UNSUPPORTED;
+    if (launch_conv_first_wgrad_fused(0, x, z, pbuf, dp, amax, coef, slab, &ns, B, H, Cin, pt, pf)) return SELD_ERR_UNSUPPORTED;
     launch_reduce_slabs(0, slab, ns, conv_first_wgrad_slab_stride(Cin), tmp, (int64_t)(9 * Cin + 1) * 64, 0);
     hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
     hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);

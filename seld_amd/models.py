@@ -123,6 +123,10 @@ class SeldNet:
             s = np.ascontiguousarray(flat_state, np.float32)
             _lib.check(self.lib.seld_set_state_host(self.ctx, s.ctypes.data, s.size), self.ctx)
 
+    def set_option(self, key: str, value: int) -> None:
+        """Kernel-selection knobs of the C library (`seld_set_option`): "conv64_split_bf16", "conv1_pool_fused"."""
+        _lib.check(self.lib.seld_set_option(self.ctx, key.encode(), int(value)), self.ctx)
+
     def get_grads(self) -> np.ndarray:
         g = np.empty(self.n_params, np.float32)
         _lib.check(self.lib.seld_get_grads_host(self.ctx, g.ctypes.data, self.n_params), self.ctx)

@@ -88,8 +88,9 @@ def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
     xd, wd, bd, gd = dev(x), dev(w), dev(b), dev(gamma)
     z = torch.full((B, H, 64, 64), float("nan"), device="cuda")
     ze = torch.full((B, H // 5, 16, 64), float("nan"), device="cuda")
+    am = torch.full((B, H // 5, 16, 64), 255, device="cuda", dtype=torch.uint8)
     st = torch.zeros(128, device="cuda")
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(z), ptr(ze), ptr(st), B, H, Cin) == 0
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(z), ptr(ze), ptr(am), ptr(st), B, H, Cin) == 0
     ref = _conv_ref(x, w, b)
     zh = z.cpu().numpy()
     check(f"conv_first_fwd_pool z {B,H,Cin}", zh, ref, tol=2e-6)
@@ -99,9 +100,13 @@ def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
     win = zh.reshape(B, H // 5, 5, 16, 4, 64)
     want = np.where(gamma < 0, win.min(axis=(2, 4)), win.max(axis=(2, 4)))
     np.testing.assert_array_equal(ze.cpu().numpy(), want)
-    # z not stored (inference): same zext
+    # amax: position row*4+col of that extreme in its window (random data: no ties)
+    flat = np.where(gamma < 0, -win, win).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 5, 16, 64, 20)
+    np.testing.assert_array_equal(am.cpu().numpy(), flat.argmax(-1).astype(np.uint8))
+    # z not stored (inference): same zext; z and amax go together
     ze2 = torch.full_like(ze, float("nan"))
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, B, H, Cin) == 0
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am), None, B, H, Cin) != 0
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, None, B, H, Cin) == 0
     assert torch.equal(ze, ze2)
     # pooled activation: elementwise over zext == BN+ReLU+MaxPool over z, bit for bit
     mean, var = zh.mean(axis=(0, 1, 2), dtype=np.float64), zh.var(axis=(0, 1, 2), dtype=np.float64)
@@ -113,7 +118,7 @@ def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
     assert seld_lib.seld_k_bn_relu_ext(ptr(ze), ptr(sc), ptr(sh), ptr(ze), ze.numel()) == 0     # in place
     assert torch.equal(ze, p_ref)
     # H not a multiple of the pooling height is refused, not mis-tiled
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, B, H - 1, Cin) != 0
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, None, B, H - 1, Cin) != 0
 
 
 @pytest.mark.parametrize("B,H,W,pt,pf", [(2, 50, 64, 5, 4), (2, 10, 16, 1, 4), (3, 10, 4, 1, 2)])
@@ -331,3 +336,42 @@ def test_conv1_bwd_fused(seld_lib, B, H, CIN):
     check(f"conv1_bwd_fused dgamma {B,H}", dg.cpu().numpy(), gg.numpy())
     check(f"conv1_bwd_fused dbeta {B,H}", dbe.cpu().numpy(), gbe.numpy())
     assert np.abs(db.cpu().numpy()).max() <= 1e-3 * np.abs(gw.numpy()).max()   # exact-arithmetic zero (bias before BN)
+
+
+def test_conv1_bwd_single_routing_on_ties(seld_lib):
+    """MaxPoolGrad routes a window's gradient to ONE element.  With all-zero weights every z of a channel equals
+    its bias — every window is a 20-way tie — so the kernel+bias gradient must equal the gradient of routing each
+    dp to one position per window (the first in the kernel's scan order: position 0), not 20 copies of it."""
+    B, H, CIN = 1, 10, 7
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((B, H, 64, CIN)).astype(np.float32)
+    w = np.zeros((3, 3, CIN, 64), np.float32)
+    b = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    gamma, beta = np.ones(64, np.float32), np.full(64, 0.25, np.float32)
+    xd, wd, bd, gd, bed = dev(x), dev(w), dev(b), dev(gamma), dev(beta)
+    zd = torch.empty((B, H, 64, 64), device="cuda")
+    ze = torch.empty((B, H // 5, 16, 64), device="cuda")
+    am = torch.full((B, H // 5, 16, 64), 255, device="cuda", dtype=torch.uint8)
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(zd), ptr(ze), ptr(am), None, B, H, CIN) == 0
+    assert (am == 0).all()                                        # ties: the first position of the scan
+    # z is constant per channel -> xhat = 0, y = beta > 0, p = beta; batch mean = bias, variance = 0
+    mean, invstd = b.copy(), np.full(64, 1.0 / np.sqrt(1e-3), np.float32)
+    dp = rng.standard_normal((B, H // 5, 16, 64)).astype(np.float32)
+    nan = lambda *s_: torch.full(s_, float("nan"), device="cuda")
+    dw, db, dg, dbe = nan(3, 3, CIN, 64), nan(64), nan(64), nan(64)
+    md, isd, dpd = dev(mean), dev(invstd), dev(dp)
+    assert seld_lib.seld_k_conv1_bwd_fused(ptr(xd), ptr(zd), ptr(dpd), ptr(md), ptr(isd), ptr(gd), ptr(bed), ptr(dw), ptr(db),
+                                           ptr(dg), ptr(dbe), B, H, CIN, 5, 4) == 0
+    # reference: dy = dp at position 0 of each window (image row 5*tp, bin 4*fp), 0 elsewhere; dz = scale*(dy - mean(dy))
+    # (xhat = 0 kills the second BN term); dW = sum_px patch(px)^T dz(px)
+    scale = gamma.astype(np.float64) * invstd.astype(np.float64)
+    dy = np.zeros((B, H, 64, 64))
+    dy[:, ::5, ::4, :] = dp
+    dz = scale * (dy - dy.mean(axis=(0, 1, 2)))
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((3, 3, CIN, 64))
+    for kh in range(3):
+        for kw in range(3):
+            ref[kh, kw] = np.einsum("bhwc,bhwo->co", xp[:, kh:kh + H, kw:kw + 64, :], dz)
+    check("single routing dw", dw.cpu().numpy(), ref)
+    check("single routing dbeta", dbe.cpu().numpy(), dp.sum(axis=(0, 1, 2)))

@@ -21,6 +21,7 @@ b = torch.randn(64, device="cuda", generator=g)
 gamma = torch.ones(64, device="cuda")
 z = torch.empty(B, H, 64, 64, device="cuda")
 ze = torch.empty(B, H // 5, 16, 64, device="cuda")
+am = torch.empty(B, H // 5, 16, 64, device="cuda", dtype=torch.uint8)
 st = torch.zeros(128, device="cuda")
 P = lambda t: C.c_void_p(t.data_ptr())
 
@@ -47,12 +48,12 @@ unfused = lambda: lib.seld_k_conv3x3_fwd(P(x), P(w), P(b), P(z), P(st), B, H, 64
 print("conv_first_fwd (unfused)      %.4f ms" % timeit(unfused))
 print("conv_first_fwd (unfused)      %.4f ms" % timeit(unfused))
 for _ in range(2):
-    t1 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(z), P(ze), P(st), B, H, Cin))
-    t2 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), None, P(ze), P(st), B, H, Cin))
+    t1 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(z), P(ze), P(am), P(st), B, H, Cin))
+    t2 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), None, P(ze), None, P(st), B, H, Cin))
     print("conv_first_fwd_pool          %.4f ms (z stored)   %.4f ms (z not stored)" % (t1, t2))
 print("conv_first_fwd (unfused)      %.4f ms" % timeit(unfused))
 if os.environ.get("CPOOL_TIMING"):      # library built with -DCPOOL_TIMING: stats slots 0..5 = summed phase cycles of wave 0
     for zz in (z, None):
-        lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(zz) if zz is not None else None, P(ze), P(st), B, H, Cin)
+        lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(zz) if zz is not None else None, P(ze), P(am) if zz is not None else None, P(st), B, H, Cin)
         v = st[:6].cpu().numpy() / 512 / 18.75
         print("z stored    " if zz is not None else "z not stored", "cycles per tile (wave 0 mean): top %.0f  phaseA %.0f  phaseB+drainA %.0f  commit %.0f  drainB %.0f  barrier %.0f  total %.0f" % (*v, v.sum()))
