@@ -144,6 +144,20 @@ int seld_frame_windows(const float* x, float* windows, int T, int FC, int win_si
                        void* stream);
 int seld_overlap_average(const float* y, float* out, int n_windows, int L, int D, void* stream);
 
+/* ---- batch augmentation on the device (reference: the tf.data sample/batch transforms of train.get_dataset,
+ * train.py:157-165).  The random draws are made by the host (seld_amd/transforms.py mirrors the reference's
+ * distributions) and passed as small device arrays; the kernels are pure data movement.
+ * seld_aug_mask: transforms.mask (transforms.py:6-44) for both axes in one pass over x [B,T,F,C], in place: for sample
+ *   b and segment s = t / period (T % period == 0, else SELD_ERR_INVALID as the reference raises ValueError), frames
+ *   [t_off, t_off+t_size) of the segment and bins [f_off, f_off+f_size) are zeroed; arrays are int32 [B * T/period];
+ *   either pair may be NULL (that axis is not masked).
+ * seld_aug_gather_sign: out[b,o,r,i] = sgn[b,r] * in[b,o,src[b,r],i] in place on x [B,outer,R,inner] (R <= 32): the
+ *   channel permutation + sign flips of foa_intensity_vec_aug / acs_aug (transforms.py:73-114,159-207) on the
+ *   features (R = channels, inner = 1) and on the labels viewed [B,S,4,n_classes] (R = 4, inner = n_classes). */
+int seld_aug_mask(float* x, int B, int T, int F, int C, int period, const int* t_off, const int* t_size, const int* f_off,
+                  const int* f_size, void* stream);
+int seld_aug_gather_sign(float* x, int B, int64_t outer, int R, int64_t inner, const int* src, const float* sgn, void* stream);
+
 /* ---- SELD metrics on the device: SELDMetrics.update_states (metrics.py:60-154), which the reference runs in TF
  * eager mode on the host after every step (train.py:82-83).  `state` = seld_metrics_state_size(nc) doubles
  * (device, zero to reset): TP FP TN FN S D I Nref Nsys total_DE DE_TP, then class_tp|fp|tn|fn [nc] each;

@@ -87,6 +87,8 @@ SIGNATURES = {
     "seld_feat_normalize": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
     "seld_frame_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "seld_overlap_average": (_I, [_P, _P, _I, _I, _I, _P]),
+    "seld_aug_mask": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "seld_aug_gather_sign": (_I, [_P, _I, _L, _I, _L, _P, _P, _P]),
     "seld_metrics_state_size": (_I, [_I]),
     "seld_metrics_scratch_floats": (_L, [_I, _I, _I, _I]),
     "seld_metrics_update": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),

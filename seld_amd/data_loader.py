@@ -4,7 +4,8 @@ windowing of data_loader.py, without tf.data.
   load_seldnet_data            data_loader.py:58-92   glob *.npy, fold = 5th character of the file name
   seldnet_data_to_dataloader   data_loader.py:132-168 + data_loader():13-55
       concat files -> [labels, 5, F, C] -> windows of 60 labels (300 frames) -> repeat(loop_time) ->
-      batch(batch_size, drop_remainder=False) -> split labels into (sed, doa) -> shuffle (train)
+      batch(batch_size, drop_remainder=False) -> [device_transforms: augmentation on the device batch, run by
+      the step loop] -> split labels into (sed, doa) -> shuffle (train)
 Batches are (x [b,300,F,C] float32, (sed [b,60,C], doa [b,60,3C])) numpy arrays; pinned host buffers
 and the H2D copy belong to the caller (`train.trainstep` accepts numpy or device tensors)."""
 from __future__ import annotations
@@ -41,10 +42,13 @@ def split_total_labels_to_sed_doa(x, y):
 class SeldDataset:
     """Iterable of batches with the structure the reference's tf.data pipeline yields."""
 
-    def __init__(self, x, y, batch_size, train, loop_time, shuffle_size, seed=None):
+    def __init__(self, x, y, batch_size, train, loop_time, shuffle_size, seed=None, device_transforms=None):
         self.x, self.y = x, y
         self.batch_size, self.train, self.loop_time, self.shuffle_size = batch_size, train, loop_time, shuffle_size
         self.rng = np.random.default_rng(seed)
+        # augmentations f(x_dev, y_total_dev, rng) -> (x_dev, y_total_dev) run by the step loop on the device batch
+        # (seld_amd.transforms); with any of them the labels stay unsplit until they have run
+        self.device_transforms = list(device_transforms or [])
 
     def __len__(self):
         n = self.x.shape[0] * (self.loop_time if self.train else 1)
@@ -55,7 +59,10 @@ class SeldDataset:
         idx = np.concatenate([np.arange(self.x.shape[0])] * reps)      # cache().repeat(loop_time)
         for i in range(0, idx.size, self.batch_size):                  # batch(drop_remainder=False)
             sel = idx[i:i + self.batch_size]
-            yield split_total_labels_to_sed_doa(self.x[sel], self.y[sel])
+            if self.device_transforms:
+                yield self.x[sel], self.y[sel]                         # total labels [b,60,4C]: split after the transforms
+            else:
+                yield split_total_labels_to_sed_doa(self.x[sel], self.y[sel])
 
     def __iter__(self):
         if not self.train or not self.shuffle_size or self.shuffle_size <= 1:
@@ -78,8 +85,9 @@ class SeldDataset:
 
 def seldnet_data_to_dataloader(features, labels, train=True, label_window_size=60, drop_remainder=True,
                                shuffle_size=None, batch_size=32, loop_time=1, seed=None, **kwargs):
-    if kwargs.get('sample_transforms') or kwargs.get('preprocessing'):
-        raise ValueError('sample transforms / augmentation are outside the accelerated path')
+    if kwargs.get('sample_transforms') or kwargs.get('preprocessing') or kwargs.get('batch_transforms'):
+        raise ValueError('host-side tf.data transforms are not taken: pass device_transforms (seld_amd.transforms)')
+    device_transforms = kwargs.get('device_transforms')
     total_length = labels[0].shape[0]
     features = np.concatenate(features, axis=0)
     labels = np.concatenate(labels, axis=0)
@@ -94,4 +102,4 @@ def seldnet_data_to_dataloader(features, labels, train=True, label_window_size=6
     if train and shuffle_size is None:
         shuffle_size = n_samples // batch_size
     return SeldDataset(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), batch_size, train,
-                       loop_time, shuffle_size, seed)
+                       loop_time, shuffle_size, seed, device_transforms)

@@ -63,7 +63,7 @@ def get_param(known=None, model_config_dir: str = './model_config'):
         raise ValueError(f'--doa_loss {config.doa_loss} has no MI355X kernel (built: MSE, MMSE)')
     if config.sed_loss != 'BCE':
         raise ValueError('--sed_loss FOCAL has no MI355X kernel (built: BCE)')
-    for flag in ('use_acs', 'use_tdm', 'use_tfm'):
-        if getattr(config, flag):
-            raise ValueError(f'--{flag}: augmentation is outside the accelerated path (SURVEY.md §2)')
+    if config.use_tdm:
+        raise ValueError('--use_tdm: time-domain mixing works on raw wavs outside the accelerated path (SURVEY.md §2); '
+                         '--use_tfm and --use_acs run on the device')
     return config, model_config

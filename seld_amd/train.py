@@ -85,13 +85,21 @@ def teststep(model: SeldNet, x, y, sed_loss, doa_loss):
 
 # ---------------------------------------------------------------------------------------------------
 def get_dataset(config, mode: str = 'train'):
-    """reference train.get_dataset (train.py:150-176) without the augmentation branches."""
+    """reference train.get_dataset (train.py:150-176).  --use_tfm: time and frequency masks (transforms.mask, per
+    sample and per 100-frame segment); --use_acs: foa_intensity_vec_aug on the batch — both on the device
+    (seld_amd.transforms), applied by `iterloop` to the batch after its host->HBM copy."""
     import os
-    from . import data_loader as dl
+    from . import data_loader as dl, transforms as tfm
     path = os.path.join(config.abspath, 'DCASE2021/feat_label/')
     x, y = dl.load_seldnet_data(os.path.join(path, 'foa_dev_norm'), os.path.join(path, 'foa_dev_label'), mode=mode, n_freq_bins=64)
+    device_transforms = []
+    if getattr(config, 'use_tfm', False) and mode == 'train':
+        device_transforms.append(lambda x, y, rng: (tfm.mask(x, -3, max_mask_size=config.time_mask_size, rng=rng), y))
+        device_transforms.append(lambda x, y, rng: (tfm.mask(x, -2, max_mask_size=config.freq_mask_size, rng=rng), y))
+    if getattr(config, 'use_acs', False) and mode == 'train':
+        device_transforms.append(lambda x, y, rng: tfm.foa_intensity_vec_aug(x, y, rng=rng))
     return dl.seldnet_data_to_dataloader(x, y, train=mode == 'train', label_window_size=60, batch_size=config.batch,
-                                         loop_time=config.loop_time)
+                                         loop_time=config.loop_time, device_transforms=device_transforms)
 
 
 def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, metric_class, config, optimizer=None, mode='train',
@@ -105,7 +113,15 @@ def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, metric_class, config, 
     tot_s = torch.zeros((), device=model._dev)
     tot_d = torch.zeros((), device=model._dev)
     n = 0
+    dev_tf = getattr(dataset, 'device_transforms', None)
     for x, y in dataset:
+        if dev_tf:        # augmentation on the device batch; labels arrive unsplit [b,60,4C] (data_loader.SeldDataset)
+            x = torch.as_tensor(x, dtype=torch.float32).to(model._dev).contiguous()
+            y = torch.as_tensor(y, dtype=torch.float32).to(model._dev).contiguous()
+            for f in dev_tf:
+                x, y = f(x, y, dataset.rng)
+            nc = y.shape[-1] // 4
+            y = (y[..., :nc].contiguous(), y[..., nc:].contiguous())
         if mode == 'train':
             preds, sloss, dloss = trainstep(model, x, y, sed_loss, doa_loss, loss_weight, optimizer, config.agc, process_group)
         else:

@@ -24,6 +24,11 @@ def test_get_param_defaults_match_reference(tmp_path, seldnet_config):
     with pytest.raises(ValueError):
         params.get_param(["--name", "x", "--doa_loss", "MAE"], model_config_dir=str(d))
     assert params.get_param(["--name", "x", "--agc", "False"], model_config_dir=str(d))[0].agc is True   # type=bool quirk
+    # augmentation flags: masks and foa swapping run on the device; time-domain mixing is refused loudly
+    cfg = params.get_param(["--name", "x", "--use_tfm", "--use_acs"], model_config_dir=str(d))[0]
+    assert cfg.use_tfm and cfg.use_acs and (cfg.time_mask_size, cfg.freq_mask_size) == (24, 16)
+    with pytest.raises(ValueError):
+        params.get_param(["--name", "x", "--use_tdm"], model_config_dir=str(d))
 
 
 def _write_dataset(root, n_per_fold=1):
@@ -61,3 +66,16 @@ def test_load_and_window(tmp_path):
     assert xb.shape == (10, 300, 64, 7)                        # eval: one file per batch
     np.testing.assert_array_equal(xb, fw[:10])
     np.testing.assert_array_equal(np.concatenate([sed, doa], -1), lw[:10])
+
+
+def test_dataset_with_device_transforms_keeps_labels_unsplit(tmp_path):
+    """With augmentations attached the loader yields the total label tensor [b,60,4C] (they act on it before the
+    sed/doa split, train.py:162-165); host-side tf.data style transforms are refused."""
+    from seld_amd import data_loader as dl
+    feat, lab = _write_dataset(tmp_path, 1)
+    x, y = dl.load_seldnet_data(feat, lab, mode="train")
+    ds = dl.seldnet_data_to_dataloader(x, y, train=True, batch_size=8, loop_time=1, seed=0, device_transforms=[lambda a, b, r: (a, b)])
+    xb, yb = next(iter(ds))
+    assert xb.shape == (8, 300, 64, 7) and yb.shape == (8, 60, 48) and len(ds.device_transforms) == 1
+    with pytest.raises(ValueError):
+        dl.seldnet_data_to_dataloader(x, y, sample_transforms=[lambda a, b: (a, b)])
