@@ -701,13 +701,17 @@ int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, flo
 // ================================================================================================
 #define WG64_SLAB (9 * 4096 + 64)
 
+constexpr int conv64_wgrad_chunk_px(int W) { return W == 16 ? 128 : 96; }
+
 template <int WLOG2>
 __global__ __launch_bounds__(256) void conv64_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ slab, int B, int H) {
-    constexpr int W = 1 << WLOG2, R = 128 / W, RW = W + 2, RR = R + 2;
+    // pixels per chunk: 128 at W = 16 (78 KB of LDS), 96 elsewhere so that two blocks fit a CU (at W = 4 a 128-pixel
+    // chunk needs 84 KB: one block per CU, nobody to hide the chunk load behind — measured 32 % MFMA utilisation)
+    constexpr int W = 1 << WLOG2, PXC = conv64_wgrad_chunk_px(W), R = PXC / W, RW = W + 2, RR = R + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xr = smem;                    // [RR][RW][64]
-    float* dzl = smem + RR * RW * 64;    // [128][64]
+    float* dzl = smem + RR * RW * 64;    // [PXC][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
     const int cih = wave >> 1, coh = wave & 1;
@@ -731,8 +735,8 @@ __global__ __launch_bounds__(256) void conv64_wgrad_kernel(const float* __restri
             reinterpret_cast<float4*>(xr)[idx] = v;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = tid + 256 * u;  // float4 index, 2048 per chunk
+        for (int u = 0; u < PXC / 16; ++u) {
+            const int idx = tid + 256 * u;  // float4 index, PXC * 16 per chunk
             const int px = idx >> 4;
             const int t = t0 + (px >> WLOG2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(256) void conv64_wgrad_kernel(const float* __restri
         __syncthreads();
         if (tid < 64) {
             float s = 0.f;
-            for (int px = 0; px < 128; ++px) s += dzl[px * 64 + tid];
+            for (int px = 0; px < PXC; ++px) s += dzl[px * 64 + tid];
             brun += s;
         }
         {
@@ -758,12 +762,14 @@ __global__ __launch_bounds__(256) void conv64_wgrad_kernel(const float* __restri
                 for (int tap = 0; tap < 9; ++tap) a9[tap] = ap[((tap / 3) * RW + (tap % 3)) * 64];
             };
             ldw(0, ca, cb);
-#pragma unroll 2
-            for (int s = 0; s < 64; ++s) {
+            // fully unrolled: across a loop back-edge the waitcnt bookkeeping fell back to lgkmcnt(0) in front of the
+            // MFMAs, i.e. it also waited for the prefetch just issued (one LDS round trip per two steps)
+#pragma unroll
+            for (int s = 0; s < PXC / 2; ++s) {
                 float na[9], nb = 0.f;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) na[tap] = 0.f;
-                if (s + 1 < 64) ldw(s + 1, na, nb);
+                if (s + 1 < PXC / 2) ldw(s + 1, na, nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) acc[tap] = MFMA_F32_32x32x2(ca[tap], cb, acc[tap]);
@@ -788,10 +794,10 @@ int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* 
     int wl = -1;
     if (W == 16) wl = 4; else if (W == 4) wl = 2; else if (W == 8) wl = 3; else if (W == 32) wl = 5; else if (W == 2) wl = 1;
     if (wl < 0) return -2;
-    const int R = 128 / W;
+    const int PXC = conv64_wgrad_chunk_px(W), R = PXC / W;
     const int nchunks = B * ((H + R - 1) / R);
     const int grid = nchunks < WGRAD_MAX_BLOCKS ? nchunks : WGRAD_MAX_BLOCKS;
-    const size_t smem = (size_t)((R + 2) * (W + 2) * 64 + 128 * 64) * sizeof(float);
+    const size_t smem = (size_t)((R + 2) * (W + 2) * 64 + PXC * 64) * sizeof(float);
 #define LAUNCH_WG(L)                                                                                          \
     {                                                                                                         \
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_kernel<L>),                            \
