@@ -373,7 +373,7 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                float* __restrict__ slab, int B, int H) {
     using G = FirstGeom<CIN>;
-    constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
+    constexpr int K = G::K, ROWF = G::ROWF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                 // [256 px][64 co]
     float* patch = smem + 256 * 64;    // [6][66][CIN]
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
                                                                      const float* __restrict__ coef, float* __restrict__ slab,
                                                                      int B, int H) {
     using G = FirstGeom<CIN>;
-    constexpr int K = G::K, KPAD = G::KPAD, ROWF = G::ROWF;
+    constexpr int K = G::K, ROWF = G::ROWF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                 // [256 px][64 co]
     float* patch = smem + 256 * 64;    // [6][66][CIN]

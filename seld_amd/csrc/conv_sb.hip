@@ -287,15 +287,25 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
         SBR_COMMIT_W()
     }
     lds_barrier();
+#ifdef SBR_TIMING
+    long long tm_mfma = 0, tm_b1 = 0, tm_cw = 0, tm_b2 = 0, tm_epi = 0, tm_top = 0, ttop = clock64();
+    int tm_n = 0;
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * R;
         const int nxt = tile + gridDim.x;
         SBR_ISSUE_REGION(nxt < ntiles ? nxt : tile)     // unconditional: no phi on the staged registers
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[2] = {zero16(), zero16()};
+        f32x16 acc[2] = {zero16(), zero16()}, accs[2] = {zero16(), zero16()};
         const unsigned short* wrow0 = Wp + li * SB_LD + 8 * hi;
+#ifdef SBR_TIMING
+        const long long tc0 = clock64();
+#endif
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
+#ifdef SBR_TIMING
+            const long long ta = clock64();
+#endif
             SBR_ISSUE_W(tap < 8 ? tap + 1 : 0)          // tap 8 prefetches tap 0 of the next tile
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads ahead of the MFMA steps
             const unsigned short* arow = Rp + rbase + ((tap / 3) * RW + (tap % 3)) * SB_LD;
@@ -308,23 +318,41 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
                     bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 16 * s);
                     bb[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 32 * SB_LD + 16 * s);
                 }
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0][c], acc[c], 0, 0, 0);   // hi*hi
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1][c], acc[c], 0, 0, 0);   // hi*mid
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0][c], acc[c], 0, 0, 0);   // mid*hi
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2][c], acc[c], 0, 0, 0);   // hi*lo
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0][c], acc[c], 0, 0, 0);   // lo*hi
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1][c], acc[c], 0, 0, 0);   // mid*mid
-                }
+                // Four accumulator chains (channel half x {large, small} products), visited round-robin: a dependent
+                // v_mfma_f32_32x32x16_bf16 cannot issue before its predecessor has left the pipe, and runs of six
+                // MFMAs into one accumulator (the natural order) held the matrix pipe at about half rate.
+#define SBR_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+                SBR_MFMA(a[0], bb[0][0], acc[0]);  SBR_MFMA(a[0], bb[0][1], acc[1]);     // hi*hi
+                SBR_MFMA(a[0], bb[1][0], accs[0]); SBR_MFMA(a[0], bb[1][1], accs[1]);    // hi*mid
+                SBR_MFMA(a[1], bb[0][0], acc[0]);  SBR_MFMA(a[1], bb[0][1], acc[1]);     // mid*hi
+                SBR_MFMA(a[0], bb[2][0], accs[0]); SBR_MFMA(a[0], bb[2][1], accs[1]);    // hi*lo
+                SBR_MFMA(a[2], bb[0][0], acc[0]);  SBR_MFMA(a[2], bb[0][1], acc[1]);     // lo*hi
+                SBR_MFMA(a[1], bb[1][0], accs[0]); SBR_MFMA(a[1], bb[1][1], accs[1]);    // mid*mid
+#undef SBR_MFMA
             }
             // The commit is UNCONDITIONAL (after tap 8 it stores tap 0 of the next tile): when the staged
             // registers were only used inside an `if (tap < 8)` block the compiler sank the global loads
             // into that block, i.e. behind the barrier, and every tap paid a full L2 round trip.
+#ifdef SBR_TIMING
+            const long long tb = clock64();
+#endif
             lds_barrier();
+#ifdef SBR_TIMING
+            const long long tcc = clock64();
+#endif
             SBR_COMMIT_W()
+#ifdef SBR_TIMING
+            const long long td = clock64();
+#endif
             lds_barrier();
+#ifdef SBR_TIMING
+            const long long te = clock64();
+            tm_mfma += tb - ta; tm_b1 += tcc - tb; tm_cw += td - tcc; tm_b2 += te - td;
+#endif
         }
+#ifdef SBR_TIMING
+        const long long tf = clock64();
+#endif
         SBR_COMMIT_REGION()     // next tile's region (every wave passed the barrier after tap 8's reads)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -334,7 +362,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
                 const int p = wave * 32 + mfma_row(r, hi);          // pixel of the tile
                 const int t = t0 + (p >> WLOG2);
                 if (t < H) {
-                    const float v = acc[c][r] + bv;
+                    const float v = (acc[c][r] + accs[c][r]) + bv;
                     z[((size_t)(b * H + t) * W + (p & (W - 1))) * 64 + c * 32 + li] = v;
                     s1[c] += v;
                     s2[c] = fmaf(v, v, s2[c]);
@@ -342,7 +370,15 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
             }
         }
         lds_barrier();          // the committed region is visible to every wave
+#ifdef SBR_TIMING
+        tm_epi += clock64() - tf; tm_top += tc0 - ttop; ttop = clock64(); ++tm_n;
+#endif
     }
+#ifdef SBR_TIMING
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 200))
+        printf("sbr W=%d block %d tiles %d: per tile top %lld  mfma+issue %lld  barrier1 %lld  commitW %lld  barrier2 %lld  epilogue+commitR %lld\n",
+               W, blockIdx.x, tm_n, tm_top / tm_n, tm_mfma / tm_n, tm_b1 / tm_n, tm_cw / tm_n, tm_b2 / tm_n, tm_epi / tm_n);
+#endif
 #undef SBR_ISSUE_REGION
 #undef SBR_COMMIT_REGION
 #undef SBR_ISSUE_W
