@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void conv64_fwd_sb_kernel(const float* __restr
 // The (R+2) x (W+2) input region is loaded ONCE per tile (prefetched into registers under the previous
 // tile's MFMAs), split into the three bf16 planes once, and all 9 taps read their A fragments from it at
 // shifted pixel rows; only the 27 KB of pre-split weights change per tap.
-template <int WLOG2, int R, bool STATS>
+template <int WLOG2, int R, bool SWZ, bool STATS>
 __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
     float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
@@ -204,10 +204,16 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
     constexpr int NW4 = 3 * 64 * 8, NWF = (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
     static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
+    // LDS rows of 64 bf16 (128 B).  Padded layout: row stride 72 (SB_LD).  Swizzled layout (SWZ): stride 64 and
+    // the 16-byte chunk c of row p stored at chunk c ^ ((p >> 1) & 7): 16 consecutive rows x one chunk index
+    // still cover all 64 banks, with no padding — which is what lets a 256-pixel tile (8 waves, two per SIMD)
+    // fit the 160 KB of LDS next to a tap's weights.
+    constexpr int LD = SWZ ? 64 : SB_LD;
     extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
-    unsigned short* Rp = sb_smem;                          // [3][NPIX][SB_LD]
-    unsigned short* Wp = sb_smem + 3 * NPIX * SB_LD;       // [3][64][SB_LD]
-    float* red = reinterpret_cast<float*>(Wp + SB_W_ELEMS);   // [NW][128]
+    unsigned short* Rp = sb_smem;                          // [3][NPIX][LD]
+    unsigned short* Wp = sb_smem + 3 * NPIX * LD;          // [3][64][LD]
+    float* red = reinterpret_cast<float*>(Wp + 3 * 64 * LD);  // [NW][128]
+#define SBR_CH(p_, c_) (SWZ ? ((c_) ^ (((p_) >> 1) & 7)) : (c_))      /* where chunk c_ of row p_ lives */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
     const int tiles_per_img = (H + R - 1) / R;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
         roff[u] = ((rr - 1) * W + (cc - 1)) * 64 + g * 4;
     }
     float4 rreg[NPF];
-    static_assert(NWF == 4, "weight staging is four named registers");
+    static_assert(NWF == 4 || NWF == 3, "weight staging is three or four named registers");
     u32x4 wreg0, wreg1, wreg2, wreg3;      // named (an indexed array of these was demoted to scratch)
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #define SBR_ISSUE_REGION(tile_)                                                                         \
@@ -246,10 +252,10 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
             unsigned h0, m0, l0, h1, m1, l1;                                                            \
             split3_pair(rreg[u].x, rreg[u].y, h0, m0, l0);                                              \
             split3_pair(rreg[u].z, rreg[u].w, h1, m1, l1);                                              \
-            unsigned short* d_ = Rp + (idx >> 4) * SB_LD + (idx & 15) * 4;                              \
+            unsigned short* d_ = Rp + (idx >> 4) * LD + SBR_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
             *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                         \
-            *reinterpret_cast<uint2*>(d_ + NPIX * SB_LD) = make_uint2(m0, m1);                          \
-            *reinterpret_cast<uint2*>(d_ + 2 * NPIX * SB_LD) = make_uint2(l0, l1);                      \
+            *reinterpret_cast<uint2*>(d_ + NPIX * LD) = make_uint2(m0, m1);                             \
+            *reinterpret_cast<uint2*>(d_ + 2 * NPIX * LD) = make_uint2(l0, l1);                         \
         }                                                                                               \
     }
 #define SBR_W_SRC(tap_, u_) \
@@ -259,14 +265,14 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
         wreg0 = SBR_W_SRC(tap_, 0);                                                                     \
         wreg1 = SBR_W_SRC(tap_, 1);                                                                     \
         wreg2 = SBR_W_SRC(tap_, 2);                                                                     \
-        wreg3 = SBR_W_SRC(tap_, 3);                                                                     \
+        if (NWF > 3) wreg3 = SBR_W_SRC(tap_, 3);                                                        \
     }
 #define SBR_W_DST(u_, v_)                                                                               \
     {                                                                                                   \
         const int idx = tid + NT * (u_);                                                                \
         if (idx < NW4) {                                                                                \
             const int pl = idx >> 9, rem = idx & 511;      /* 512 uint4 per plane: row = rem>>3 */      \
-            *reinterpret_cast<u32x4*>(Wp + pl * 64 * SB_LD + (rem >> 3) * SB_LD + (rem & 7) * 8) = v_;  \
+            *reinterpret_cast<u32x4*>(Wp + pl * 64 * LD + (rem >> 3) * LD + SBR_CH(rem >> 3, rem & 7) * 8) = v_; \
         }                                                                                               \
     }
 #define SBR_COMMIT_W()                                                                                  \
@@ -274,12 +280,12 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
         SBR_W_DST(0, wreg0)                                                                             \
         SBR_W_DST(1, wreg1)                                                                             \
         SBR_W_DST(2, wreg2)                                                                             \
-        SBR_W_DST(3, wreg3)                                                                             \
+        if (NWF > 3) SBR_W_DST(3, wreg3)                                                                \
     }
     int tile = blockIdx.x;
     // region row of this lane's pixel for tap (0,0): pixel p = 32*wave + li of the tile -> (r, c)
     const int pl_ = wave * 32 + li;
-    const int rbase = ((pl_ >> WLOG2) * RW + (pl_ & (W - 1))) * SB_LD + 8 * hi;
+    const int pbase = (pl_ >> WLOG2) * RW + (pl_ & (W - 1));       // region row of this lane's pixel at tap (0,0)
     if (tile < ntiles) {
         SBR_ISSUE_REGION(tile)
         SBR_ISSUE_W(0)
@@ -297,7 +303,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
         SBR_ISSUE_REGION(nxt < ntiles ? nxt : tile)     // unconditional: no phi on the staged registers
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2] = {zero16(), zero16()}, accs[2] = {zero16(), zero16()};
-        const unsigned short* wrow0 = Wp + li * SB_LD + 8 * hi;
+        const unsigned short* wrow0 = Wp + li * LD;
+        const int wsw = (li >> 1) & 7;        // swizzle key of weight rows li and li + 32 (the same)
 #ifdef SBR_TIMING
         const long long tc0 = clock64();
 #endif
@@ -308,15 +315,18 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
 #endif
             SBR_ISSUE_W(tap < 8 ? tap + 1 : 0)          // tap 8 prefetches tap 0 of the next tile
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads ahead of the MFMA steps
-            const unsigned short* arow = Rp + rbase + ((tap / 3) * RW + (tap % 3)) * SB_LD;
+            const int prow = pbase + (tap / 3) * RW + (tap % 3);
+            const unsigned short* arow = Rp + prow * LD;
+            const int asw = (prow >> 1) & 7;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 bf16x8 a[3], bb[3][2];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * NPIX * SB_LD + 16 * s);
-                    bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 16 * s);
-                    bb[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * SB_LD + 32 * SB_LD + 16 * s);
+                    const int ca = SWZ ? ((2 * s + hi) ^ asw) : (2 * s + hi), cw = SWZ ? ((2 * s + hi) ^ wsw) : (2 * s + hi);
+                    a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * NPIX * LD + 8 * ca);
+                    bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 8 * cw);
+                    bb[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 32 * LD + 8 * cw);
                 }
                 // Four accumulator chains (channel half x {large, small} products), visited round-robin: a dependent
                 // v_mfma_f32_32x32x16_bf16 cannot issue before its predecessor has left the pipe, and runs of six
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
 #undef SBR_COMMIT_REGION
 #undef SBR_ISSUE_W
 #undef SBR_COMMIT_W
+#undef SBR_CH
 #undef SBR_W_SRC
 #undef SBR_W_DST
     if (STATS) {
@@ -408,19 +419,19 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbr_k
     }
 }
 
-template <int WLOG2, int R>
+template <int WLOG2, int R, bool SWZ>
 static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                       float* stat_partial, int* n_partial, int B, int H) {
-    constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * (W + 2);
+    constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * (W + 2), LD = SWZ ? 64 : SB_LD;
     const int ntiles = B * ((H + R - 1) / R);
     const int grid = ntiles < 256 ? ntiles : 256;      // one block per CU (LDS-limited), persistent
-    const size_t smem = (size_t)(3 * NPIX * SB_LD + SB_W_ELEMS) * sizeof(unsigned short) + (size_t)NW * 128 * sizeof(float);
+    const size_t smem = (size_t)(3 * NPIX * LD + 3 * 64 * LD) * sizeof(unsigned short) + (size_t)NW * 128 * sizeof(float);
     if (stat_partial) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, SWZ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, SWZ, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, false>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbr_kernel<WLOG2, R, SWZ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbr_kernel<WLOG2, R, SWZ, false>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
     }
     if (n_partial) *n_partial = grid;
     return 0;
@@ -428,8 +439,8 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
 
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W) {
-    if (W == 16) return launch_sbr<4, 14>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);
-    if (W == 4) return launch_sbr<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);
+    if (W == 16) return launch_sbr<4, 16, true>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves, 153 KB
+    if (W == 4) return launch_sbr<2, 48, false>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 6 waves (halo columns: no room for 8)
     const int npix = B * H * W;
     const int ntiles = (npix + 255) / 256;
     const int grid = ntiles < SB_MAX_PERSISTENT ? ntiles : SB_MAX_PERSISTENT;
