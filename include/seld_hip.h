@@ -100,6 +100,12 @@ void* seld_grad_ptr(seld_ctx* ctx);  /* device, [param_count] fp32: the DP all-r
  * moving statistics updated.  sed [B,S,nc], doa [B,S,3nc], S = T / prod(pool_t). */
 int seld_forward(seld_ctx* ctx, const float* x, float* sed, float* doa, int training);
 
+/* Data-parallel overlap: after seld_train_fwd_bwd has been ENQUEUED, make `stream` wait until the gradients of the
+ * GRU and head variables — grads[*offset : param_count), 86 % of the buffer — are final.  They are produced on the
+ * library's side stream early in the backward pass, so a host can start their all-reduce on a communication stream
+ * while the conv backward is still running on the main stream; grads[0 : *offset) (conv/BN) are final when the main
+ * stream has drained.  (No counterpart in the reference, which has no distributed path.) */
+int seld_grads_tail_ready(seld_ctx* ctx, void* stream, int64_t* offset);
 /* ---- train.trainstep (train.py:22-36), split so that a data-parallel host can all-reduce
  * seld_grad_ptr() between the two halves:
  *   seld_train_fwd_bwd : forward(training=True) + losses + tape.gradient -> grad buffer

@@ -74,6 +74,7 @@ SIGNATURES = {
     "seld_grad_ptr": (_P, [_P]),
     "seld_forward": (_I, [_P, _P, _P, _P, _I]),
     "seld_train_fwd_bwd": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
+    "seld_grads_tail_ready": (_I, [_P, _P, C.POINTER(_L)]),
     "seld_adam_step": (_I, [_P, _F, _F, _F, _F, _I]),
     "seld_train_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _F, _I, _P, _P, _P, _P]),
     "seld_test_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),

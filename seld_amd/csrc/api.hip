@@ -626,6 +626,16 @@ static int backward_impl(seld_ctx* c, const float* x) {
     return check_launch(c, "backward");
 }
 
+int seld_grads_tail_ready(seld_ctx* c, void* stream, int64_t* offset) {
+    if (!c || !offset || c->gru.empty()) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    // the GRU and head variables follow the conv/BN ones in the flat buffer; their gradients are the side stream's
+    // work, complete at ev_join (recorded by the last seld_train_fwd_bwd)
+    *offset = c->gru[0].k_off[0];
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_join, 0));
+    return SELD_OK;
+}
+
 int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,
                        float* sed, float* doa, float* sloss, float* dloss) {
     if (!c || !x || !y_sed || !y_doa || !cfg) return SELD_ERR_INVALID;

@@ -64,7 +64,7 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     _lib.check(model.lib.seld_train_fwd_bwd(model.ctx, x.data_ptr(), ys.data_ptr(), yd.data_ptr(), C.byref(cfg),
                                             sed.data_ptr(), doa.data_ptr(), sloss.data_ptr(), dloss.data_ptr()), model.ctx)
     if world > 1:
-        parallel.allreduce_gradients(model.grad_tensor(), process_group)
+        parallel.allreduce_gradients(model.grad_tensor(), process_group, model)
     _lib.check(model.lib.seld_adam_step(model.ctx, optimizer.learning_rate, optimizer.beta_1, optimizer.beta_2,
                                         optimizer.epsilon, int(bool(agc))), model.ctx)
     return [sed, doa], sloss, dloss
