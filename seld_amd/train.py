@@ -84,8 +84,9 @@ def teststep(model: SeldNet, x, y, sed_loss, doa_loss):
 
 
 # ---------------------------------------------------------------------------------------------------
-def get_dataset(config, mode: str = 'train'):
-    """reference train.get_dataset (train.py:150-176).  --use_tfm: time and frequency masks (transforms.mask, per
+def get_dataset(config, mode: str = 'train', device=None):
+    """reference train.get_dataset (train.py:150-176).  `device`: keep the windowed dataset resident in that GPU's HBM
+    (batches are device-side gathers; what `main` does) instead of yielding numpy batches.  --use_tfm: time and frequency masks (transforms.mask, per
     sample and per 100-frame segment); --use_acs: foa_intensity_vec_aug on the batch — both on the device
     (seld_amd.transforms), applied by `iterloop` to the batch after its host->HBM copy."""
     import os
@@ -98,8 +99,9 @@ def get_dataset(config, mode: str = 'train'):
         device_transforms.append(lambda x, y, rng: (tfm.mask(x, -2, max_mask_size=config.freq_mask_size, rng=rng), y))
     if getattr(config, 'use_acs', False) and mode == 'train':
         device_transforms.append(lambda x, y, rng: tfm.foa_intensity_vec_aug(x, y, rng=rng))
-    return dl.seldnet_data_to_dataloader(x, y, train=mode == 'train', label_window_size=60, batch_size=config.batch,
-                                         loop_time=config.loop_time, device_transforms=device_transforms)
+    ds = dl.seldnet_data_to_dataloader(x, y, train=mode == 'train', label_window_size=60, batch_size=config.batch,
+                                       loop_time=config.loop_time, device_transforms=device_transforms)
+    return ds.to_device(device) if device is not None else ds
 
 
 def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, metric_class, config, optimizer=None, mode='train',
@@ -145,7 +147,8 @@ def main(config, model_config=None, max_epochs=None):
     from . import models
     if isinstance(config, tuple):
         config, model_config = config
-    trainset, valset = get_dataset(config, 'train'), get_dataset(config, 'val')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    trainset, valset = get_dataset(config, 'train', dev), get_dataset(config, 'val', dev)    # HBM-resident
     x, y = next(iter(trainset.take(1)))
     input_shape = (max(config.batch, valset.batch_size),) + tuple(x.shape[1:])
     model_config = dict(model_config)
