@@ -11,6 +11,8 @@
 // Block partials go to slabs that reduce_slabs_kernel (gemm.hip) combines in a fixed order.
 #include "common.h"
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 #define CONV_MAX_PERSISTENT 768
 int conv_stat_partial_capacity() { return CONV_MAX_PERSISTENT; }
 #define WGRAD_MAX_BLOCKS 512
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 // Each thread owns a 4-row x 4-pixel x 4-channel block of the tile, so it needs ONE pooled column
 // (PF = 4) and at most two pooled rows of p / dp.
 template <int CIN, int PT>
-__global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float* __restrict__ x, const float* __restrict__ z,
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_fused_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                                      const float* __restrict__ p, const float* __restrict__ dp,
                                                                      const unsigned char* __restrict__ amax,
                                                                      const float* __restrict__ coef, float* __restrict__ slab,
@@ -512,6 +514,12 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
         // k == K is the bias row: its A operand is the constant 1.0 parked at patch[PATCH];
         // k > K (padding of the last k-tile) reads the 0.0 parked at patch[PATCH + 1]
         koffs[kt] = (k < K) ? wave * ROWF + kh * ROWF + (k - kh * 3 * CIN) : (k == K ? -1 : -2);
+    }
+    int pa[NKT], sa[NKT];    // patch address of this lane's A operand at step 0, and its stride per step (0 for the constant rows)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        pa[kt] = koffs[kt] >= 0 ? koffs[kt] + hi * CIN : G::PATCH - 1 - koffs[kt];
+        sa[kt] = koffs[kt] >= 0 ? 2 * CIN : 0;
     }
     const int tiles_per_img = (H + 3) >> 2;
     const int ntiles = B * tiles_per_img;
@@ -536,14 +544,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     float4 zr[16], pr[2], dpr[2];
     unsigned ar[2];    // window positions of the extreme, 4 channels packed (amax bytes)
     int st_t0 = 0;     // t0 of the staged tile
-    auto issue_z = [&](int b, int t0) {
+    const float* zn = z;   // staged tile: this thread's first z element (row 0, pixel 4q, channels 4g..)
+    // the 16 z loads of a tile are issued ONE PER TWO K-STEPS inside the previous tile's MFMA loop (WGF_ZLOAD): issued
+    // in a burst at the top of the tile they kept the wave ~6 k cycles in back-pressured VMEM issue while HBM then
+    // sat idle for the rest of the tile (cycle counters: 3.9 TB/s of the 6.3 the card streams)
+    auto issue_small = [&](int b, int t0) {
         st_t0 = t0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int row = u >> 2, px = 4 * q + (u & 3);
-            zr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + row < H) zr[u] = *reinterpret_cast<const float4*>(z + ((size_t)(b * H + t0 + row) * 64 + px) * 64 + g * 4);
-        }
+        zn = z + ((size_t)(b * H + t0) * 64 + 4 * q) * 64 + g * 4;
         const int pr0 = t0 / PT;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -554,29 +561,45 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
             ar[v] = *reinterpret_cast<const unsigned*>(amax + off);
         }
     };
+#define WGF_ZLOAD(u_)                                                                                   \
+    {                                                                                                   \
+        const bool ok_ = st_t0 + ((u_) >> 2) < H;          /* uniform */                                \
+        const u32x4 v_ = *reinterpret_cast<const u32x4*>(ok_ ? zn + (((u_) >> 2) * 64 + ((u_) & 3)) * 64 : z) & (ok_ ? 0xffffffffu : 0u); \
+        zr[u_] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
+    }
     auto commit_dz = [&]() {
+        // dz = scale*(dy - c1 - xhat*c2) = fma(z, ka, kb) + (argmax ? scale*dp : 0).  The argmax is the ONE position the
+        // forward recorded (MaxPoolGrad routes to a single element): testing y == p instead double-counts dp whenever
+        // two pixels of a window round to the same fp32 y — a few windows per step at B = 32, each worth ~1e-3 of a
+        // kernel gradient's scale.  Per pooled row and channel: key = that position (255 = no gradient: p <= 0) and
+        // kbg = kb + scale*dp, so that an element costs a compare, a select and one fma: fma(z, ka, hit ? kbg : kb).
         const int pr0 = st_t0 / PT;
+        unsigned key[2][4];
+        float kbg[2][4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const float pp[4] = {pr[v].x, pr[v].y, pr[v].z, pr[v].w}, dd[4] = {dpr[v].x, dpr[v].y, dpr[v].z, dpr[v].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                key[v][c] = pp[c] > 0.f ? ((ar[v] >> (8 * c)) & 255u) : 255u;
+                kbg[v][c] = kb[c] + sc[c] * dd[c];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int row = u >> 2, px = 4 * q + (u & 3);
-            const int t = st_t0 + row;
-            const bool second = (t / PT) != pr0;
-            const float4 pv = second ? pr[1] : pr[0];
-            const float4 dv = second ? dpr[1] : dpr[0];
-            const unsigned av = second ? ar[1] : ar[0];
+            const int t = st_t0 + row;                                              // uniform
+            const int v = (t / PT) != pr0 ? 1 : 0;
             const unsigned pos = (unsigned)((t - (t / PT) * PT) * 4 + (u & 3));    // this pixel's position in its window
             const float zz[4] = {zr[u].x, zr[u].y, zr[u].z, zr[u].w};
-            const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                // dz = scale*(dy - c1 - xhat*c2) = fma(z, ka, kb) + (argmax ? scale*dp : 0).  The argmax is the ONE
-                // position the forward recorded (MaxPoolGrad routes to a single element): testing y == p instead
-                // double-counts dp whenever two pixels of a window round to the same fp32 y — a few windows per
-                // step at B = 32, each worth ~1e-3 of a kernel gradient's scale.
-                const float g_sel = (((av >> (8 * c)) & 255u) == pos && pp[c] > 0.f) ? sc[c] * dd[c] : 0.f;
-                o[c] = (t < H) ? fmaf(zz[c], ka[c], kb[c]) + g_sel : 0.f;
+                const unsigned kc = v ? key[1][c] : key[0][c];
+                const float kg = v ? kbg[1][c] : kbg[0][c];
+                o[c] = fmaf(zz[c], ka[c], kc == pos ? kg : kb[c]);
             }
+            if (t >= H) o[0] = o[1] = o[2] = o[3] = 0.f;                            // ragged last tile (uniform)
             *reinterpret_cast<float4*>(dzl + (size_t)(row * 64 + px) * 64 + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
     };
@@ -587,7 +610,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     if (tile < ntiles) {
         const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 4;
         stg.issue(x, b, t0, H, tid);
-        issue_z(b, t0);
+        issue_small(b, t0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) WGF_ZLOAD(u)
         stg.commit(patch, tid);
         commit_dz();
     }
@@ -600,28 +625,31 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_fused_kernel(const float
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
         const bool has_next = nxt < ntiles;
-        if (has_next) {
-            const int nb = nxt / tiles_per_img, nt0 = (nxt - nb * tiles_per_img) * 4;
+        {   // unconditional (the last tile re-stages itself): a conditional issue makes the staged registers a phi
+            const int st = has_next ? nxt : tile;
+            const int nb = st / tiles_per_img, nt0 = (st - nb * tiles_per_img) * 4;
             stg.issue(x, nb, nt0, H, tid);
-            issue_z(nb, nt0);
+            issue_small(nb, nt0);
         }
         // per step (2 pixels): 2 A reads (k-tiles) + 2 B reads (co-tiles) feed 4 MFMAs; one-step pipeline
+        const float* bp0 = dzl + (wave * 64 + hi) * 64 + li;
+        // A address = pa[kt] + s * sa[kt] (one multiply-add per read) and B address = bp0 + immediate: with per-step
+        // selects the fully unrolled loop had 64 loop-invariant addresses hoisted into registers
         auto ld = [&](int s, float (&a)[NKT], float& b0, float& b1) {
-            const int f = 2 * s + hi;                       // pixel column in this wave's row
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) a[kt] = patch[koffs[kt] >= 0 ? koffs[kt] + f * CIN : G::PATCH - 1 - koffs[kt]];
-            const float* bp = dzl + (wave * 64 + f) * 64 + li;
-            b0 = bp[0];
-            b1 = bp[32];
+            for (int kt = 0; kt < NKT; ++kt) a[kt] = patch[pa[kt] + s * sa[kt]];
+            b0 = bp0[s * 128];
+            b1 = bp0[s * 128 + 32];
         };
         float a[NKT], b0, b1;
         ld(0, a, b0, b1);
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {      // fully unrolled: precise lgkmcnt, compile-time z slot
             float na[NKT], nb0 = 0.f, nb1 = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) na[kt] = 0.f;
             if (s + 1 < 32) ld(s + 1, na, nb0, nb1);
+            if ((s & 1) == 0) WGF_ZLOAD(s >> 1)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
