@@ -40,7 +40,10 @@ def kernel_work(name, B, T, F=64, C=7):
     rows = B * S
     mac = {"conv1": px1 * 64 * 9 * C, "conv2": px2 * 64 * 576, "conv3": px3 * 64 * 576}
     table = {
-        "conv1_fwd": ("mfma", 2 * mac["conv1"]), "conv1_wgrad": ("mfma", 2 * mac["conv1"]),
+        "conv1_fwd": ("mfma", 2 * mac["conv1"]),
+        # first block's kernel gradient without the pre-BN tensor (conv_gram.hip): the dense product runs as the patch Gram
+        # matrix on the side stream; what is timed here is the sparse gather-accumulate over x, p, dp (fp32) and amax (u8)
+        "conv1_wgrad": ("hbm", 4 * (px1 * C + 2 * (px1 * 64 // 20)) + px1 * 64 // 20),
         "conv2_fwd": ("mfma", 2 * mac["conv2"]), "conv2_wgrad": ("mfma", 2 * mac["conv2"]), "conv2_dgrad": ("mfma", 2 * mac["conv2"]),
         "conv3_fwd": ("mfma", 2 * mac["conv3"]), "conv3_wgrad": ("mfma", 2 * mac["conv3"]), "conv3_dgrad": ("mfma", 2 * mac["conv3"]),
         # first block: the conv epilogue already reduced the (5,4) windows; what is left reads zext and writes p

@@ -192,10 +192,22 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
  * seldnet.json FIRST_ARGS pool_size[0]): x [B,H,64,Cin] (Cin 7 or 10, H % 5 == 0) -> z [B,H,64,64] (may be NULL:
  * not stored), zext [B,H/5,16,64] = per pooling window max(z) where gamma >= 0 / min(z) where gamma < 0, amax
  * [B,H/5,16,64] bytes = position row*4+col of that extreme inside its window (what MaxPoolGrad routes to; the first
- * in column-then-row scan order on ties; NULL exactly when z is NULL), and the batch statistics as in
+ * in column-then-row scan order on ties; may be NULL only if z is NULL), and the batch statistics as in
  * seld_k_conv3x3_fwd.  BN+ReLU is monotone in z, so MaxPool(ReLU(BN(z))) == seld_k_bn_relu_ext(zext) bit for bit. */
 int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias, const float* gamma, float* z, float* zext,
                                unsigned char* amax, float* stats, int B, int H, int Cin);
+/* The first block trained WITHOUT its pre-BN tensor (conv_gram.hip): z = P W + b is linear in the im2col patches P, so
+ * the kernel/bias gradient through BatchNorm(batch statistics)+ReLU+MaxPool(5,4) is
+ *   dW = ka (G W + g b) + g kb + M,   G = P^T P (Gram matrix of the input patches), g = column sums of P,
+ *   M[k][co] = sum over windows with p > 0 of scale[co] dp P[recorded argmax pixel][k]
+ * seld_k_conv1_gram: G alone, [KP x KP] floats with KP = 64 (Cin 7) / 128 (Cin 10); row/column 9*Cin is the ones column
+ *   (G[k][9 Cin] = g[k], G[9 Cin][9 Cin] = B*H*64); only the upper 32x32 tiles are written (symmetric).
+ * seld_k_conv1_train_gram: the whole block from x: forward (window extremes, positions, statistics, p) and backward
+ *   (dgamma, dbeta, dw [9*Cin*64], db [64]) for a given dp [B,H/5,16,64]; replaces tape.gradient through
+ *   conv2d_bn + MaxPooling2D of the first block (layers.py:27-37). */
+int seld_k_conv1_gram(const float* x, float* G, int B, int H, int Cin);
+int seld_k_conv1_train_gram(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                            const float* dp, float* p, float* dw, float* db, float* dgamma, float* dbeta, int B, int H, int Cin);
 /* p = max(0, zext * scale[c] + shift[c]) (fused multiply-add), n elements, 64 channels innermost */
 int seld_k_bn_relu_ext(const float* zext, const float* scale, const float* shift, float* p, int64_t n);
 /* input gradient of the same conv (tape.gradient through Conv2D): dz [B,H,W,64] -> dx [B,H,W,Cin=64] */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "seld_profile_reset": (_I, [_P]),
     "seld_k_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_conv_first_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    "seld_k_conv1_gram": (_I, [_P, _P, _I, _I, _I]),
+    "seld_k_conv1_train_gram": (_I, [_P] * 11 + [_I] * 3),
     "seld_k_bn_relu_ext": (_I, [_P, _P, _P, _P, _L]),
     "seld_k_conv3x3_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -21,6 +21,7 @@ struct ConvL {
     int64_t mm_off, mv_off;           // state offsets
     float *z = nullptr, *p = nullptr, *dp = nullptr;
     unsigned char* amax = nullptr;    // first block only: position of each pooling window's extreme [B,H/pt,W/pf,64]
+    float* zext = nullptr;            // first block only: the windows' extreme z (kept next to p for the z-free backward)
     float *mean, *invstd, *scale, *shift, *c1c2;   // into small buffer
 };
 
@@ -56,6 +57,10 @@ struct seld_ctx {
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
     unsigned short* wsplit = nullptr;      // [9][3][64][64] bf16 planes of the current conv64 weights (split-bf16 mode)
+    int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
+    bool gram_active = false;              // the last training forward took that path
+    float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
+    hipEvent_t ev_gram = nullptr;
     int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
@@ -240,12 +245,18 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         const size_t nz = (size_t)B * L.H * L.W * 64;
         const size_t np = (size_t)B * (L.H / L.pt) * (L.W / L.pf) * 64;
         ALLOC(L.z, nz); ALLOC(L.p, np); ALLOC(L.dp, np);
-        if (i == 0) { float* am = nullptr; ALLOC(am, (np + 3) / 4); L.amax = reinterpret_cast<unsigned char*>(am); }
+        if (i == 0) { float* am = nullptr; ALLOC(am, (np + 3) / 4); L.amax = reinterpret_cast<unsigned char*>(am); ALLOC(L.zext, np); }
         if (nz > zmax) zmax = nz;
         float* sm = c->small + (size_t)i * 64 * 6;
         L.mean = sm; L.invstd = sm + 64; L.scale = sm + 128; L.shift = sm + 192; L.c1c2 = sm + 256;
     }
     ALLOC(c->dzbuf, zmax);
+    {
+        const size_t kp = (size_t)conv_gram_dim(c->conv[0].Cin);
+        ALLOC(c->gram_slab, (size_t)conv_gram_slab_capacity() * kp * kp);
+        ALLOC(c->gram, kp * kp);
+        ALLOC(c->mmat, kp * 64);
+    }
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
     ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
@@ -263,9 +274,14 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     for (int i = 0; i < a->n_gru; ++i)
         for (int d = 0; d < 2; ++d) { ALLOC(c->dgx[i][d], rows * 384); ALLOC(c->dgh[i][d], rows * 384); }
     ALLOC(c->tn_slab_side, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    // lowest priority: the side stream only carries work nobody waits for soon (weight-gradient GEMMs, the patch Gram
+    // matrix); whenever the main stream has a kernel ready it should get the CUs
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
     }
@@ -286,6 +302,7 @@ void seld_destroy(seld_ctx* c) {
     for (auto& t : c->timers) for (auto e : t.ev) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_gram) hipEventDestroy(c->ev_gram);
     if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -302,6 +319,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!c || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 int seld_sync(seld_ctx* c) {
@@ -361,6 +379,11 @@ void* seld_param_ptr(seld_ctx* c) { return c ? c->params : nullptr; }
 void* seld_grad_ptr(seld_ctx* c) { return c ? c->grads : nullptr; }
 
 // ---------------------------------------------------------------------------------------------- forward
+// side stream: everything enqueued on it after this call starts once the main stream has reached this point
+static void fork_side(seld_ctx* c) {
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->side, c->ev_fork, 0);
+}
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
@@ -376,10 +399,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // (conv_pool.hip), BN+ReLU+MaxPool becomes an elementwise pass over 1/20 of the data, z is stored
         // only when the backward pass will read it
         const bool fused_pool = i == 0 && c->conv1_pool_fused && L.pt == 5 && L.pf == 4 && L.W == 64;
+        const bool gram = fused_pool && save && c->conv1_gram;      // backward without the pre-BN tensor: z is not stored
+        if (i == 0) c->gram_active = gram;
         if (fused_pool) {
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd_pool(st, in, c->params + L.w_off, c->params + L.b_off, c->params + L.g_off,
-                                           save ? L.z : nullptr, L.p, save ? L.amax : nullptr, stat, &npart, B, L.H, L.Cin))
+                                           (save && !gram) ? L.z : nullptr, gram ? L.zext : L.p, save ? L.amax : nullptr, stat,
+                                           &npart, B, L.H, L.Cin))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd_pool");
         } else if (i == 0) {
             PROF(c, tn);   // level 1
@@ -404,8 +430,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
             PROF2(c, tn);
-            if (fused_pool)
-                launch_bn_relu_ext(st, L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);   // in place over zext
+            if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
+                launch_bn_relu_ext(st, gram ? L.zext : L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);
             else if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
@@ -420,10 +446,22 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 launch_gemm(st, feat, G.in_feat, c->params + G.k_off[d], 384, c->params + G.b_off[d], G.gx[d], 384, rows, 384,
                             G.in_feat, 0, 0, 0);
         }
+        if (i == 0 && c->gram_active) fork_side(c);
         {
             PROF(c, "gru_fwd");
             launch_gru_fwd(st, G.gx[0], G.gx[1], c->params + G.u_off[0], c->params + G.u_off[1], c->params + G.b_off[0] + 384,
                            c->params + G.b_off[1] + 384, G.h[0], G.h[1], save ? G.sv[0] : nullptr, save ? G.sv[1] : nullptr, B, S);
+        }
+        if (i == 0 && c->gram_active) {
+            // Gram matrix of the input patches (conv_gram.hip): depends on x alone -> side stream, under the GRU
+            // recurrences (2B of the 256 CUs): eligible when the first GRU kernel is (fork event recorded in front of it) but
+            // enqueued after it, on a lower-priority stream, so that the recurrence gets its CUs first
+            int ns = 0;
+            const int kp = conv_gram_dim(c->conv[0].Cin);
+            if (launch_conv_first_gram(c->side, x, c->gram_slab, &ns, B, c->conv[0].H, c->conv[0].Cin, 1))
+                return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_gram");
+            launch_reduce_slabs(c->side, c->gram_slab, ns, (int64_t)kp * kp, c->gram, (int64_t)kp * kp, 0);
+            hipEventRecord(c->ev_gram, c->side);
         }
         launch_mul(st, G.h[0], G.h[1], G.out, (int64_t)rows * 128);
         feat = G.out;
@@ -505,11 +543,6 @@ static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A
     launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1);
     launch_reduce_slabs2(st, slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
 }
-// side stream: everything enqueued on it after this call starts once the main stream has reached this point
-static void fork_side(seld_ctx* c) {
-    hipEventRecord(c->ev_fork, c->stream);
-    hipStreamWaitEvent(c->side, c->ev_fork, 0);
-}
 
 static int backward_impl(seld_ctx* c, const float* x) {
     hipStream_t st = c->stream;
@@ -574,8 +607,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
         snprintf(tn, sizeof tn, "pool%d_bwd_reduce", i + 1);
         {
             PROF2(c, tn);
-            if (launch_bn_pool_bwd_reduce(st, L.z, L.p, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B, L.H, L.W, 64,
-                                          L.pt, L.pf))
+            const bool gz = i == 0 && c->gram_active;      // no z: the windows' extreme values stand in
+            if (launch_bn_pool_bwd_reduce(st, gz ? L.zext : L.z, L.p, dp, L.mean, L.invstd, L.scale, L.shift, c->bn_partial, &np, B,
+                                          L.H, L.W, 64, L.pt, L.pf, gz ? 1 : 0))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
         }
         launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
@@ -586,7 +620,17 @@ static int backward_impl(seld_ctx* c, const float* x) {
             PROF2(c, tn);
             launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
         }
-        if (i == 0) {
+        if (i == 0 && c->gram_active) {
+            PROF(c, "conv1_wgrad");
+            // dW = ka (G W + g b) + g kb + M  (conv_gram.hip): M from x, the pooled gradient and the recorded argmax
+            const int kp = conv_gram_dim(L.Cin);
+            if (launch_conv_first_msparse(st, x, L.p, dp, L.amax, L.scale, c->wgrad_slab, &ns, B, L.H, L.Cin))
+                return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_msparse");
+            launch_reduce_slabs(st, c->wgrad_slab, ns, (int64_t)kp * 64, c->mmat, (int64_t)kp * 64, 0);
+            hipStreamWaitEvent(st, c->ev_gram, 0);
+            launch_conv_first_assemble(st, c->gram, c->mmat, c->params + L.w_off, c->params + L.b_off, L.mean, c->grads + L.w_off,
+                                       c->grads + L.b_off, L.Cin);
+        } else if (i == 0) {
             {
                 PROF(c, "conv1_wgrad");
                 // fused: dz = BN/ReLU/pool backward formed inside the wgrad kernel (L.mean.. are contiguous: 6 x 64)

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
         float zsel[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) zsel[c] = (pv[c] - sh[c]) / sc[c];
-        if (degenerate) {
+        if (PT < 0) {        // z holds the pooled EXTREME of z per window (zext of conv_pool.hip): the routed element itself
+            const float4 ze = reinterpret_cast<const float4*>(z)[pp * 16 + g];
+            zsel[0] = ze.x; zsel[1] = ze.y; zsel[2] = ze.z; zsel[3] = ze.w;
+        } else if (degenerate) {
             const int fp = (int)(pp % Wp);
             const int tp = (int)((pp / Wp) % Hp);
             const int b = (int)(pp / ((int64_t)Wp * Hp));
@@ -199,13 +202,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
 
 int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, const float* dp, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* partial,
-                              int* npartial, int B, int H, int W, int C, int pt, int pf) {
+                              int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme) {
     if (C != 64 || H % pt || W % pf) return -2;
     const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
     int64_t blocks = (npool + 15) / 16;
     if (blocks > BN_MAX_PARTIAL) blocks = BN_MAX_PARTIAL;
+    // z_is_pooled_extreme: `z` is zext [B,H/pt,W/pf,C] (no full-resolution z exists); signalled to the kernel as PT < 0
     hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, p, dp, mean, invstd, scale,
-                       shift, partial, npool, H, W, pt, pf);
+                       shift, partial, npool, H, W, z_is_pooled_extreme ? -pt : pt, pf);
     *npartial = (int)blocks;
     return 0;
 }

@@ -48,6 +48,14 @@ int launch_conv_first_wgrad(hipStream_t st, const float* x, const float* dz, flo
 int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z, const float* p, const float* dp,
                                   const unsigned char* amax, const float* coef, float* slab, int* n_slab, int B, int H,
                                   int Cin, int pt, int pf);
+int conv_gram_dim(int Cin);
+int conv_gram_slab_capacity();
+int conv_msparse_slab_capacity();
+int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background = 0);
+int launch_conv_first_msparse(hipStream_t st, const float* x, const float* p, const float* dp, const unsigned char* amax,
+                              const float* scale, float* slab, int* n_slab, int B, int H, int Cin);
+int launch_conv_first_assemble(hipStream_t st, const float* G, const float* M, const float* W, const float* bias, const float* coef,
+                               float* dW, float* db, int Cin);
 int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,
                         int B, int H, int W);
 int conv_wgrad_slab_capacity();
@@ -70,7 +78,7 @@ int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, 
                             int B, int H, int W, int C, int pt, int pf);
 int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, const float* dp, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* partial,
-                              int* npartial, int B, int H, int W, int C, int pt, int pf);
+                              int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme = 0);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C);
 int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,

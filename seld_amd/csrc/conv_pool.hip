@@ -32,7 +32,7 @@ struct PoolGeom {
     static constexpr size_t SMEM = (size_t)(KPAD * 64 + 2 * PATCH + 512) * sizeof(float);
 };
 
-template <int CIN, bool WRITE_Z>
+template <int CIN, bool WRITE_Z, bool WRITE_AMAX>
 __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma, float* __restrict__ z,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         const float w4 = __uint_as_float(__float_as_uint(v4) ^ smask[c_]);                              \
         const float hi5 = fmaxf(fmaxf(fmaxf(w0, w1), fmaxf(w2, w3)), w4);                               \
         const bool take_ = ((r_) & 3) == 0 || hi5 > best;     /* strict: the first extreme in scan order wins ties */ \
-        if (WRITE_Z) {       /* training: remember WHERE the extreme is: position row * 4 + column of the window */ \
+        if (WRITE_AMAX) {    /* training: remember WHERE the extreme is: position row * 4 + column of the window */ \
             int row_ = 4;                                                                               \
             row_ = (w3 == hi5) ? 3 : row_; row_ = (w2 == hi5) ? 2 : row_;                               \
             row_ = (w1 == hi5) ? 1 : row_; row_ = (w0 == hi5) ? 0 : row_;                               \
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         best = take_ ? hi5 : best;                                                                      \
         if (((r_) & 3) == 3) {                                                                          \
             (zext + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = __uint_as_float(__float_as_uint(best) ^ smask[c_]); \
-            if (WRITE_Z) (amax + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = (unsigned char)bpos; \
+            if (WRITE_AMAX) (amax + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = (unsigned char)bpos; \
         }                                                                                               \
     }
     static_assert(NS >= 32, "the drain of half a tile is spread over 32 k-steps");
@@ -272,13 +272,17 @@ static int launch_cpool(hipStream_t st, const float* x, const float* w, const fl
     using G = PoolGeom<CIN>;
     const int ntiles = B * ((H + 9) / 10);
     const int grid = ntiles < CPOOL_MAX_PERSISTENT ? ntiles : CPOOL_MAX_PERSISTENT;
-    if (z) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_kernel<CIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, true>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, amax, stat_partial, B, H);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_kernel<CIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, false>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, gamma, z, zext, amax, stat_partial, B, H);
+#define CPOOL_GO(Z_, A_)                                                                                              \
+    {                                                                                                                 \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_kernel<CIN, Z_, A_>),                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);                                \
+        hipLaunchKernelGGL((conv_first_fwd_pool_kernel<CIN, Z_, A_>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
+                           gamma, z, zext, amax, stat_partial, B, H);                                                 \
     }
+    if (z && amax) CPOOL_GO(true, true)
+    else if (amax) CPOOL_GO(false, true)        // training without z: the Gram-matrix backward (conv_gram.hip)
+    else CPOOL_GO(false, false)                 // inference
+#undef CPOOL_GO
     if (n_partial) *n_partial = grid;
     return 0;
 }
@@ -290,7 +294,7 @@ static int launch_cpool(hipStream_t st, const float* x, const float* w, const fl
 int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
                                float* z, float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H,
                                int Cin) {
-    if (H % 5 || H <= 0 || B <= 0 || (z != nullptr) != (amax != nullptr)) return -2;   // z and amax are stored together
+    if (H % 5 || H <= 0 || B <= 0 || (z != nullptr && amax == nullptr)) return -2;   // z is stored for a backward pass, which needs amax
     if (Cin == 7) return launch_cpool<7>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
     if (Cin == 10) return launch_cpool<10>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
     return -2;

@@ -56,7 +56,7 @@ int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float*
 
 int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias, const float* gamma, float* z, float* zext,
                                unsigned char* amax, float* stats, int B, int H, int Cin) {
-    if (!x || !w || !gamma || !zext || (z != nullptr) != (amax != nullptr)) return SELD_ERR_INVALID;
+    if (!x || !w || !gamma || !zext || (z != nullptr && amax == nullptr)) return SELD_ERR_INVALID;
     Scratch s;
     float* part = stats ? s.get((size_t)conv_pool_stat_capacity() * 128) : nullptr;
     if (stats && !part) return SELD_ERR_NOMEM;
@@ -135,6 +135,58 @@ int seld_k_conv1_bwd_fused(const float* x, const float* z, const float* dp, cons
     launch_reduce_slabs(0, slab, ns, conv_first_wgrad_slab_stride(Cin), tmp, (int64_t)(9 * Cin + 1) * 64, 0);
     hipMemcpyAsync(dw, tmp, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
     hipMemcpyAsync(db, tmp + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
+    return done();
+}
+
+int seld_k_conv1_gram(const float* x, float* G, int B, int H, int Cin) {
+    if (!x || !G) return SELD_ERR_INVALID;
+    if (Cin != 7 && Cin != 10) return SELD_ERR_UNSUPPORTED;
+    const size_t kp = (size_t)conv_gram_dim(Cin);
+    Scratch s;
+    float* slab = s.get((size_t)conv_gram_slab_capacity() * kp * kp);
+    if (!slab) return SELD_ERR_NOMEM;
+    int ns = 0;
+    if (launch_conv_first_gram(0, x, slab, &ns, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    launch_reduce_slabs(0, slab, ns, (int64_t)(kp * kp), G, (int64_t)(kp * kp), 0);
+    return done();
+}
+
+int seld_k_conv1_train_gram(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                            const float* dp, float* p, float* dw, float* db, float* dgamma, float* dbeta, int B, int H, int Cin) {
+    if (!x || !w || !bias || !gamma || !beta || !dp || !p || !dw || !db || !dgamma || !dbeta) return SELD_ERR_INVALID;
+    if ((Cin != 7 && Cin != 10) || H % 5) return SELD_ERR_UNSUPPORTED;
+    const int W = 64, C = 64;
+    const size_t np = (size_t)B * (H / 5) * 16 * 64, kp = (size_t)conv_gram_dim(Cin);
+    Scratch s;
+    float* coef = s.get(64 * 6);          // mean | invstd | scale | shift | c1 | c2
+    float* mov = s.get(128);
+    float* part = s.get((size_t)conv_pool_stat_capacity() * 128);
+    float* bpart = s.get((size_t)bn_partial_capacity() * 128);
+    float* zext = s.get(np);
+    unsigned char* amax = reinterpret_cast<unsigned char*>(s.get((np + 3) / 4));
+    float* gslab = s.get((size_t)conv_gram_slab_capacity() * kp * kp);
+    float* gm = s.get(kp * kp);
+    float* mslab = s.get((size_t)conv_msparse_slab_capacity() * kp * 64);
+    float* mm = s.get(kp * 64);
+    float* out = s.get((size_t)(9 * Cin + 1) * 64);
+    if (!coef || !mov || !part || !bpart || !zext || !amax || !gslab || !gm || !mslab || !mm || !out) return SELD_ERR_NOMEM;
+    hipMemsetAsync(mov, 0, 128 * sizeof(float), 0);
+    int npart = 0, nb = 0, ns = 0;
+    // forward without z: window extremes + positions + statistics; then BN coefficients and the pooled activation
+    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, nullptr, zext, amax, part, &npart, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    launch_bn_finalize(0, part, npart, (double)B * H * W, gamma, beta, mov, mov + 64, coef, coef + 64, coef + 128, coef + 192, C, 1);
+    launch_bn_relu_ext(0, zext, coef + 128, coef + 192, p, (int64_t)np);
+    // backward: BN sums from the pooled tensors, then dW = ka (G W + g b) + g kb + M
+    if (launch_bn_pool_bwd_reduce(0, zext, p, dp, coef, coef + 64, coef + 128, coef + 192, bpart, &nb, B, H, W, C, 5, 4, 1))
+        return SELD_ERR_UNSUPPORTED;
+    launch_bn_bwd_finalize(0, bpart, nb, (double)B * H * W, dgamma, dbeta, coef + 256, C);
+    if (launch_conv_first_gram(0, x, gslab, &ns, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    launch_reduce_slabs(0, gslab, ns, (int64_t)(kp * kp), gm, (int64_t)(kp * kp), 0);
+    if (launch_conv_first_msparse(0, x, p, dp, amax, coef + 128, mslab, &ns, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    launch_reduce_slabs(0, mslab, ns, (int64_t)(kp * 64), mm, (int64_t)(kp * 64), 0);
+    launch_conv_first_assemble(0, gm, mm, w, bias, coef, out, out + 9 * Cin * 64, Cin);
+    hipMemcpyAsync(dw, out, (size_t)9 * Cin * 64 * 4, hipMemcpyDeviceToDevice, 0);
+    hipMemcpyAsync(db, out + 9 * Cin * 64, 64 * 4, hipMemcpyDeviceToDevice, 0);
     return done();
 }
 

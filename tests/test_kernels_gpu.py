@@ -103,9 +103,13 @@ def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
     # amax: position row*4+col of that extreme in its window (random data: no ties)
     flat = np.where(gamma < 0, -win, win).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 5, 16, 64, 20)
     np.testing.assert_array_equal(am.cpu().numpy(), flat.argmax(-1).astype(np.uint8))
-    # z not stored (inference): same zext; z and amax go together
+    # z not stored: inference (no amax either) and the z-free training path (amax only); z without amax is refused
     ze2 = torch.full_like(ze, float("nan"))
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am), None, B, H, Cin) != 0
+    am2 = torch.full_like(am, 255)
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(z), ptr(ze2), None, None, B, H, Cin) != 0
+    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am2), None, B, H, Cin) == 0
+    assert torch.equal(ze, ze2) and torch.equal(am, am2)
+    ze2.fill_(float("nan"))
     assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, None, B, H, Cin) == 0
     assert torch.equal(ze, ze2)
     # pooled activation: elementwise over zext == BN+ReLU+MaxPool over z, bit for bit
@@ -375,3 +379,66 @@ def test_conv1_bwd_single_routing_on_ties(seld_lib):
             ref[kh, kw] = np.einsum("bhwc,bhwo->co", xp[:, kh:kh + H, kw:kw + 64, :], dz)
     check("single routing dw", dw.cpu().numpy(), ref)
     check("single routing dbeta", dbe.cpu().numpy(), dp.sum(axis=(0, 1, 2)))
+
+
+def _patches(x):
+    """im2col of a 3x3 'same' conv: [B*H*W, 9*Cin + 1] in fp64, k = (kh, kw, ci), last column = 1 (bias)."""
+    B, H, W, Cin = x.shape
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    cols = [xp[:, kh:kh + H, kw:kw + W, :] for kh in range(3) for kw in range(3)]
+    P = np.concatenate(cols + [np.ones((B, H, W, 1))], axis=-1)
+    return P.reshape(-1, 9 * Cin + 1)
+
+
+@pytest.mark.parametrize("B,H,Cin", [(2, 50, 7), (1, 7, 7), (2, 10, 10), (3, 700, 7)])
+def test_conv1_gram_matrix(seld_lib, B, H, Cin):
+    """conv_gram.hip: G = P^T P of the zero-padded input patches (+ ones column), upper 32x32 tiles."""
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((B, H, 64, Cin)) + 0.3).astype(np.float32)
+    KP = 64 if Cin == 7 else 128
+    G = torch.full((KP, KP), float("nan"), device="cuda")
+    xd = dev(x)
+    assert seld_lib.seld_k_conv1_gram(ptr(xd), ptr(G), B, H, Cin) == 0
+    P = _patches(x)
+    ref = P.T @ P
+    K1 = 9 * Cin + 1
+    got = G.cpu().numpy()
+    for r0 in range(0, KP, 32):
+        for c0 in range(r0, KP, 32):                       # upper tiles only
+            r1, c1 = min(r0 + 32, K1), min(c0 + 32, K1)
+            if r0 < K1 and c0 < K1:
+                check(f"gram tile {r0},{c0}", got[r0:r1, c0:c1], ref[r0:r1, c0:c1], tol=2e-6)
+    assert got[K1 - 1, K1 - 1] == B * H * 64
+
+
+@pytest.mark.parametrize("B,H,CIN", [(2, 50, 7), (1, 20, 7), (2, 15, 7), (2, 25, 10), (4, 600, 7)])
+def test_conv1_train_without_pre_bn_tensor(seld_lib, B, H, CIN):
+    """The first block trained from x alone (no z in memory): forward p and the four gradients against fp64 autograd
+    through conv -> BN(batch statistics) -> ReLU -> MaxPool(5,4)."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((B, H, 64, CIN)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, CIN, 64)) / np.sqrt(9 * CIN)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32) * 0.1
+    gamma = (rng.uniform(0.5, 1.5, 64) * np.where(rng.random(64) < 0.2, -1, 1)).astype(np.float32)
+    beta = rng.normal(0, 0.3, 64).astype(np.float32)
+    tw = torch.as_tensor(w, dtype=torch.float64).requires_grad_(True)
+    tb = torch.as_tensor(b, dtype=torch.float64).requires_grad_(True)
+    tg = torch.as_tensor(gamma, dtype=torch.float64).requires_grad_(True)
+    tbe = torch.as_tensor(beta, dtype=torch.float64).requires_grad_(True)
+    zt = F.conv2d(torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), tw.permute(3, 2, 0, 1), tb, padding=1).permute(0, 2, 3, 1)
+    mean = zt.mean(dim=(0, 1, 2))
+    var = ((zt - mean) ** 2).mean(dim=(0, 1, 2))
+    y = (zt - mean) * torch.rsqrt(var + 1e-3) * tg + tbe
+    p = F.max_pool2d(torch.relu(y).permute(0, 3, 1, 2), (5, 4), (5, 4)).permute(0, 2, 3, 1)
+    dp = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+    gw, gb, gg, gbe = torch.autograd.grad(p, (tw, tb, tg, tbe), torch.as_tensor(dp, dtype=torch.float64))
+    nan = lambda *s_: torch.full(s_, float("nan"), device="cuda")
+    xd, wd, bd, gd, bed, dpd = dev(x), dev(w), dev(b), dev(gamma), dev(beta), dev(dp)
+    pd, dw, db, dg, dbe = nan(*p.shape), nan(3, 3, CIN, 64), nan(64), nan(64), nan(64)
+    assert seld_lib.seld_k_conv1_train_gram(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(bed), ptr(dpd), ptr(pd), ptr(dw), ptr(db),
+                                            ptr(dg), ptr(dbe), B, H, CIN) == 0
+    check(f"z-free p {B,H}", pd.cpu().numpy(), p.detach().numpy(), tol=2e-6)
+    check(f"z-free dw {B,H}", dw.cpu().numpy(), gw.numpy())
+    check(f"z-free dgamma {B,H}", dg.cpu().numpy(), gg.numpy())
+    check(f"z-free dbeta {B,H}", dbe.cpu().numpy(), gbe.numpy())
+    assert np.abs(db.cpu().numpy()).max() <= 1e-3 * np.abs(gw.numpy()).max()   # exact-arithmetic zero (bias before BN)
