@@ -52,9 +52,14 @@ def test_forward_inference(seldnet_config, B, T):
     check("model(x) sed", sed.cpu().numpy(), ref["sed"])
 
 
-@pytest.mark.parametrize("B,T,doa_loss", [(2, 50, "MSE"), (2, 50, "MMSE"), (3, 100, "MSE")])
-def test_train_step(seldnet_config, B, T, doa_loss):
+@pytest.mark.parametrize("B,T,doa_loss,opts", [(2, 50, "MSE", {}), (2, 50, "MMSE", {}), (3, 100, "MSE", {}),
+                                               (3, 100, "MSE", {"conv1_gram": 0}),                        # first block through the stored pre-BN tensor
+                                               (2, 50, "MSE", {"conv1_gram": 0, "conv1_pool_fused": 0}),   # ... and the unfused pooling
+                                               (2, 50, "MSE", {"conv64_split_bf16": 0})])                  # fp32-MFMA 64->64 convs
+def test_train_step(seldnet_config, B, T, doa_loss, opts):
     O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
+    for k, v in opts.items():
+        model.set_option(k, v)
     from seld_amd import losses, train
     ref = O.train_step(spec, w, st, x, ys, yd, doa_loss=doa_loss, loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
     opt = train.Adam(1e-3)

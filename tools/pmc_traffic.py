@@ -8,7 +8,8 @@ import sys
 from collections import defaultdict
 
 GROUPS = {  # bench.py timer group -> kernel-name substring
-    "conv1_fwd": "conv_first_fwd_pool_kernel", "conv1_wgrad": "conv_first_wgrad_fused_kernel",
+    "conv1_fwd": "conv_first_fwd_pool_kernel", "conv1_wgrad": "conv_first_msparse_kernel", "conv1_gram": "conv_first_gram_kernel",
+    "conv1_wgrad_fused": "conv_first_wgrad_fused_kernel",
     "gru_fwd": "gru_fwd_kernel", "gru_bwd": "gru_bwd_kernel",
     "conv64_fwd_dgrad_W16": "conv64_fwd_sbr_kernel<4", "conv64_fwd_dgrad_W4": "conv64_fwd_sbr_kernel<2",
     "conv2_wgrad": "conv64_wgrad_kernel<4>", "conv3_wgrad": "conv64_wgrad_kernel<2>",
