@@ -143,11 +143,12 @@ __global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __
 // `background`: the launch shares the GPU with a latency-critical kernel on another stream (the GRU recurrence: one
 // 512-thread block with 50 KB of LDS on 2B of the CUs).  Co-resident Gram blocks cost that kernel ~30 % (measured), so
 // a background launch asks for 112 KB of LDS per block — it cannot land on a CU that runs a recurrence block — and for
-// at most 192 blocks; it has the whole backward pass (~2 ms) to finish.
+// at most 128 blocks (swept 64..192: 128 disturbs the input-projection GEMMs and the second GRU layer least while still
+// finishing well before the first block's backward needs G, ~2 ms later).
 int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background) {
     if ((Cin != 7 && Cin != 10) || B <= 0 || H <= 0) return -2;
     const int ntiles = B * ((H + 3) / 4);
-    const int cap = background ? 192 : GRAM_MAX_BLOCKS;
+    const int cap = background ? 128 : GRAM_MAX_BLOCKS;
     const int grid = ntiles < cap ? ntiles : cap;
     const size_t lds_floor = background ? (size_t)112 * 1024 : 0;
     if (Cin == 7) {
