@@ -167,8 +167,41 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
 #ifdef CPOOL_TIMING
         const long long c1 = clock64();
 #endif
-        // ---- phase A: channels 0..31 of the wave's 5 row tiles
         f32x16 accA0 = zero16(), accA1 = zero16(), accA2 = zero16(), accA3 = zero16(), accA4 = zero16();
+        f32x16 accB0 = zero16(), accB1 = zero16(), accB2 = zero16(), accB3 = zero16(), accB4 = zero16();
+        if constexpr (!WRITE_Z) {
+            // No z to store (inference, or training through the patch Gram matrix): nothing to spread, so ONE pass over k
+            // with all 10 accumulator chains — 7 LDS reads per 10 MFMAs instead of 12 — and the window reduction after it.
+            float a0, a1, a2, a3, a4, b0, b1;
+            CP_LD(0, 0, a0, a1, a2, a3, a4, b0)
+            b1 = wlh[32];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f, n4 = 0.f, m0 = 0.f, m1 = 0.f;
+                if (s + 1 < NS) {
+                    CP_LD(s + 1, 0, n0, n1, n2, n3, n4, m0)
+                    m1 = wlh[128 * (s + 1) + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                accA0 = MFMA_F32_32x32x2(a0, b0, accA0);
+                accB0 = MFMA_F32_32x32x2(a0, b1, accB0);
+                accA1 = MFMA_F32_32x32x2(a1, b0, accA1);
+                accB1 = MFMA_F32_32x32x2(a1, b1, accB1);
+                accA2 = MFMA_F32_32x32x2(a2, b0, accA2);
+                accB2 = MFMA_F32_32x32x2(a2, b1, accB2);
+                accA3 = MFMA_F32_32x32x2(a3, b0, accA3);
+                accB3 = MFMA_F32_32x32x2(a3, b1, accB3);
+                accA4 = MFMA_F32_32x32x2(a4, b0, accA4);
+                accB4 = MFMA_F32_32x32x2(a4, b1, accB4);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3; a4 = n4; b0 = m0; b1 = m1;
+            }
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) CP_DRAIN(r, 0, accA0, accA1, accA2, accA3, accA4)
+            }
+        } else {
+        // ---- phase A: channels 0..31 of the wave's 5 row tiles
         {
             float a0, a1, a2, a3, a4, b0;
             CP_LD(0, 0, a0, a1, a2, a3, a4, b0)
@@ -193,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
         // register (5 stores) every second k-step.  A wave can have 64 vector-memory operations in flight
         // (vmcnt); the 160 stores of a whole tile issued in one burst stalled on HBM write acknowledgements
         // for ~19k cycles per tile (measured with -DCPOOL_TIMING), longer than the other block's k-loop.
-        f32x16 accB0 = zero16(), accB1 = zero16(), accB2 = zero16(), accB3 = zero16(), accB4 = zero16();
         {
             float a0, a1, a2, a3, a4, b0;
             CP_LD(0, 1, a0, a1, a2, a3, a4, b0)
@@ -211,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_pool_kernel(const float
                 __builtin_amdgcn_sched_barrier(0);
                 a0 = n0; a1 = n1; a2 = n2; a3 = n3; a4 = n4; b0 = m0;
             }
+        }
         }
 #ifdef CPOOL_TIMING
         const long long c3 = clock64();
