@@ -442,9 +442,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         GruL& G = c->gru[i];
         {
             PROF2(c, "gru_inproj_gemm");
-            for (int d = 0; d < 2; ++d)
-                launch_gemm(st, feat, G.in_feat, c->params + G.k_off[d], 384, c->params + G.b_off[d], G.gx[d], 384, rows, 384,
-                            G.in_feat, 0, 0, 0);
+            // both directions' projections of the same input in one launch
+            launch_gemm_dual_n(st, feat, G.in_feat, c->params + G.k_off[0], c->params + G.k_off[1], 384, c->params + G.b_off[0],
+                               c->params + G.b_off[1], G.gx[0], G.gx[1], 384, rows, 384, G.in_feat, 0, 0);
         }
         if (i == 0 && c->gram_active) fork_side(c);
         {
@@ -468,6 +468,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     }
     {
         PROF2(c, "heads_fwd");
+        // the first layers of the two heads read the same features: one launch when their shapes agree (seldnet.json:
+        // Conv1D(128) in both) and neither is the head's output layer
+        DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+        const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out;
+        if (merged0)
+            launch_gemm_dual_n(st, feat, S0.in, c->params + S0.w_off, c->params + D0.w_off, S0.out, c->params + S0.b_off,
+                               c->params + D0.b_off, S0.y, D0.y, S0.out, rows, S0.out, S0.in, 0, 0);
         for (int hd = 0; hd < 2; ++hd) {
             const float* a = feat;
             Head& Hd = c->heads[hd];
@@ -475,8 +482,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 DenseL& D = Hd.layers[j];
                 const bool lastl = (j + 1 == Hd.layers.size());
                 float* y = D.y;
-                launch_gemm(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, D.out, rows, D.out, D.in, 0,
-                            lastl ? Hd.act : 0, 0);
+                if (!(merged0 && j == 0))
+                    launch_gemm(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, D.out, rows, D.out, D.in, 0,
+                                lastl ? Hd.act : 0, 0);
                 a = y;
             }
             float* outp = hd == 0 ? sed : doa;
@@ -553,15 +561,22 @@ static int backward_impl(seld_ctx* c, const float* x) {
     {
         PROF2(c, "heads_bwd");
         float* dfeat = c->feat_grad;
+        // the gradient w.r.t. the shared features is the sum over the two heads' first layers: one product over the
+        // concatenated K axis when their shapes agree (out % 32 == 0), otherwise two launches with accumulation
+        DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+        const bool merged0 = S0.in == D0.in && S0.out == D0.out && (S0.out & 31) == 0;
         for (int hd = 0; hd < 2; ++hd) {
             Head& Hd = c->heads[hd];
-            for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
+            for (int j = (int)Hd.layers.size() - 1; j >= (merged0 ? 1 : 0); --j) {
                 DenseL& D = Hd.layers[j];
                 float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
                 const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
                 launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
             }
         }
+        if (merged0)
+            launch_gemm_dual_k(st, S0.dy, D0.dy, S0.out, c->params + S0.w_off, c->params + D0.w_off, S0.out, nullptr, dfeat, S0.in, rows,
+                               S0.in, S0.out, 1, 0, 0);
         fork_side(c);
         for (int hd = 0; hd < 2; ++hd) {
             Head& Hd = c->heads[hd];
@@ -593,8 +608,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
         }
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
-            for (int d = 0; d < 2; ++d)
-                launch_gemm(st, c->dgx[i][d], 384, c->params + G.k_off[d], 384, nullptr, G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, d);
+            // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
+            launch_gemm_dual_k(st, c->dgx[i][0], c->dgx[i][1], 384, c->params + G.k_off[0], c->params + G.k_off[1], 384, nullptr, G.din,
+                               G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
         }
         dout = G.din;
     }

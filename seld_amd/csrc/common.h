@@ -88,6 +88,10 @@ int bn_partial_capacity();
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
                 int ldc, int M, int N, int K, int transb, int act, int accumulate);
+int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0, const float* B1, int ldb, const float* bias0,
+                       const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int transb, int act);
+int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda, const float* B0, const float* B1, int ldb,
+                       const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate);
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,

@@ -16,14 +16,21 @@ template <int TRANSB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ Bm, int ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
-                                                       int ldc, int M, int N, int K, int act, int accumulate) {
+                                                       int ldc, int M, int N, int K, int act, int accumulate,
+                                                       const float* __restrict__ A1, const float* __restrict__ B1,
+                                                       const float* __restrict__ bias1, float* __restrict__ C1, int mode) {
+    // mode 0: C = act(A B + bias) (+C).   mode 1 (two products sharing A): column tiles >= ceil(N/64) compute
+    // C1 = act(A B1 + bias1).   mode 2 (one product over a concatenated K): C = act(A B + A1 B1 + bias) (+C), K % 32 == 0.
+    const int ntx = (N + 63) >> 6;
+    const bool second = mode == 1 && (int)blockIdx.x >= ntx;
+    if (second) { Bm = B1; bias = bias1; C = C1; }
     constexpr int LDB = TRANSB ? 65 : 64;
     __shared__ __attribute__((aligned(16))) float As[32 * GT_LDA];
     __shared__ __attribute__((aligned(16))) float Bs[32 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64, n0 = (second ? (int)blockIdx.x - ntx : (int)blockIdx.x) * 64;
     const bool a_vec = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && (TRANSB ? ((K & 3) == 0) : ((N & 3) == 0)) &&
                        ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const int gm = m0 + row, gk = (k0_) + k4;                                                    \
             va[u][0] = va[u][1] = va[u][2] = va[u][3] = 0.f;                                             \
             if (gm < M) {                                                                                \
-                const float* p = A + (size_t)gm * lda + gk;                                              \
+                const float* p = Ap + (size_t)gm * lda + gk;                                              \
                 if (a_vec && gk + 3 < K) {                                                               \
                     const float4 t = *reinterpret_cast<const float4*>(p);                                \
                     va[u][0] = t.x; va[u][1] = t.y; va[u][2] = t.z; va[u][3] = t.w;                      \
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const int kk = idx >> 4, n4 = (idx & 15) * 4;                                                \
             const int gk = (k0_) + kk, gn = n0 + n4;                                                     \
             if (gk < K) {                                                                                \
-                const float* p = Bm + (size_t)gk * ldb + gn;                                             \
+                const float* p = Bp + (size_t)gk * ldb + gn;                                             \
                 if (b_vec && gn + 3 < N) {                                                               \
                     const float4 t = *reinterpret_cast<const float4*>(p);                                \
                     vb[u][0] = t.x; vb[u][1] = t.y; vb[u][2] = t.z; vb[u][3] = t.w;                      \
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const int n = idx >> 3, k4 = (idx & 7) * 4;                                                  \
             const int gn = n0 + n, gk = (k0_) + k4;                                                      \
             if (gn < N) {                                                                                \
-                const float* p = Bm + (size_t)gn * ldb + gk;                                             \
+                const float* p = Bp + (size_t)gn * ldb + gk;                                             \
                 if (b_vec && gk + 3 < K) {                                                               \
                     const float4 t = *reinterpret_cast<const float4*>(p);                                \
                     vb[u][0] = t.x; vb[u][1] = t.y; vb[u][2] = t.z; vb[u][3] = t.w;                      \
@@ -89,11 +96,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             _Pragma("unroll") for (int j = 0; j < 4; ++j) Bs[(k4 + j) * LDB + n] = vb[u][j];             \
         }                                                                                                \
     }
-    GEMM_LOAD(0)
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    // chunk g of the (possibly concatenated) K axis: operand pair g / nck, k offset (g % nck) * 32
+    const int nck = (K + 31) >> 5, ng = mode == 2 ? 2 * nck : nck;
+#define GEMM_LOADG(g_)                                                                                   \
+    {                                                                                                    \
+        const int h_ = (g_) >= nck ? 1 : 0;                                                              \
+        const float* Ap = h_ ? A1 : A;                                                                   \
+        const float* Bp = h_ ? B1 : Bm;                                                                  \
+        GEMM_LOAD(((g_) - h_ * nck) * 32)                                                                \
+    }
+    GEMM_LOADG(0)
+    for (int g = 0; g < ng; ++g) {
         GEMM_COMMIT()
         lds_barrier();
-        if (k0 + 32 < K) GEMM_LOAD(k0 + 32)
+        if (g + 1 < ng) GEMM_LOADG(g + 1)
         {
             // 4-deep LDS operand ring pinned with sched_barrier (see conv.hip)
             float ra[4], rb[4];
@@ -117,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         lds_barrier();
     }
+#undef GEMM_LOADG
 #undef GEMM_LOAD
 #undef GEMM_COMMIT
     const int col = n0 + wc * 32 + li;
@@ -137,15 +154,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+static int gemm_go(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, int ldc, int M,
+                   int N, int K, int transb, int act, int accumulate, const float* A1, const float* B1, const float* bias1, float* C1,
+                   int mode) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    if (mode == 2 && (K & 31)) return -2;
+    dim3 grid((N + 63) / 64 * (mode == 1 ? 2 : 1), (M + 63) / 64);
+    if (transb)
+        hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
+                           bias1, C1, mode);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
+                           bias1, C1, mode);
+    return 0;
+}
+
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
                 int ldc, int M, int N, int K, int transb, int act, int accumulate) {
-    if (M <= 0 || N <= 0 || K <= 0) return -1;
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    if (transb)
-        hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate);
-    else
-        hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate);
-    return 0;
+    return gemm_go(st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, transb, act, accumulate, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+// two products that share A in one launch: C0 = act(A B0 + bias0), C1 = act(A B1 + bias1) (same shapes and leading dimensions)
+int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0, const float* B1, int ldb, const float* bias0,
+                       const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int transb, int act) {
+    return gemm_go(st, A, lda, B0, ldb, bias0, C0, ldc, M, N, K, transb, act, 0, nullptr, B1, bias1, C1, 1);
+}
+
+// one product over a concatenated K axis: C = act(A0 B0 + A1 B1 + bias) (+C); K % 32 == 0
+int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda, const float* B0, const float* B1, int ldb,
+                       const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate) {
+    return gemm_go(st, A0, lda, B0, ldb, bias, C, ldc, M, N, K, transb, act, accumulate, A1, B1, nullptr, nullptr, 2);
 }
 
 // ------------------------------------------------------------------------------------------------
