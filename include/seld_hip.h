@@ -75,7 +75,10 @@ int seld_set_batch(seld_ctx* ctx, int B);
 int seld_sync(seld_ctx* ctx);
 /* compute options.  "conv64_split_bf16" (default 1): conv2/conv3 forward and input gradient run on the bf16 matrix
  * cores with every fp32 operand split exactly into three bf16 values and six partial products (fp32-level accuracy);
- * 0 selects the f32-input MFMA kernels. */
+ * 0 selects the f32-input MFMA kernels.  "gemm_split_bf16" (default 1): the same scheme for the GRU input projections,
+ * the heads' first Conv1D and their input gradients (gemm_sb.hip) where K % 32 == 0 and N % 128 == 0; 0 keeps them on
+ * the f32-input MFMA GEMM.  "conv1_pool_fused" / "conv1_gram" (default 1): first block's pooling inside the conv
+ * epilogue / its kernel gradient from the patch Gram matrix. */
 int seld_set_option(seld_ctx* ctx, const char* key, int value);
 
 /* ---- variables: replaces model.trainable_variables / get_weights / set_weights
@@ -231,6 +234,21 @@ int seld_k_bn_relu_pool_bwd(const float* z, const float* dp, const float* mean, 
 /* C[M,N] = act(A[M,K] * op(B) + bias); transb=0: B [K,N]; 1: B [N,K]; act 0 none,1 sigmoid,2 tanh */
 int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int K,
                 int transb, int act, int accumulate);
+/* two products sharing A in one launch: C0 = act(A*op(B0)+bias0), C1 = act(A*op(B1)+bias1) (the forward/backward GRU
+ * input projections of modules.py:311-316, the first Conv1D of the two heads of modules.py:326-346) */
+int seld_k_gemm_pair_n(const float* A, const float* B0, const float* B1, const float* bias0, const float* bias1,
+                       float* C0, float* C1, int M, int N, int K, int transb, int act);
+/* one product over a concatenated K axis: C = act(A0*op(B0) + A1*op(B1) + bias) (the gradient w.r.t. an input that
+ * feeds two layers); K % 32 == 0 is required and anything else is refused */
+int seld_k_gemm_pair_k(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias,
+                       float* C, int M, int N, int K, int transb, int act, int accumulate);
+/* the same products on the split-bf16 path (three exact bf16 terms per operand, 6 bf16 MFMAs per product, fp32
+ * accumulation: fp32-level accuracy at 2.7x the fp32 MFMA rate): mode 0 C0 = act(A0 op(B0) + bias0); mode 1 also
+ * C1 = act(A0 op(B1) + bias1); mode 2 C0 = act(A0 op(B0) + A1 op(B1) + bias0).  K % 32 == 0 and N % 128 == 0 are
+ * required (anything else is refused: the caller uses seld_k_gemm).  This is what the train / predict entry points
+ * run for the GRU input projections and the heads' first Conv1D. */
+int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                   const float* bias1, float* C0, float* C1, int M, int N, int K, int transb, int act, int mode);
 /* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels); colsum (may be NULL): [N] = sum_m B[m,:]
  * (the matching bias gradient, produced by the same launch) */
 int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N);

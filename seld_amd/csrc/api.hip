@@ -62,6 +62,10 @@ struct seld_ctx {
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
     hipEvent_t ev_gram = nullptr;
     int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
+    int gemm_split_bf16 = 1;               // 1: GRU input projections / heads' first Conv1D (and their input gradients) on the
+                                           //    split-bf16 GEMM (gemm_sb.hip) where the shapes allow; 0: exact-fp32 MFMA GEMM
+    unsigned short* gsplit = nullptr;      // pre-split weight operands of those products, refreshed by every forward
+    unsigned short *ksp_fwd[SELD_MAX_LAYERS][2] = {}, *ksp_bwd[SELD_MAX_LAYERS][2] = {}, *h0sp_fwd[2] = {}, *h0sp_bwd[2] = {};
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -287,6 +291,25 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     }
     for (int hd = 0; hd < 2; ++hd)
         for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
+    {
+        // pre-split bf16 planes: every GRU kernel and the heads' first layers, in the forward ([n][k]) and the
+        // input-gradient ([in][out]) orientation
+        size_t ne = 0;
+        for (int i = 0; i < a->n_gru; ++i) ne += 4 * gemm_sb_split_elems(c->gru[i].in_feat, 384);
+        for (int hd = 0; hd < 2; ++hd) ne += 2 * gemm_sb_split_elems(c->heads[hd].layers[0].in, c->heads[hd].layers[0].out);
+        ALLOC(c->gsplit, ne);
+        unsigned short* q = c->gsplit;
+        for (int i = 0; i < a->n_gru; ++i)
+            for (int d = 0; d < 2; ++d) {
+                c->ksp_fwd[i][d] = q; q += gemm_sb_split_elems(c->gru[i].in_feat, 384);
+                c->ksp_bwd[i][d] = q; q += gemm_sb_split_elems(c->gru[i].in_feat, 384);
+            }
+        for (int hd = 0; hd < 2; ++hd) {
+            const DenseL& D = c->heads[hd].layers[0];
+            c->h0sp_fwd[hd] = q; q += gemm_sb_split_elems(D.in, D.out);
+            c->h0sp_bwd[hd] = q; q += gemm_sb_split_elems(D.in, D.out);
+        }
+    }
     ALLOC(c->loss_scratch, (size_t)loss_scratch_floats((int)rows));
     ALLOC(c->den_dev, 4); ALLOC(c->loss_out, rows + 4);
 #undef ALLOC
@@ -318,6 +341,7 @@ int seld_set_batch(seld_ctx* c, int B) {
 int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!c || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
@@ -384,10 +408,46 @@ static void fork_side(seld_ctx* c) {
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
 }
+// Which products run on the split-bf16 GEMM: shapes gemm_sb.hip handles (K % 32 == 0, N % 128 == 0); anything else stays
+// on the exact-fp32 MFMA GEMM.  The same predicates gate the forward product and its input gradient.
+static bool gru_sb(const seld_ctx* c, const GruL& G) { return c->gemm_split_bf16 && (G.in_feat % 128) == 0; }
+static bool heads_sb(const seld_ctx* c) {
+    const DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+    return c->gemm_split_bf16 && c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out &&
+           (S0.in % 128) == 0 && (S0.out % 128) == 0;
+}
+
+// one launch splits every weight operand the split-bf16 GEMMs of this step will read (the weights change every step)
+static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orientation) {
+    const float* src[16]; unsigned short* dst[16]; int ldb[16], tb[16], K[16], N[16];
+    int n = 0;
+    auto flush = [&]() { int rc = n ? launch_gemm_split_b(st, n, src, dst, ldb, tb, K, N) : 0; n = 0; return rc; };
+    auto add = [&](const float* w, unsigned short* d, int ld, int transb, int k, int nn) {
+        src[n] = w; dst[n] = d; ldb[n] = ld; tb[n] = transb; K[n] = k; N[n] = nn;
+        return ++n == 16 ? flush() : 0;
+    };
+    for (size_t i = 0; i < c->gru.size(); ++i) {
+        const GruL& G = c->gru[i];
+        if (!gru_sb(c, G)) continue;
+        for (int d = 0; d < 2; ++d) {
+            if (add(c->params + G.k_off[d], c->ksp_fwd[i][d], 384, 0, G.in_feat, 384)) return -1;     // gx = feat K
+            if (with_grad_orientation && add(c->params + G.k_off[d], c->ksp_bwd[i][d], 384, 1, 384, G.in_feat)) return -1;   // din = dgx K^T
+        }
+    }
+    if (heads_sb(c))
+        for (int hd = 0; hd < 2; ++hd) {
+            const DenseL& D = c->heads[hd].layers[0];
+            if (add(c->params + D.w_off, c->h0sp_fwd[hd], D.out, 0, D.in, D.out)) return -1;
+            if (with_grad_orientation && add(c->params + D.w_off, c->h0sp_bwd[hd], D.out, 1, D.out, D.in)) return -1;
+        }
+    return flush();
+}
+
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
     const int rows = B * S;
+    if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
     const float* in = x;
     for (size_t i = 0; i < c->conv.size(); ++i) {
         ConvL& L = c->conv[i];
@@ -443,8 +503,12 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         {
             PROF2(c, "gru_inproj_gemm");
             // both directions' projections of the same input in one launch
-            launch_gemm_dual_n(st, feat, G.in_feat, c->params + G.k_off[0], c->params + G.k_off[1], 384, c->params + G.b_off[0],
-                               c->params + G.b_off[1], G.gx[0], G.gx[1], 384, rows, 384, G.in_feat, 0, 0);
+            if (gru_sb(c, G) && gemm_sb_usable(feat, G.in_feat, 384, G.in_feat))
+                launch_gemm_sb(st, feat, nullptr, G.in_feat, c->ksp_fwd[i][0], c->ksp_fwd[i][1], c->params + G.b_off[0],
+                               c->params + G.b_off[1], G.gx[0], G.gx[1], 384, rows, 384, G.in_feat, 0, 1);
+            else
+                launch_gemm_dual_n(st, feat, G.in_feat, c->params + G.k_off[0], c->params + G.k_off[1], 384, c->params + G.b_off[0],
+                                   c->params + G.b_off[1], G.gx[0], G.gx[1], 384, rows, 384, G.in_feat, 0, 0);
         }
         if (i == 0 && c->gram_active) fork_side(c);
         {
@@ -472,7 +536,10 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // Conv1D(128) in both) and neither is the head's output layer
         DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
         const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out;
-        if (merged0)
+        if (merged0 && heads_sb(c) && gemm_sb_usable(feat, S0.in, S0.out, S0.in))
+            launch_gemm_sb(st, feat, nullptr, S0.in, c->h0sp_fwd[0], c->h0sp_fwd[1], c->params + S0.b_off, c->params + D0.b_off, S0.y,
+                           D0.y, S0.out, rows, S0.out, S0.in, 0, 1);
+        else if (merged0)
             launch_gemm_dual_n(st, feat, S0.in, c->params + S0.w_off, c->params + D0.w_off, S0.out, c->params + S0.b_off,
                                c->params + D0.b_off, S0.y, D0.y, S0.out, rows, S0.out, S0.in, 0, 0);
         for (int hd = 0; hd < 2; ++hd) {
@@ -574,7 +641,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
             }
         }
-        if (merged0)
+        if (merged0 && heads_sb(c) && gemm_sb_usable(S0.dy, S0.out, S0.in, S0.out) && gemm_sb_usable(D0.dy, S0.out, S0.in, S0.out))
+            launch_gemm_sb(st, S0.dy, D0.dy, S0.out, c->h0sp_bwd[0], c->h0sp_bwd[1], nullptr, nullptr, dfeat, nullptr, S0.in, rows, S0.in,
+                           S0.out, 0, 2);
+        else if (merged0)
             launch_gemm_dual_k(st, S0.dy, D0.dy, S0.out, c->params + S0.w_off, c->params + D0.w_off, S0.out, nullptr, dfeat, S0.in, rows,
                                S0.in, S0.out, 1, 0, 0);
         fork_side(c);
@@ -609,8 +679,12 @@ static int backward_impl(seld_ctx* c, const float* x) {
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
-            launch_gemm_dual_k(st, c->dgx[i][0], c->dgx[i][1], 384, c->params + G.k_off[0], c->params + G.k_off[1], 384, nullptr, G.din,
-                               G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
+            if (gru_sb(c, G))
+                launch_gemm_sb(st, c->dgx[i][0], c->dgx[i][1], 384, c->ksp_bwd[i][0], c->ksp_bwd[i][1], nullptr, nullptr, G.din, nullptr,
+                               G.in_feat, rows, G.in_feat, 384, 0, 2);
+            else
+                launch_gemm_dual_k(st, c->dgx[i][0], c->dgx[i][1], 384, c->params + G.k_off[0], c->params + G.k_off[1], 384, nullptr,
+                                   G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
         }
         dout = G.din;
     }

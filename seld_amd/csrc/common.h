@@ -92,6 +92,16 @@ int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0,
                        const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int transb, int act);
 int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda, const float* B0, const float* B1, int ldb,
                        const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate);
+// split-bf16 GEMM (gemm_sb.hip): weights pre-split into bf16 planes by launch_gemm_split_b (up to 16 operands per launch),
+// then C = act(A B + bias) with mode 0 / 1 (two products sharing A) / 2 (one product over a concatenated K).
+// Usable when K % 32 == 0, N % 128 == 0, lda % 4 == 0 and A is 16-byte aligned (gemm_sb_usable); no accumulate form.
+extern int g_gsb_dbg;   // tools/tune_gemm.py: 1 no loads in the 4-wave loop, 2 no stores, 4 force the 4-wave form, 8 the 16-wave form
+size_t gemm_sb_split_elems(int K, int N);
+int gemm_sb_usable(const void* A, int lda, int N, int K);
+int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsigned short* const* dst, const int* ldb,
+                        const int* transb, const int* K, const int* N);
+int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
+                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode);
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,

@@ -1,0 +1,329 @@
+// gemm_sb.hip — split-bf16 GEMM for the row-streamed products of the recurrent block and the heads:
+//   GRU input projections   gx = feat * kernel + bias          (modules.py:311-316; M = B*T/5, K = 128, N = 2 x 384)
+//   their input gradients   dfeat = dgx_f kernel_f^T + dgx_b kernel_b^T                     (K = 2 x 384, N = 128)
+//   first Conv1D(128, 1) of the SED / DOA heads and its input gradient (modules.py:326-346)
+// Same numerics as conv_sb.hip: every fp32 operand is split exactly into three bf16 values (x = hi + mid + lo)
+// and the product is the 6 leading bf16 MFMA terms accumulated in fp32 (error ~2^-24 relative per product, i.e.
+// fp32 level; the parity bar is 1e-4).  v_mfma_f32_32x32x16_bf16 runs 16x the rate of the fp32 MFMA, so 6 of
+// them still cost 2.7x less than the exact-fp32 instruction, and a bf16 A fragment is 8 CONTIGUOUS k of one row:
+// the fp32 rows of A go global -> registers in MFMA layout (64 B per lane per 32-k chunk) and are split there,
+// with no LDS transpose at all.  Only the (small, pre-split) weight operand passes through LDS.
+//
+// Work split: wave = 32 rows x 128 columns (4 accumulator tiles), workgroup = 4 waves = 128 rows; K is walked in
+// chunks of 32; the chunk of B (3 planes x 128 columns x 32 k = 24 KB) is double-buffered in LDS with one LDS-only
+// barrier per chunk; the next chunk's A rows and B planes are in flight (registers) while the current one is
+// multiplied.  Column groups are the fast grid index so the blocks that share rows of A run together.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define GSB_KC 32
+#define GSB_BN 128
+#define GSB_MAX_JOBS 16
+
+// exact 3-way truncation split of two floats, packed as bf16 pairs (element 0 in the low half) — as conv_sb.hip
+__device__ __forceinline__ void gsb_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+
+// ---- weight pre-pass ---------------------------------------------------------------------------
+// B fp32 ([K,N] if !transb, [N,K] if transb) -> planes [chunk c = k/32][plane][n][piece'][8] bf16 with
+// piece' = piece ^ ((n >> 2) & 3): the image of one (chunk, plane, 128-column group) is the 8 KB the GEMM copies
+// verbatim into LDS, already swizzled so that each 16-lane group of a ds_read_b128 (lanes {0-3,12-15,20-27}, ...: 64-B rows put
+// column n on slot 4 (n & 3) + piece' of the 256-B bank row) covers all 16 slots.
+struct GemmSplitJobs {
+    int njobs;
+    const float* src[GSB_MAX_JOBS];
+    unsigned short* dst[GSB_MAX_JOBS];
+    int ldb[GSB_MAX_JOBS], transb[GSB_MAX_JOBS], K[GSB_MAX_JOBS], N[GSB_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void gemm_split_b_kernel(GemmSplitJobs jobs) {
+    const int job = blockIdx.y;
+    const int K = jobs.K[job], N = jobs.N[job], ldb = jobs.ldb[job], transb = jobs.transb[job];
+    const float* __restrict__ src = jobs.src[job];
+    unsigned short* __restrict__ dst = jobs.dst[job];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < K * N; idx += gridDim.x * 256) {
+        // the fast index follows the contiguous axis of the source
+        const int k = transb ? idx % K : idx / N, n = transb ? idx / K : idx % N;
+        const float x = transb ? src[(size_t)n * ldb + k] : src[(size_t)k * ldb + n];
+        const unsigned u = __float_as_uint(x);
+        const float r = x - __uint_as_float(u & 0xffff0000u);
+        const unsigned v = __float_as_uint(r);
+        const float s = r - __uint_as_float(v & 0xffff0000u);
+        const int c = k >> 5, kk = k & 31, piece = (kk >> 3) ^ ((n >> 2) & 3);
+        unsigned short* o = dst + ((size_t)c * 3 * N + n) * GSB_KC + piece * 8 + (kk & 7);
+        o[0] = (unsigned short)(u >> 16);
+        o[(size_t)N * GSB_KC] = (unsigned short)(v >> 16);
+        o[(size_t)2 * N * GSB_KC] = (unsigned short)(__float_as_uint(s) >> 16);
+    }
+}
+
+size_t gemm_sb_split_elems(int K, int N) { return (size_t)3 * K * N; }   // bf16 elements of one pre-split operand
+
+int gemm_sb_usable(const void* A, int lda, int N, int K) {
+    return (K % GSB_KC) == 0 && (N % GSB_BN) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+}
+
+int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsigned short* const* dst, const int* ldb,
+                        const int* transb, const int* K, const int* N) {
+    if (njobs <= 0 || njobs > GSB_MAX_JOBS) return -1;
+    GemmSplitJobs j;
+    j.njobs = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (K[i] % GSB_KC) return -2;
+        j.src[i] = src[i]; j.dst[i] = dst[i]; j.ldb[i] = ldb[i]; j.transb[i] = transb[i]; j.K[i] = K[i]; j.N[i] = N[i];
+    }
+    hipLaunchKernelGGL(gemm_split_b_kernel, dim3(48, njobs), dim3(256), 0, st, j);
+    return 0;
+}
+
+// ---- the product -------------------------------------------------------------------------------
+// mode 0: C0 = act(A0 B0 + bias0).
+// mode 1 (two products sharing A): column groups >= N/128 compute C1 = act(A0 B1 + bias1).
+// mode 2 (one product over a concatenated K axis): C0 = act(A0 B0 + A1 B1 + bias0).
+__global__ __launch_bounds__(256, 3) void gemm_sb_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
+                                                         const unsigned short* __restrict__ Bs0,
+                                                         const unsigned short* __restrict__ Bs1,
+                                                         const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                                         float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
+                                                         int K, int act, int mode, int dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 5, li = lane & 31;
+    const int ngrp = N / GSB_BN;
+    int grp = blockIdx.x;
+    const float* bias = bias0;
+    float* C = C0;
+    if (mode == 1 && grp >= ngrp) { grp -= ngrp; Bs0 = Bs1; bias = bias1; C = C1; }
+    const int n0 = grp * GSB_BN;
+    const int m0 = blockIdx.y * 128 + wave * 32;
+    const int nck = K / GSB_KC, ng = mode == 2 ? 2 * nck : nck;
+    // this lane's row of A (rows past M read the last row; their results are not stored)
+    const int arow = min(m0 + li, M - 1);
+    const size_t aoff = (size_t)arow * lda + 16 * kg;
+
+    f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16(), acc3 = zero16();
+    float4 ca0, ca1, ca2, ca3, na0, na1, na2, na3;    // the chunk being multiplied / the chunk in flight (16 k each)
+    u32x4 bq0, bq1, bq2, bq3, bq4, bq5;               // B chunk in flight: 3 planes x 2 pieces of 16 B per thread
+    // the (chunk g, plane p) image of this column group: 128 columns x 64 B, contiguous
+#define GSB_ISSUE(g_)                                                                                          \
+    {                                                                                                          \
+        const int h_ = (g_) >= nck ? 1 : 0, gc_ = (g_) - h_ * nck;                                             \
+        const float4* ap_ = reinterpret_cast<const float4*>((h_ ? A1 : A0) + aoff + (size_t)gc_ * GSB_KC);     \
+        na0 = ap_[0]; na1 = ap_[1]; na2 = ap_[2]; na3 = ap_[3];                                                \
+        const u32x4* bp_ = reinterpret_cast<const u32x4*>((h_ ? Bs1 : Bs0) + ((size_t)gc_ * 3 * N + n0) * GSB_KC); \
+        const size_t ps_ = (size_t)N * GSB_KC / 8;  /* plane stride in 16-B units */                           \
+        bq0 = bp_[tid]; bq1 = bp_[tid + 256];                                                                  \
+        bq2 = bp_[ps_ + tid]; bq3 = bp_[ps_ + tid + 256];                                                      \
+        bq4 = bp_[2 * ps_ + tid]; bq5 = bp_[2 * ps_ + tid + 256];                                              \
+    }
+#define GSB_COMMIT(buf_)                                                          \
+    {                                                                             \
+        u32x4* d_ = reinterpret_cast<u32x4*>(Bl[buf_]);                           \
+        d_[tid] = bq0; d_[tid + 256] = bq1;                                       \
+        d_[512 + tid] = bq2; d_[512 + tid + 256] = bq3;                           \
+        d_[1024 + tid] = bq4; d_[1024 + tid + 256] = bq5;                         \
+    }
+    GSB_ISSUE(0)
+    GSB_COMMIT(0)
+    ca0 = na0; ca1 = na1; ca2 = na2; ca3 = na3;
+    lds_barrier();
+    // fragment of column (nt*32 + li), k-step s: piece (2 kg + s) ^ ((li >> 2) & 3) of its 64-B row
+    const int swz = (li >> 2) & 3;
+    const int boff0 = li * GSB_KC + (((2 * kg) ^ swz) << 3), boff1 = li * GSB_KC + (((2 * kg + 1) ^ swz) << 3);
+#define GSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+#define GSB_STEP(x0_, x1_, boff_)                                                                     \
+    {                                                                                                 \
+        unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_, l0_, l1_, l2_, l3_;                          \
+        gsb_split3_pair(x0_.x, x0_.y, h0_, m0_, l0_);                                                 \
+        gsb_split3_pair(x0_.z, x0_.w, h1_, m1_, l1_);                                                 \
+        gsb_split3_pair(x1_.x, x1_.y, h2_, m2_, l2_);                                                 \
+        gsb_split3_pair(x1_.z, x1_.w, h3_, m3_, l3_);                                                 \
+        const u32x4 h_ = {h0_, h1_, h2_, h3_}, m_ = {m0_, m1_, m2_, m3_}, l_ = {l0_, l1_, l2_, l3_};  \
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h_), am = __builtin_bit_cast(bf16x8, m_),        \
+                     al = __builtin_bit_cast(bf16x8, l_);                                             \
+        const unsigned short* bb_ = bl + boff_;                                                       \
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb_), bh1 = *reinterpret_cast<const bf16x8*>(bb_ + 32 * GSB_KC), \
+                     bh2 = *reinterpret_cast<const bf16x8*>(bb_ + 64 * GSB_KC), bh3 = *reinterpret_cast<const bf16x8*>(bb_ + 96 * GSB_KC); \
+        const unsigned short* bm_ = bb_ + GSB_BN * GSB_KC;                                            \
+        const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(bm_), bm1 = *reinterpret_cast<const bf16x8*>(bm_ + 32 * GSB_KC), \
+                     bm2 = *reinterpret_cast<const bf16x8*>(bm_ + 64 * GSB_KC), bm3 = *reinterpret_cast<const bf16x8*>(bm_ + 96 * GSB_KC); \
+        const unsigned short* bl_ = bm_ + GSB_BN * GSB_KC;                                            \
+        const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(bl_), bl1 = *reinterpret_cast<const bf16x8*>(bl_ + 32 * GSB_KC), \
+                     bl2 = *reinterpret_cast<const bf16x8*>(bl_ + 64 * GSB_KC), bl3 = *reinterpret_cast<const bf16x8*>(bl_ + 96 * GSB_KC); \
+        GSB_MFMA(ah, bh0, acc0); GSB_MFMA(ah, bh1, acc1); GSB_MFMA(ah, bh2, acc2); GSB_MFMA(ah, bh3, acc3);   /* hi*hi  */ \
+        GSB_MFMA(ah, bm0, acc0); GSB_MFMA(ah, bm1, acc1); GSB_MFMA(ah, bm2, acc2); GSB_MFMA(ah, bm3, acc3);   /* hi*mid */ \
+        GSB_MFMA(am, bh0, acc0); GSB_MFMA(am, bh1, acc1); GSB_MFMA(am, bh2, acc2); GSB_MFMA(am, bh3, acc3);   /* mid*hi */ \
+        GSB_MFMA(ah, bl0, acc0); GSB_MFMA(ah, bl1, acc1); GSB_MFMA(ah, bl2, acc2); GSB_MFMA(ah, bl3, acc3);   /* hi*lo  */ \
+        GSB_MFMA(al, bh0, acc0); GSB_MFMA(al, bh1, acc1); GSB_MFMA(al, bh2, acc2); GSB_MFMA(al, bh3, acc3);   /* lo*hi  */ \
+        GSB_MFMA(am, bm0, acc0); GSB_MFMA(am, bm1, acc1); GSB_MFMA(am, bm2, acc2); GSB_MFMA(am, bm3, acc3);   /* mid*mid */ \
+    }
+    for (int g = 0; g < ng; ++g) {
+        // always issue (the last chunk re-reads itself): a conditional issue would make the in-flight registers a phi and
+        // put the wait for the loads right at the merge
+        if (!(dbg & 1)) GSB_ISSUE(min(g + 1, ng - 1))
+        __builtin_amdgcn_sched_barrier(0);   // keep the issue up here: the scheduler otherwise sinks the loads to their use
+        const unsigned short* bl = Bl[g & 1];
+        GSB_STEP(ca0, ca1, boff0)
+        GSB_STEP(ca2, ca3, boff1)
+        __builtin_amdgcn_sched_barrier(0);
+        GSB_COMMIT((g + 1) & 1)
+        ca0 = na0; ca1 = na1; ca2 = na2; ca3 = na3;
+        lds_barrier();
+    }
+#undef GSB_ISSUE
+#undef GSB_COMMIT
+#undef GSB_STEP
+    // epilogue.  The bias values are fetched before the first store: on gfx950 stores count in vmcnt too, so a load placed
+    // between the store groups would wait for every store issued before it.
+    const float bv0 = bias ? bias[n0 + li] : 0.f, bv1 = bias ? bias[n0 + 32 + li] : 0.f, bv2 = bias ? bias[n0 + 64 + li] : 0.f,
+                bv3 = bias ? bias[n0 + 96 + li] : 0.f;
+    if (dbg & 2) return;
+    float* crow = C + (size_t)(m0 + 4 * kg) * ldc + n0 + li;
+    const int rows_left = M - m0 - 4 * kg;   // rows of this lane's stripe that exist
+#define GSB_STORE(ACC_, nt_, BV_)                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+        const int dr = (r & 3) + 8 * (r >> 2);                                               \
+        float v = ACC_[r] + BV_;                                                             \
+        if (act == 1) v = 1.f / (1.f + expf(-v));                                            \
+        else if (act == 2) v = tanhf(v);                                                     \
+        if (full || dr < rows_left) crow[(size_t)dr * ldc + (nt_) * 32] = v;                 \
+    }
+    const bool full = m0 + 32 <= M;   // wave-uniform: every block but the last takes the unguarded stores
+    if (act == 0 && full) {
+#define GSB_STORE_PLAIN(ACC_, nt_, BV_)                                                      \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * ldc + (nt_) * 32] = ACC_[r] + BV_;
+        GSB_STORE_PLAIN(acc0, 0, bv0) GSB_STORE_PLAIN(acc1, 1, bv1) GSB_STORE_PLAIN(acc2, 2, bv2) GSB_STORE_PLAIN(acc3, 3, bv3)
+#undef GSB_STORE_PLAIN
+    } else {
+        GSB_STORE(acc0, 0, bv0) GSB_STORE(acc1, 1, bv1) GSB_STORE(acc2, 2, bv2) GSB_STORE(acc3, 3, bv3)
+    }
+#undef GSB_STORE
+}
+
+// ---- variant with both operands in LDS ----------------------------------------------------------
+// Workgroup = 16 waves = 128 rows x 128 columns, wave (wr, wc) = one 32x32 tile.  The A chunk (128 rows x 32 k) is read
+// as one float4 per thread (8 rows x 128 B per wave: whole cache lines), split there and stored as three bf16 planes in
+// the same swizzled [row][4 pieces x 16 B] image as B.  With N = 128 the model has only 600 row tiles for 1024 SIMDs, so
+// the one-wave-per-row-tile form above leaves a lone wave per SIMD that exposes every load and every split; here each
+// SIMD interleaves 4 waves and the staging work per thread is 4 elements per chunk.  Measured (tools/tune_gemm.py,
+// M = 19200): K = 2 x 384, N = 128: 37 us against 52 us; K = 128, N = 2 x 384: 38 us against 35 us — the launcher
+// picks by the number of column groups.  (Prefetching three chunks ahead and placing the next chunk's split / LDS stores
+// in the MFMA gaps with sched_group_barrier were both measured slower than this plain form.)
+__global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
+                                                         const unsigned short* __restrict__ Bs0,
+                                                         const unsigned short* __restrict__ Bs1,
+                                                         const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                                         float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
+                                                         int K, int act, int mode) {
+    __shared__ __attribute__((aligned(16))) unsigned short Al[2][3 * 128 * GSB_KC];      // 2 x 24 KB
+    __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 5, li = lane & 31, wr = wave >> 2, wc = wave & 3;
+    const int ngrp = N / GSB_BN;
+    int grp = blockIdx.x;
+    const float* bias = bias0;
+    float* C = C0;
+    if (mode == 1 && grp >= ngrp) { grp -= ngrp; Bs0 = Bs1; bias = bias1; C = C1; }
+    const int n0 = grp * GSB_BN, m0 = blockIdx.y * 128;
+    const int nck = K / GSB_KC, ng = mode == 2 ? 2 * nck : nck;
+    // staging role: row srow, floats [4 sk, 4 sk + 4) of the chunk
+    const int srow = tid >> 3, sk = tid & 7;
+    const size_t aoff = (size_t)min(m0 + srow, M - 1) * lda + 4 * sk;
+    const int a_dst = srow * GSB_KC + ((((sk >> 1) ^ (srow >> 2)) & 3) << 3) + 4 * (sk & 1);   // bf16 index inside a plane
+    const size_t bplane = (size_t)N * GSB_KC / 8;   // plane stride of the pre-split B, in 16-B units
+    float4 na;
+    u32x4 nb0, nb1;
+#define G16_ISSUE(g_)                                                                                           \
+    {                                                                                                           \
+        const int h_ = (g_) >= nck ? 1 : 0, gc_ = (g_) - h_ * nck;                                              \
+        na = *reinterpret_cast<const float4*>((h_ ? A1 : A0) + aoff + (size_t)gc_ * GSB_KC);                    \
+        const u32x4* bp_ = reinterpret_cast<const u32x4*>((h_ ? Bs1 : Bs0) + ((size_t)gc_ * 3 * N + n0) * GSB_KC); \
+        nb0 = bp_[(tid >> 9) * bplane + (tid & 511)];            /* planes 0 and 1 */                           \
+        nb1 = bp_[2 * bplane + (tid & 511)];                     /* plane 2: used by the first 512 threads */   \
+    }
+#define G16_COMMIT(buf_)                                                                                        \
+    {                                                                                                           \
+        unsigned h0_, m0_, l0_, h1_, m1_, l1_;                                                                  \
+        gsb_split3_pair(na.x, na.y, h0_, m0_, l0_);                                                             \
+        gsb_split3_pair(na.z, na.w, h1_, m1_, l1_);                                                             \
+        unsigned short* ad_ = Al[buf_] + a_dst;                                                                 \
+        *reinterpret_cast<uint2*>(ad_) = make_uint2(h0_, h1_);                                                  \
+        *reinterpret_cast<uint2*>(ad_ + 128 * GSB_KC) = make_uint2(m0_, m1_);                                   \
+        *reinterpret_cast<uint2*>(ad_ + 2 * 128 * GSB_KC) = make_uint2(l0_, l1_);                               \
+        u32x4* bd_ = reinterpret_cast<u32x4*>(Bl[buf_]);                                                        \
+        bd_[tid] = nb0;                                                                                         \
+        if (tid < 512) bd_[1024 + tid] = nb1;                                                                   \
+    }
+    G16_ISSUE(0)
+    G16_COMMIT(0)
+    lds_barrier();
+    f32x16 acc0 = zero16(), acc1 = zero16();   // two chains: 3 of the 6 products each
+    // fragment (row or column r, k-step s): piece (2 s + kg) ^ ((r >> 2) & 3) of its 64-B row; r = tile * 32 + li
+    const int swz = (li >> 2) & 3;
+    const int foff0 = li * GSB_KC + ((kg ^ swz) << 3), foff1 = li * GSB_KC + (((2 + kg) ^ swz) << 3);
+    const int aofs = wr * 32 * GSB_KC, bofs = wc * 32 * GSB_KC;
+#define G16_STEP(foff_)                                                                                         \
+    {                                                                                                           \
+        const unsigned short* ap_ = al + aofs + foff_;                                                          \
+        const unsigned short* bp_ = bl + bofs + foff_;                                                          \
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), am = *reinterpret_cast<const bf16x8*>(ap_ + 128 * GSB_KC),   \
+                     al_ = *reinterpret_cast<const bf16x8*>(ap_ + 2 * 128 * GSB_KC);                            \
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp_), bm = *reinterpret_cast<const bf16x8*>(bp_ + GSB_BN * GSB_KC), \
+                     bl_ = *reinterpret_cast<const bf16x8*>(bp_ + 2 * GSB_BN * GSB_KC);                         \
+        GSB_MFMA(ah, bh, acc0); GSB_MFMA(ah, bm, acc1); GSB_MFMA(am, bh, acc0);                                 \
+        GSB_MFMA(ah, bl_, acc1); GSB_MFMA(al_, bh, acc0); GSB_MFMA(am, bm, acc1);                               \
+    }
+    for (int g = 0; g < ng; ++g) {
+        G16_ISSUE(min(g + 1, ng - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short* al = Al[g & 1];
+        const unsigned short* bl = Bl[g & 1];
+        G16_STEP(foff0)
+        G16_STEP(foff1)
+        __builtin_amdgcn_sched_barrier(0);
+        G16_COMMIT((g + 1) & 1)
+        lds_barrier();
+    }
+#undef G16_ISSUE
+#undef G16_COMMIT
+#undef G16_STEP
+    const int col = n0 + wc * 32 + li;
+    const float bv = bias ? bias[col] : 0.f;
+    const int rbase = m0 + wr * 32 + 4 * kg;
+    float* crow = C + (size_t)rbase * ldc + col;
+    const int rows_left = M - rbase;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float v = (acc0[r] + acc1[r]) + bv;
+        if (act == 1) v = 1.f / (1.f + expf(-v));
+        else if (act == 2) v = tanhf(v);
+        if (dr < rows_left) crow[(size_t)dr * ldc] = v;
+    }
+}
+
+int g_gsb_dbg = 0;
+int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
+                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode) {
+    if (M <= 0 || N <= 0 || K <= 0 || !gemm_sb_usable(A0, lda, N, K)) return -1;
+    if (mode == 2 && !gemm_sb_usable(A1, lda, N, K)) return -1;
+    dim3 grid(N / GSB_BN * (mode == 1 ? 2 : 1), (M + 127) / 128);
+    // few column groups: not enough row tiles to give every SIMD more than one wave -> the 16-wave form
+    const bool wide = grid.x >= 2;
+    if ((g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide)
+        hipLaunchKernelGGL(gemm_sb_kernel, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode,
+                           g_gsb_dbg & 3);
+    else
+        hipLaunchKernelGGL(gemm_sb16_kernel, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
+                           mode);
+    return 0;
+}

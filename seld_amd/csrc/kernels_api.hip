@@ -31,6 +31,7 @@ extern "C" {
 int seld_k_set_option(const char* key, int value) {
     if (!key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
     return SELD_ERR_INVALID;
 }
 
@@ -221,6 +222,37 @@ int seld_k_gemm(const float* A, const float* Bm, const float* bias, float* C, in
                 int accumulate) {
     if (!A || !Bm || !C) return SELD_ERR_INVALID;
     if (launch_gemm(0, A, K, Bm, transb ? K : N, bias, C, N, M, N, K, transb, act, accumulate)) return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_gemm_pair_n(const float* A, const float* B0, const float* B1, const float* bias0, const float* bias1, float* C0,
+                       float* C1, int M, int N, int K, int transb, int act) {
+    if (!A || !B0 || !B1 || !C0 || !C1) return SELD_ERR_INVALID;
+    if (launch_gemm_dual_n(0, A, K, B0, B1, transb ? K : N, bias0, bias1, C0, C1, N, M, N, K, transb, act)) return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_gemm_pair_k(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias, float* C, int M,
+                       int N, int K, int transb, int act, int accumulate) {
+    if (!A0 || !A1 || !B0 || !B1 || !C) return SELD_ERR_INVALID;
+    if (launch_gemm_dual_k(0, A0, A1, K, B0, B1, transb ? K : N, bias, C, N, M, N, K, transb, act, accumulate))
+        return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0, const float* bias1,
+                   float* C0, float* C1, int M, int N, int K, int transb, int act, int mode) {
+    if (!A0 || !B0 || !C0 || mode < 0 || mode > 2 || (mode && !B1) || (mode == 1 && !C1) || (mode == 2 && !A1)) return SELD_ERR_INVALID;
+    if (M <= 0 || N <= 0 || K <= 0 || !gemm_sb_usable(A0, K, N, K) || (mode == 2 && !gemm_sb_usable(A1, K, N, K))) return SELD_ERR_INVALID;
+    Scratch s;
+    const size_t ne = gemm_sb_split_elems(K, N);
+    unsigned short* sp = reinterpret_cast<unsigned short*>(s.get(ne));   // 2 operands x ne bf16 = ne floats
+    if (!sp) return SELD_ERR_NOMEM;
+    const float* src[2] = {B0, B1};
+    unsigned short* dst[2] = {sp, sp + ne};
+    const int ldb[2] = {transb ? K : N, transb ? K : N}, tb[2] = {transb, transb}, Ks[2] = {K, K}, Ns[2] = {N, N};
+    if (launch_gemm_split_b(0, mode ? 2 : 1, src, dst, ldb, tb, Ks, Ns)) return SELD_ERR_INVALID;
+    if (launch_gemm_sb(0, A0, A1, K, dst[0], dst[1], bias0, bias1, C0, C1, N, M, N, K, act, mode)) return SELD_ERR_INVALID;
     return done();
 }
 

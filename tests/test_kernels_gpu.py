@@ -184,6 +184,73 @@ def test_gemm(seld_lib, M, N, K, transb, act):
     check("gemm accumulate", Cd.cpu().numpy(), C0 + A.astype(np.float64) @ (Bm.T if transb else Bm).astype(np.float64))
 
 
+@pytest.mark.parametrize("M,N,K,transb", [(1200, 384, 128, 0), (333, 384, 64, 0), (200, 128, 128, 0), (1200, 128, 384, 1),
+                                          (77, 128, 128, 1), (50, 30, 64, 0)])
+def test_gemm_pairs(seld_lib, M, N, K, transb):
+    """Merged launches: two products sharing A, and one product over a concatenated K axis."""
+    rng = np.random.default_rng(15)
+    A0, A1 = (rng.standard_normal((M, K)).astype(np.float32) for _ in range(2))
+    B0, B1 = ((rng.standard_normal((N, K) if transb else (K, N)) / np.sqrt(K)).astype(np.float32) for _ in range(2))
+    b0, b1 = (rng.standard_normal(N).astype(np.float32) for _ in range(2))
+    op = (lambda m: m.T.astype(np.float64)) if transb else (lambda m: m.astype(np.float64))
+    C0 = torch.full((M, N), float("nan"), device="cuda")
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    A0d, A1d, B0d, B1d, b0d, b1d = dev(A0), dev(A1), dev(B0), dev(B1), dev(b0), dev(b1)
+    assert seld_lib.seld_k_gemm_pair_n(ptr(A0d), ptr(B0d), ptr(B1d), ptr(b0d), ptr(b1d), ptr(C0), ptr(C1), M, N, K, transb, 0) == 0
+    check("pair_n first", C0.cpu().numpy(), A0.astype(np.float64) @ op(B0) + b0)
+    check("pair_n second", C1.cpu().numpy(), A0.astype(np.float64) @ op(B1) + b1)
+    # the merged launch returns the very bits of two separate launches
+    S = torch.empty((M, N), device="cuda")
+    assert seld_lib.seld_k_gemm(ptr(A0d), ptr(B1d), ptr(b1d), ptr(S), M, N, K, transb, 0, 0) == 0
+    assert torch.equal(S, C1)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    rc = seld_lib.seld_k_gemm_pair_k(ptr(A0d), ptr(A1d), ptr(B0d), ptr(B1d), None, ptr(C), M, N, K, transb, 0, 0)
+    assert rc == 0
+    check("pair_k", C.cpu().numpy(), A0.astype(np.float64) @ op(B0) + A1.astype(np.float64) @ op(B1))
+
+
+def test_gemm_pair_k_refuses_ragged_k(seld_lib):
+    t = torch.zeros(64 * 64, device="cuda")
+    assert seld_lib.seld_k_gemm_pair_k(ptr(t), ptr(t), ptr(t), ptr(t), None, ptr(t), 8, 8, 20, 0, 0, 0) != 0
+
+
+@pytest.mark.parametrize("M,N,K,transb,mode", [(1200, 384, 128, 0, 1), (333, 128, 128, 0, 1), (200, 128, 64, 0, 0),
+                                               (1200, 128, 384, 1, 2), (77, 128, 128, 1, 2), (130, 256, 96, 1, 0),
+                                               (19200, 384, 128, 0, 1), (19200, 128, 384, 1, 2)])
+def test_gemm_split_bf16(seld_lib, M, N, K, transb, mode):
+    """Split-bf16 products (gemm_sb.hip) against float64, with operands spanning many binades so that the mid / lo
+    terms matter; the last two cases are the model's shapes at BASELINE.json's batch (32 clips x 600 frames)."""
+    rng = np.random.default_rng(16)
+    scale = lambda shape: np.exp2(rng.integers(-6, 7, size=shape)).astype(np.float32)
+    A0, A1 = ((rng.standard_normal((M, K)) * scale((M, K))).astype(np.float32) for _ in range(2))
+    bshape = (N, K) if transb else (K, N)
+    B0, B1 = ((rng.standard_normal(bshape) * scale(bshape) / np.sqrt(K)).astype(np.float32) for _ in range(2))
+    b0, b1 = (rng.standard_normal(N).astype(np.float32) for _ in range(2))
+    op = (lambda m: m.T.astype(np.float64)) if transb else (lambda m: m.astype(np.float64))
+    C0 = torch.full((M, N), float("nan"), device="cuda")
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    A0d, A1d, B0d, B1d, b0d, b1d = dev(A0), dev(A1), dev(B0), dev(B1), dev(b0), dev(b1)
+    rc = seld_lib.seld_k_gemm_sb(ptr(A0d), ptr(A1d), ptr(B0d), ptr(B1d), ptr(b0d), ptr(b1d), ptr(C0), ptr(C1), M, N, K, transb, 0,
+                                 mode)
+    assert rc == 0
+    ref0 = A0.astype(np.float64) @ op(B0) + b0
+    if mode == 2:
+        ref0 = ref0 + A1.astype(np.float64) @ op(B1)
+    # |error| against the product of magnitudes (what an fp32 dot product of these operands can promise)
+    mag = np.abs(A0).astype(np.float64) @ np.abs(op(B0)) + (np.abs(A1).astype(np.float64) @ np.abs(op(B1)) if mode == 2 else 0) + 1.0
+    err = np.abs(C0.cpu().numpy() - ref0) / mag
+    assert err.max() < 2e-6, err.max()
+    check("gemm_sb", C0.cpu().numpy(), ref0)
+    if mode == 1:
+        check("gemm_sb second product", C1.cpu().numpy(), A0.astype(np.float64) @ op(B1) + b1)
+
+
+def test_gemm_split_bf16_refuses_unsupported_shapes(seld_lib):
+    t = torch.zeros(256 * 256, device="cuda")
+    for N, K in ((100, 64), (128, 40)):
+        assert seld_lib.seld_k_gemm_sb(ptr(t), None, ptr(t), None, None, None, ptr(t), None, 64, N, K, 0, 0, 0) != 0
+
+
 @pytest.mark.parametrize("M,K1,N", [(1200, 128, 384), (333, 128, 12), (100, 128, 36), (40, 30, 50)])
 def test_gemm_tn(seld_lib, M, K1, N):
     rng = np.random.default_rng(6)

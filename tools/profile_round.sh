@@ -1,0 +1,26 @@
+#!/bin/bash
+# One round's evidence set, run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r01_h'
+# Writes gpurun_out/prof_<tag>/: bench.json (default bench line), bench_l2.json (every kernel group timed),
+# stats_kernel_stats.csv + bench_under_rocprof.json (rocprofv3 --kernel-trace --stats of the same command),
+# traffic.json (HBM bytes per launch from two separate PMC passes, tools/pmc_traffic.py).
+set -e -o pipefail
+tag=${1:-round}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd "$root"
+timeout -k 10 300 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --timing-level 2 > "$out/bench_l2.json" 2>> "$out/bench.err"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- \
+    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.log"
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o pmc -- \
+        python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> "$out/rocprof_$c.log"
+done
+f=$(find "$out/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
+w=$(find "$out/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
+python3 "$root/tools/pmc_traffic.py" "$f" "$w" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, build $tag" > "$out/traffic.json"
+rm -rf "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"   # raw per-dispatch counters are large; the per-kernel summary stays
+find "$out/stats" -name '*kernel_trace.csv' -delete
+cat "$out/bench.json"
