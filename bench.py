@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-level", type=int, default=1, help="1: major kernel groups (default), 2: every group")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=0|1",
+                    help="kernel-selection option of the C library (seld_set_option), for A/B runs; the default build is the product")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -126,6 +128,9 @@ def main():
 
     B, T = args.batch, args.frames
     model = models.seldnet((B, T, 64, 7), SELDNET_CONFIG, device=local)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        model.set_option(key, int(val))
     x, ys, yd = O.synthetic_batch(B, T, seed=1234 + rank)
     dev = torch.device("cuda", local)
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing

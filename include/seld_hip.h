@@ -77,7 +77,8 @@ int seld_sync(seld_ctx* ctx);
  * cores with every fp32 operand split exactly into three bf16 values and six partial products (fp32-level accuracy);
  * 0 selects the f32-input MFMA kernels.  "gemm_split_bf16" (default 1): the same scheme for the GRU input projections,
  * the heads' first Conv1D and their input gradients (gemm_sb.hip) where K % 32 == 0 and N % 128 == 0; 0 keeps them on
- * the f32-input MFMA GEMM.  "conv1_pool_fused" / "conv1_gram" (default 1): first block's pooling inside the conv
+ * the f32-input MFMA GEMM.  "conv1_split_bf16" (default 1): the same scheme for the first
+ * block's forward whenever its pre-BN tensor is not stored (conv_pool_sb.hip).  "conv1_pool_fused" / "conv1_gram" (default 1): first block's pooling inside the conv
  * epilogue / its kernel gradient from the patch Gram matrix. */
 int seld_set_option(seld_ctx* ctx, const char* key, int value);
 

@@ -61,6 +61,7 @@ struct seld_ctx {
     bool gram_active = false;              // the last training forward took that path
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
     hipEvent_t ev_gram = nullptr;
+    int conv1_split_bf16 = 1;              // 1: the z-free first-block forward on bf16 MFMA with exactly split operands (conv_pool_sb.hip)
     int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
     int gemm_split_bf16 = 1;               // 1: GRU input projections / heads' first Conv1D (and their input gradients) on the
                                            //    split-bf16 GEMM (gemm_sb.hip) where the shapes allow; 0: exact-fp32 MFMA GEMM
@@ -342,6 +343,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!c || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
@@ -465,7 +467,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd_pool(st, in, c->params + L.w_off, c->params + L.b_off, c->params + L.g_off,
                                            (save && !gram) ? L.z : nullptr, gram ? L.zext : L.p, save ? L.amax : nullptr, stat,
-                                           &npart, B, L.H, L.Cin))
+                                           &npart, B, L.H, L.Cin, c->conv1_split_bf16))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd_pool");
         } else if (i == 0) {
             PROF(c, tn);   // level 1

@@ -34,7 +34,10 @@ int launch_conv_first_fwd(hipStream_t st, const float* x, const float* w, const 
                           float* stat_partial, int* n_partial, int B, int H, int Cin);
 int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
                                float* z, float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H,
-                               int Cin);
+                               int Cin, int split_bf16 = 1);
+int launch_conv_first_fwd_pool_sb(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
+                                  float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H, int Cin);
+int conv_pool_sb_stat_capacity();
 int launch_pool_argext(hipStream_t st, const float* z, const float* gamma, unsigned char* amax, int B, int H, int W, int pt,
                        int pf);
 int conv_pool_stat_capacity();

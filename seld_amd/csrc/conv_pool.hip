@@ -326,8 +326,10 @@ static int launch_cpool(hipStream_t st, const float* x, const float* w, const fl
 // [n_partial][128].
 int launch_conv_first_fwd_pool(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
                                float* z, float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H,
-                               int Cin) {
+                               int Cin, int split_bf16) {
     if (H % 5 || H <= 0 || B <= 0 || (z != nullptr && amax == nullptr)) return -2;   // z is stored for a backward pass, which needs amax
+    // without a z to store the layer runs on the bf16 matrix cores with exactly split operands (conv_pool_sb.hip)
+    if (!z && split_bf16) return launch_conv_first_fwd_pool_sb(st, x, w, bias, gamma, zext, amax, stat_partial, n_partial, B, H, Cin);
     if (Cin == 7) return launch_cpool<7>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
     if (Cin == 10) return launch_cpool<10>(st, x, w, bias, gamma, z, zext, amax, stat_partial, n_partial, B, H);
     return -2;

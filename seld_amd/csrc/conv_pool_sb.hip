@@ -1,0 +1,253 @@
+// conv_pool_sb.hip — the z-free form of conv_pool.hip (first-layer Conv2D, layers.py:27-32, with the (5,4) max-pool
+// window reduction of the pre-normalisation output in its epilogue) on the bf16 matrix cores: every fp32 operand is
+// split exactly into three bf16 values and a product is the 6 leading partial products, accumulated in fp32 — the
+// scheme of conv_sb.hip / gemm_sb.hip (fp32-level accuracy, 2.7x the rate of v_mfma_f32_32x32x2_f32).
+//
+// Why this layer maps well: the reduction index is k = tap * CP + channel with the channels of a pixel contiguous
+// (CP = 8 slots for the 7 FOA channels, 16 for the 10 MIC ones), so the 8 consecutive k of a bf16 A fragment are ONE
+// pixel's channel vector: a lane reads 16 B of the halo patch at (row + dy, bin + dx), no im2col and no transpose.
+// Slot CIN of every pixel holds 1.0 and carries the bias through the centre tap's weight row; the slots above it and
+// the k-steps past tap 8 meet zero weights.
+//
+// Tile, wave roles and the epilogue (window extreme zext, its position amax, BN statistics) are those of
+// conv_first_fwd_pool_kernel<CIN, false, *>: tile = 10 image rows x 64 bins, wave = pooling row (w >> 1) x 32-bin strip
+// (w & 1), 5 row tiles x 2 channel halves = 10 accumulator tiles that share the 6 weight fragments of a k-step.
+// The patch (3 bf16 planes [12][66][CP]) is single-buffered: two workgroups share a CU and cover each other's staging.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CPSB_MAX_PERSISTENT 512
+int conv_pool_sb_stat_capacity() { return CPSB_MAX_PERSISTENT; }
+
+// exact 3-way truncation split of two floats, packed as bf16 pairs (element 0 in the low half) — as conv_sb.hip
+__device__ __forceinline__ void cpsb_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+
+template <int CIN>
+struct PoolSbGeom {
+    static constexpr int CP = CIN < 8 ? 8 : 16;              // channel slots per pixel (CIN values, 1.0, zeros)
+    static constexpr int KTOT = 9 * CP;
+    static constexpr int NS = (KTOT + 15) / 16;              // k-steps of 16
+    // weight row stride in bf16: >= NS*16 and an odd number of 16-B slots, so the 16 lanes of a ds_read_b128 group
+    // (co = lane) land on 16 different slots of the 256-B bank row
+    static constexpr int KW = (((NS * 16 / 8) | 1)) * 8;
+    static constexpr int PLANE = 12 * 66 * CP;               // bf16 per patch plane
+    static constexpr int WPLANE = 64 * KW;
+    static constexpr size_t SMEM = (size_t)(3 * PLANE + 3 * WPLANE) * 2 + 512 * sizeof(float);
+};
+
+template <int CIN, bool WRITE_AMAX>
+__global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                        const float* __restrict__ bias,
+                                                                        const float* __restrict__ gamma, float* __restrict__ zext,
+                                                                        unsigned char* __restrict__ amax,
+                                                                        float* __restrict__ stat_partial, int B, int H) {
+    using G = PoolSbGeom<CIN>;
+    constexpr int CP = G::CP, NS = G::NS, KW = G::KW, PLANE = G::PLANE, WPLANE = G::WPLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short cpsb_smem[];
+    unsigned short* patch = cpsb_smem;                 // [3][12][66][CP]
+    unsigned short* Wl = patch + 3 * PLANE;            // [3][64][KW]
+    float* red = reinterpret_cast<float*>(Wl + 3 * WPLANE);   // [4][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 5, li = lane & 31;
+    const int grp = wave >> 1, strip = wave & 1;
+    // ---- weights: w [9*CIN][64] fp32 (k = tap*CIN + c) -> planes [co][tap*CP + c]; bias on (centre tap, slot CIN)
+    for (int idx = tid; idx < 3 * WPLANE / 2; idx += 256) reinterpret_cast<unsigned*>(Wl)[idx] = 0u;
+    for (int idx = tid; idx < 3 * PLANE / 2; idx += 256) reinterpret_cast<unsigned*>(patch)[idx] = 0u;   // halo columns stay zero
+    __syncthreads();
+    for (int idx = tid; idx < (9 * CIN + 1) * 64; idx += 256) {
+        const int k = idx >> 6, co = idx & 63;
+        const bool isb = k == 9 * CIN;
+        const float v = isb ? (bias ? bias[co] : 0.f) : w[idx];
+        const int kk = isb ? 4 * CP + CIN : (k / CIN) * CP + (k % CIN);
+        const unsigned u = __float_as_uint(v);
+        const float r = v - __uint_as_float(u & 0xffff0000u);
+        const unsigned vv = __float_as_uint(r);
+        const float s = r - __uint_as_float(vv & 0xffff0000u);
+        unsigned short* o = Wl + co * KW + kk;
+        o[0] = (unsigned short)(u >> 16);
+        o[WPLANE] = (unsigned short)(vv >> 16);
+        o[2 * WPLANE] = (unsigned short)(__float_as_uint(s) >> 16);
+    }
+    // gamma < 0: the window extreme that survives BN+ReLU+MaxPool is the minimum of z -> flip the sign, take the maximum
+    const unsigned smask[2] = {gamma[li] < 0.f ? 0x80000000u : 0u, gamma[32 + li] < 0.f ? 0x80000000u : 0u};
+    const int tiles_per_img = (H + 9) / 10;
+    const int ntiles = B * tiles_per_img;
+    const int HP = H / 5;
+    // ---- patch staging: 12 rows x 64 bins = 768 pixels, 3 per thread (pixel = idx: row idx >> 6, bin idx & 63)
+    float stg[3][CIN];
+#define CPSB_ISSUE(tile_)                                                                               \
+    {                                                                                                   \
+        const int ib_ = (tile_) / tiles_per_img, it0_ = ((tile_) - ib_ * tiles_per_img) * 10;           \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                 \
+            const int idx = tid + 256 * u;                                                              \
+            const int t = it0_ - 1 + (idx >> 6);                                                        \
+            const bool ok = t >= 0 && t < H;                                                            \
+            const float* p_ = ok ? x + ((size_t)(ib_ * H + t) * 64 + (idx & 63)) * CIN : x;             \
+            const unsigned keep_ = ok ? 0xffffffffu : 0u;   /* AND mask: a select on a loaded value becomes a branch */ \
+            _Pragma("unroll") for (int c = 0; c < CIN; ++c) stg[u][c] = __uint_as_float(__float_as_uint(p_[c]) & keep_); \
+        }                                                                                               \
+    }
+#define CPSB_SLOT(u_, c_) ((c_) < CIN ? stg[u_][(c_) < CIN ? (c_) : 0] : ((c_) == CIN ? 1.f : 0.f))
+#define CPSB_COMMIT()                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                     \
+        const int idx = tid + 256 * u;                                                                  \
+        unsigned short* d_ = patch + (((idx >> 6) * 66 + (idx & 63) + 1) * CP);                         \
+        _Pragma("unroll") for (int q = 0; q < CP / 8; ++q) {                                            \
+            unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_, l0_, l1_, l2_, l3_;                        \
+            cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 0), CPSB_SLOT(u, 8 * q + 1), h0_, m0_, l0_);          \
+            cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 2), CPSB_SLOT(u, 8 * q + 3), h1_, m1_, l1_);          \
+            cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 4), CPSB_SLOT(u, 8 * q + 5), h2_, m2_, l2_);          \
+            cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 6), CPSB_SLOT(u, 8 * q + 7), h3_, m3_, l3_);          \
+            const u32x4 hv_ = {h0_, h1_, h2_, h3_}, mv_ = {m0_, m1_, m2_, m3_}, lv_ = {l0_, l1_, l2_, l3_}; \
+            *reinterpret_cast<u32x4*>(d_ + 8 * q) = hv_;                                                \
+            *reinterpret_cast<u32x4*>(d_ + PLANE + 8 * q) = mv_;                                        \
+            *reinterpret_cast<u32x4*>(d_ + 2 * PLANE + 8 * q) = lv_;                                    \
+        }                                                                                               \
+    }
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        CPSB_ISSUE(tile)
+        CPSB_COMMIT()
+    }
+    __syncthreads();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // A fragment of k-step s: lane (li, kg) reads the 8 slots [c0, c0 + 8) of pixel (row + dy, bin + dx) with
+    // k0 = 16 s + 8 kg, tap = min(k0 / CP, 8) (past tap 8 the weights are zero: any finite pixel will do), c0 = k0 % CP
+#define CPSB_TAP(s_, g_) ((16 * (s_) + 8 * (g_)) / CP > 8 ? 8 : (16 * (s_) + 8 * (g_)) / CP)
+#define CPSB_AOFF(s_, g_) (((CPSB_TAP(s_, g_) / 3) * 66 + (CPSB_TAP(s_, g_) % 3)) * CP + ((16 * (s_) + 8 * (g_)) / CP > 8 ? 0 : (16 * (s_) + 8 * (g_)) % CP))
+    const unsigned short* pbase = patch + ((5 * grp) * 66 + 32 * strip + li) * CP;
+    const unsigned short* wbase = Wl + li * KW + 8 * kg;
+    const int lane_e = kg * 64 + li;
+#define CPSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+#define CPSB_ROW(j_, ACCA_, ACCB_)                                                                      \
+    {                                                                                                   \
+        const unsigned short* ap_ = pa + (j_) * 66 * CP;                                                \
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), am = *reinterpret_cast<const bf16x8*>(ap_ + PLANE),   \
+                     al = *reinterpret_cast<const bf16x8*>(ap_ + 2 * PLANE);                            \
+        CPSB_MFMA(ah, bh0, ACCA_); CPSB_MFMA(ah, bh1, ACCB_); CPSB_MFMA(ah, bm0, ACCA_); CPSB_MFMA(ah, bm1, ACCB_);   \
+        CPSB_MFMA(am, bh0, ACCA_); CPSB_MFMA(am, bh1, ACCB_); CPSB_MFMA(ah, bl0, ACCA_); CPSB_MFMA(ah, bl1, ACCB_);   \
+        CPSB_MFMA(al, bh0, ACCA_); CPSB_MFMA(al, bh1, ACCB_); CPSB_MFMA(am, bm0, ACCA_); CPSB_MFMA(am, bm1, ACCB_);   \
+    }
+    // window reduction of one accumulator register of one channel half: conv_pool.hip's CP_DRAIN without the z store
+#define CPSB_DRAIN(r_, c_, Y0, Y1, Y2, Y3, Y4)                                                          \
+    {                                                                                                   \
+        const float v0 = Y0[r_], v1 = Y1[r_], v2 = Y2[r_], v3 = Y3[r_], v4 = Y4[r_];                    \
+        s1[c_] += (v0 + v1) + (v2 + v3) + v4;                                                           \
+        s2[c_] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, fmaf(v4, v4, s2[c_])))));          \
+        const float w0 = __uint_as_float(__float_as_uint(v0) ^ smask[c_]), w1 = __uint_as_float(__float_as_uint(v1) ^ smask[c_]); \
+        const float w2 = __uint_as_float(__float_as_uint(v2) ^ smask[c_]), w3 = __uint_as_float(__float_as_uint(v3) ^ smask[c_]); \
+        const float w4 = __uint_as_float(__float_as_uint(v4) ^ smask[c_]);                              \
+        const float hi5 = fmaxf(fmaxf(fmaxf(w0, w1), fmaxf(w2, w3)), w4);                               \
+        const bool take_ = ((r_) & 3) == 0 || hi5 > best;     /* strict: the first extreme in scan order wins ties */ \
+        if (WRITE_AMAX) {    /* training: remember WHERE the extreme is: position row * 4 + column of the window */ \
+            int row_ = 4;                                                                               \
+            row_ = (w3 == hi5) ? 3 : row_; row_ = (w2 == hi5) ? 2 : row_;                               \
+            row_ = (w1 == hi5) ? 1 : row_; row_ = (w0 == hi5) ? 0 : row_;                               \
+            bpos = take_ ? row_ * 4 + ((r_) & 3) : bpos;                                                \
+        }                                                                                               \
+        best = take_ ? hi5 : best;                                                                      \
+        if (((r_) & 3) == 3) {                                                                          \
+            (zext + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = __uint_as_float(__float_as_uint(best) ^ smask[c_]); \
+            if (WRITE_AMAX) (amax + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = (unsigned char)bpos; \
+        }                                                                                               \
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 10;
+        const int nxt = tile + gridDim.x;
+        CPSB_ISSUE(nxt < ntiles ? nxt : tile)
+        __builtin_amdgcn_sched_barrier(0);
+        const int tg = t0 + 5 * grp;             // first image row of this wave's pooling row
+        const bool live = tg < H;                // H % 5 == 0: a pooling row is entirely inside or outside
+        const size_t er = ((size_t)(b * HP + tg / 5) * 16 + 8 * strip) * 64;
+        float best = 0.f;
+        int bpos = 0;
+        f32x16 accA0 = zero16(), accA1 = zero16(), accA2 = zero16(), accA3 = zero16(), accA4 = zero16();
+        f32x16 accB0 = zero16(), accB1 = zero16(), accB2 = zero16(), accB3 = zero16(), accB4 = zero16();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned short* pa = pbase + (kg ? CPSB_AOFF(s, 1) : CPSB_AOFF(s, 0));
+            const unsigned short* wp = wbase + 16 * s;
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(wp), bh1 = *reinterpret_cast<const bf16x8*>(wp + 32 * KW);
+            const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(wp + WPLANE), bm1 = *reinterpret_cast<const bf16x8*>(wp + WPLANE + 32 * KW);
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE), bl1 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE + 32 * KW);
+            CPSB_ROW(0, accA0, accB0)
+            CPSB_ROW(1, accA1, accB1)
+            CPSB_ROW(2, accA2, accB2)
+            CPSB_ROW(3, accA3, accB3)
+            CPSB_ROW(4, accA4, accB4)
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) CPSB_DRAIN(r, 0, accA0, accA1, accA2, accA3, accA4)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) CPSB_DRAIN(r, 1, accB0, accB1, accB2, accB3, accB4)
+        }
+        // single patch buffer: everyone is done reading it, then the prefetched tile replaces it
+        lds_barrier();
+        CPSB_COMMIT()
+        lds_barrier();
+    }
+#undef CPSB_DRAIN
+#undef CPSB_ROW
+#undef CPSB_MFMA
+#undef CPSB_AOFF
+#undef CPSB_TAP
+#undef CPSB_ISSUE
+#undef CPSB_COMMIT
+#undef CPSB_SLOT
+    if (stat_partial) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (kg == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+    }
+}
+
+template <int CIN>
+static int launch_cpsb(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma, float* zext,
+                       unsigned char* amax, float* stat_partial, int* n_partial, int B, int H) {
+    using G = PoolSbGeom<CIN>;
+    const int ntiles = B * ((H + 9) / 10);
+    const int grid = ntiles < CPSB_MAX_PERSISTENT ? ntiles : CPSB_MAX_PERSISTENT;
+#define CPSB_GO(A_)                                                                                                  \
+    {                                                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_sb_kernel<CIN, A_>),                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);                               \
+        hipLaunchKernelGGL((conv_first_fwd_pool_sb_kernel<CIN, A_>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
+                           gamma, zext, amax, stat_partial, B, H);                                                   \
+    }
+    if (amax) CPSB_GO(true)
+    else CPSB_GO(false)
+#undef CPSB_GO
+    if (n_partial) *n_partial = grid;
+    return 0;
+}
+
+// same contract as launch_conv_first_fwd_pool with z == nullptr (conv_pool.hip)
+int launch_conv_first_fwd_pool_sb(hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
+                                  float* zext, unsigned char* amax, float* stat_partial, int* n_partial, int B, int H, int Cin) {
+    if (H % 5 || H <= 0 || B <= 0) return -2;
+    if (Cin == 7) return launch_cpsb<7>(st, x, w, bias, gamma, zext, amax, stat_partial, n_partial, B, H);
+    if (Cin == 10) return launch_cpsb<10>(st, x, w, bias, gamma, zext, amax, stat_partial, n_partial, B, H);
+    return -2;
+}

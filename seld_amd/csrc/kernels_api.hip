@@ -9,6 +9,7 @@
 
 namespace {
 int g_conv64_split_bf16 = 1;
+int g_conv1_split_bf16 = 1;
 struct Scratch {
     std::vector<void*> p;
     float* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, n * sizeof(float) + 256) != hipSuccess) return nullptr; p.push_back(q); return (float*)q; }
@@ -31,6 +32,7 @@ extern "C" {
 int seld_k_set_option(const char* key, int value) {
     if (!key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv1_split_bf16")) { g_conv1_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
     return SELD_ERR_INVALID;
 }
@@ -62,7 +64,7 @@ int seld_k_conv_first_fwd_pool(const float* x, const float* w, const float* bias
     float* part = stats ? s.get((size_t)conv_pool_stat_capacity() * 128) : nullptr;
     if (stats && !part) return SELD_ERR_NOMEM;
     int np = 0;
-    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, z, zext, amax, part, &np, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, z, zext, amax, part, &np, B, H, Cin, g_conv1_split_bf16)) return SELD_ERR_UNSUPPORTED;
     if (stats) launch_reduce_slabs(0, part, np, 128, stats, 128, 0);
     return done();
 }
@@ -174,7 +176,7 @@ int seld_k_conv1_train_gram(const float* x, const float* w, const float* bias, c
     hipMemsetAsync(mov, 0, 128 * sizeof(float), 0);
     int npart = 0, nb = 0, ns = 0;
     // forward without z: window extremes + positions + statistics; then BN coefficients and the pooled activation
-    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, nullptr, zext, amax, part, &npart, B, H, Cin)) return SELD_ERR_UNSUPPORTED;
+    if (launch_conv_first_fwd_pool(0, x, w, bias, gamma, nullptr, zext, amax, part, &npart, B, H, Cin, g_conv1_split_bf16)) return SELD_ERR_UNSUPPORTED;
     launch_bn_finalize(0, part, npart, (double)B * H * W, gamma, beta, mov, mov + 64, coef, coef + 64, coef + 128, coef + 192, C, 1);
     launch_bn_relu_ext(0, zext, coef + 128, coef + 192, p, (int64_t)np);
     // backward: BN sums from the pooled tensors, then dW = ka (G W + g b) + g kb + M

@@ -124,7 +124,7 @@ class SeldNet:
             _lib.check(self.lib.seld_set_state_host(self.ctx, s.ctypes.data, s.size), self.ctx)
 
     def set_option(self, key: str, value: int) -> None:
-        """Kernel-selection knobs of the C library (`seld_set_option`): "conv64_split_bf16", "gemm_split_bf16",
+        """Kernel-selection knobs of the C library (`seld_set_option`): "conv64_split_bf16", "gemm_split_bf16", "conv1_split_bf16",
         "conv1_pool_fused", "conv1_gram"."""
         _lib.check(self.lib.seld_set_option(self.ctx, key.encode(), int(value)), self.ctx)
 

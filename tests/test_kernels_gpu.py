@@ -107,11 +107,35 @@ def test_conv_first_fwd_pool(seld_lib, B, H, Cin):
     ze2 = torch.full_like(ze, float("nan"))
     am2 = torch.full_like(am, 255)
     assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), ptr(z), ptr(ze2), None, None, B, H, Cin) != 0
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am2), None, B, H, Cin) == 0
-    assert torch.equal(ze, ze2) and torch.equal(am, am2)
-    ze2.fill_(float("nan"))
-    assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, None, B, H, Cin) == 0
-    assert torch.equal(ze, ze2)
+    # ... on the f32-input MFMA path: the same bits as the z-storing kernel
+    assert seld_lib.seld_k_set_option(b"conv1_split_bf16", 0) == 0
+    try:
+        assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am2), None, B, H, Cin) == 0
+        assert torch.equal(ze, ze2) and torch.equal(am, am2)
+        ze2.fill_(float("nan"))
+        assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), None, None, B, H, Cin) == 0
+        assert torch.equal(ze, ze2)
+    finally:
+        seld_lib.seld_k_set_option(b"conv1_split_bf16", 1)
+    # ... on the default split-bf16 path (conv_pool_sb.hip): fp32-level values, so the window extreme is compared with
+    # the float64 reference's, and the recorded position must hold a value within rounding of that extreme
+    st2 = torch.zeros(128, device="cuda")
+    for with_amax in (True, False):
+        ze2.fill_(float("nan")); am2.fill_(255)
+        assert seld_lib.seld_k_conv_first_fwd_pool(ptr(xd), ptr(wd), ptr(bd), ptr(gd), None, ptr(ze2), ptr(am2) if with_amax else None,
+                                                   ptr(st2), B, H, Cin) == 0
+        rwin = ref.reshape(B, H // 5, 5, 16, 4, 64)
+        rwant = np.where(gamma < 0, rwin.min(axis=(2, 4)), rwin.max(axis=(2, 4)))
+        check(f"conv_first_fwd_pool(split-bf16) zext {B,H,Cin}", ze2.cpu().numpy(), rwant, tol=2e-6)
+        s2_ = st2.cpu().numpy()
+        check("conv_first_fwd_pool(split-bf16) sum(z)", s2_[:64], ref.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref.size / 64))
+        check("conv_first_fwd_pool(split-bf16) sum(z^2)", s2_[64:], (ref ** 2).sum(axis=(0, 1, 2)))
+        if with_amax:
+            rflat = np.where(gamma < 0, -rwin, rwin).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 5, 16, 64, 20)
+            at = np.take_along_axis(rflat, am2.cpu().numpy().astype(np.int64)[..., None], axis=-1)[..., 0]
+            assert am2.max().item() < 20
+            assert np.abs(at - rflat.max(-1)).max() <= 2e-6 * np.abs(ref).max()
+            assert (am2 == am).float().mean().item() > 0.999     # near-ties aside, the same positions as the fp32 kernel
     # pooled activation: elementwise over zext == BN+ReLU+MaxPool over z, bit for bit
     mean, var = zh.mean(axis=(0, 1, 2), dtype=np.float64), zh.var(axis=(0, 1, 2), dtype=np.float64)
     scale = (gamma / np.sqrt(var + 1e-3)).astype(np.float32)
