@@ -739,7 +739,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
             {
                 PROF2(c, tn);
-                if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
+                if (c->conv64_split_bf16 && conv64_wgrad_sb_usable(L.W)) {
+                    if (launch_conv64_wgrad_sb(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
+                        return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad_sb");
+                } else if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
             }
             launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);

@@ -99,7 +99,9 @@ int seld_k_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, 
     if (!slab || !tmp) return SELD_ERR_NOMEM;
     int ns = 0;
     if (Cin == 64) {
-        if (launch_conv64_wgrad(0, x, dz, slab, &ns, B, H, W)) return SELD_ERR_UNSUPPORTED;
+        if (g_conv64_split_bf16 && conv64_wgrad_sb_usable(W)) {
+            if (launch_conv64_wgrad_sb(0, x, dz, slab, &ns, B, H, W)) return SELD_ERR_UNSUPPORTED;
+        } else if (launch_conv64_wgrad(0, x, dz, slab, &ns, B, H, W)) return SELD_ERR_UNSUPPORTED;
         launch_reduce_slabs(0, slab, ns, 9 * 4096 + 64, tmp, 9 * 4096 + 64, 0);
         hipMemcpyAsync(dw, tmp, 9 * 4096 * 4, hipMemcpyDeviceToDevice, 0);
         hipMemcpyAsync(db, tmp + 9 * 4096, 64 * 4, hipMemcpyDeviceToDevice, 0);

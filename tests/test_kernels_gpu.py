@@ -57,7 +57,8 @@ def test_conv_dgrad(seld_lib, B, H, W):
     seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
 
 
-@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64),
+                                       (1, 3, 4, 64), (2, 33, 4, 64), (4, 600, 16, 64), (4, 600, 4, 64)])
 def test_conv_wgrad(seld_lib, B, H, W, Cin):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -69,9 +70,16 @@ def test_conv_wgrad(seld_lib, B, H, W, Cin):
     dw = torch.full((3, 3, Cin, 64), float("nan"), device="cuda")
     db = torch.full((64,), float("nan"), device="cuda")
     xd, dzd = dev(x), dev(dz)
-    assert seld_lib.seld_k_conv3x3_wgrad(ptr(xd), ptr(dzd), ptr(dw), ptr(db), B, H, W, Cin, 64) == 0
-    check(f"conv_wgrad dw {B,H,W,Cin}", dw.cpu().numpy(), gw.numpy())
-    check(f"conv_wgrad db {B,H,W,Cin}", db.cpu().numpy(), gb.numpy())
+    # 64 -> 64: split-bf16 with transposed LDS reads (conv_wgrad_sb.hip, default) and the f32-input MFMA kernel
+    for mode in ((1, 0) if Cin == 64 else (1,)):
+        dw.fill_(float("nan")); db.fill_(float("nan"))
+        assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
+        try:
+            assert seld_lib.seld_k_conv3x3_wgrad(ptr(xd), ptr(dzd), ptr(dw), ptr(db), B, H, W, Cin, 64) == 0
+        finally:
+            seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
+        check(f"conv_wgrad dw {B,H,W,Cin} mode{mode}", dw.cpu().numpy(), gw.numpy())
+        check(f"conv_wgrad db {B,H,W,Cin} mode{mode}", db.cpu().numpy(), gb.numpy())
 
 
 @pytest.mark.parametrize("B,H,Cin", [(2, 50, 7), (1, 5, 7), (3, 35, 7), (2, 30, 10), (20, 300, 7)])
