@@ -28,6 +28,12 @@ from __graft_entry__ import SELDNET_CONFIG
 
 METRIC = "train-step clips/sec (7ch×3000×64) seldnet.json at 1/2/4/8 MI355X"
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
+# fp32 products computed as 6 bf16 MFMA products of exactly split operands (conv_sb / conv_pool_sb / conv_wgrad_sb /
+# gemm_sb): the ceiling for the fp32-equivalent FLOP count is a sixth of the bf16 peak
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
+SPLIT_BF16_GROUPS = {"conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "conv3_fwd", "conv3_dgrad", "conv3_wgrad",
+                     "gru_inproj_gemm", "gru_bwd_gemms"}   # with the default options (seld_set_option)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -184,13 +190,18 @@ def main():
                 return None
             bound, amount = work
             avg_s = ms / n / 1e3
+            path = None
             if bound == "mfma":
-                ach, peak, unit = amount / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+                split = name in SPLIT_BF16_GROUPS and not args.opt
+                ach, unit = amount / avg_s / 1e12, "TFLOP/s"
+                peak = round(PEAK_SPLIT_BF16_TFLOPS, 1) if split else PEAK_F32_MFMA_TFLOPS
+                path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
             else:
                 ach, peak, unit = amount / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s"
             return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name, {}).get("hbm_bytes_per_launch"),
-                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": n // args.steps}
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": n // args.steps,
+                    **({"mfma_path": path} if path else {})}
 
         if kernels:
             for name, n, ms in kernels:

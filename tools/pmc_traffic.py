@@ -8,12 +8,15 @@ import sys
 from collections import defaultdict
 
 GROUPS = {  # bench.py timer group -> kernel-name substring
-    "conv1_fwd": "conv_first_fwd_pool_kernel", "conv1_wgrad": "conv_first_msparse_kernel", "conv1_gram": "conv_first_gram_kernel",
+    "conv1_fwd": "conv_first_fwd_pool_sb_kernel", "conv1_fwd_f32": "conv_first_fwd_pool_kernel",
+    "conv1_wgrad": "conv_first_msparse_kernel", "conv1_gram": "conv_first_gram_kernel",
     "conv1_wgrad_fused": "conv_first_wgrad_fused_kernel",
     "gru_fwd": "gru_fwd_kernel", "gru_bwd": "gru_bwd_kernel",
     "conv64_fwd_dgrad_W16": "conv64_fwd_sbr_kernel<4", "conv64_fwd_dgrad_W4": "conv64_fwd_sbr_kernel<2",
-    "conv2_wgrad": "conv64_wgrad_kernel<4>", "conv3_wgrad": "conv64_wgrad_kernel<2>",
+    "conv2_wgrad": "conv64_wgrad_sb_kernel<4>", "conv3_wgrad": "conv64_wgrad_sb_kernel<2>",
+    "conv2_wgrad_f32": "conv64_wgrad_kernel<4>", "conv3_wgrad_f32": "conv64_wgrad_kernel<2>",
     "pool1_fwd": "bn_relu_ext_kernel", "gemm": "gemm_f32_kernel", "gemm_tn": "gemm_tn_kernel",
+    "gemm_sb_4wave": "gemm_sb_kernel", "gemm_sb_16wave": "gemm_sb16_kernel",
 }
 
 
