@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseld_hip.so")
+# SELD_HIP_LIB: another build of the same library (A/B timing of two builds on one box, tools/); still a HIP build of csrc/
+LIB_PATH = os.environ.get("SELD_HIP_LIB") or os.path.join(_HERE, "libseld_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SELD_OK = 0

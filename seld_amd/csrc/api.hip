@@ -56,7 +56,8 @@ struct seld_ctx {
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
-    unsigned short* wsplit = nullptr;      // [9][3][64][64] bf16 planes of the current conv64 weights (split-bf16 mode)
+    unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
+    unsigned short *wsp_fwd[SELD_MAX_LAYERS] = {}, *wsp_bwd[SELD_MAX_LAYERS] = {};
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
     bool gram_active = false;              // the last training forward took that path
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
@@ -268,7 +269,11 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
-    ALLOC(c->wsplit, 9 * 3 * 4096);
+    ALLOC(c->wsplit, (size_t)2 * c->conv.size() * 9 * 3 * 4096);
+    for (size_t i = 0; i < c->conv.size(); ++i) {
+        c->wsp_fwd[i] = c->wsplit + (2 * i) * 9 * 3 * 4096;
+        c->wsp_bwd[i] = c->wsplit + (2 * i + 1) * 9 * 3 * 4096;
+    }
     const size_t rows = (size_t)B * S;
     for (int i = 0; i < a->n_gru; ++i) {
         GruL& G = c->gru[i];
@@ -450,6 +455,16 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     const int B = c->B, S = c->S;
     const int rows = B * S;
     if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
+    if (c->conv64_split_bf16) {   // 64 -> 64 conv weights: forward planes and (when a backward follows) the flipped ones, one launch
+        const float* w[8]; unsigned short* dst[8]; int flip[8];
+        int n = 0;
+        for (size_t i = 1; i < c->conv.size(); ++i) {
+            if (n + 2 > 8) { launch_split_weights_batch(st, n, w, dst, flip); n = 0; }
+            w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_fwd[i]; flip[n++] = 0;
+            if (save) { w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_bwd[i]; flip[n++] = 1; }
+        }
+        if (n && launch_split_weights_batch(st, n, w, dst, flip)) return fail(c, SELD_ERR_UNSUPPORTED, "split_weights");
+    }
     const float* in = x;
     for (size_t i = 0; i < c->conv.size(); ++i) {
         ConvL& L = c->conv[i];
@@ -477,8 +492,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         } else {
             PROF2(c, tn);
             if (c->conv64_split_bf16) {
-                launch_split_weights(st, c->params + L.w_off, c->wsplit);
-                if (launch_conv64_fwd_sb(st, in, c->wsplit, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
+                if (launch_conv64_fwd_sb(st, in, c->wsp_fwd[i], c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd_sb");
             } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
@@ -746,15 +760,15 @@ static int backward_impl(seld_ctx* c, const float* x) {
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
             }
             launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
-            launch_flip_weights(st, c->params + L.w_off, c->wflip);
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
                 PROF2(c, tn);
-                if (c->conv64_split_bf16) {
-                    launch_split_weights(st, c->wflip, c->wsplit);
-                    launch_conv64_fwd_sb(st, c->dzbuf, c->wsplit, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
-                } else
+                if (c->conv64_split_bf16) {   // flipped + split planes were made by the forward's weight pre-pass
+                    launch_conv64_fwd_sb(st, c->dzbuf, c->wsp_bwd[i], nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+                } else {
+                    launch_flip_weights(st, c->params + L.w_off, c->wflip);
                     launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+                }
             }
             dp = c->conv[i - 1].dp;
         }

@@ -69,6 +69,8 @@ int conv_first_wgrad_slab_stride(int Cin);   // floats per first-layer wgrad sla
 int launch_flip_weights(hipStream_t st, const float* w, float* wt);
 // split-bf16 conv (conv_sb.hip): w [9][in][out] fp32 -> planes [9][3][out][in] bf16; conv with 6 bf16 MFMAs per product
 int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp);
+// up to 8 tensors in one launch; flip[i] != 0: the planes of the flipped (input-gradient) weights, from the unflipped tensor
+int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, unsigned short* const* dst, const int* flip);
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights

@@ -54,22 +54,34 @@ int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scrat
     return 0;
 }
 
+// sum over the 4 lanes of a quad (DPP quad_perm moves; every lane gets the sum)
+__device__ __forceinline__ float loss_quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+    return v;
+}
+
+// Four threads per row (q = tid & 3 takes the columns q, q + 4, ...: a quad reads 16 contiguous bytes), 64 rows per block.
+// Per block the two loss sums are reduced in a fixed order (quad -> row order in LDS, double) into blockpart[block][2];
+// losses_finalize adds those in block order: two runs give the same bits.
 __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
                                                      const float* __restrict__ y_sed, const float* __restrict__ y_doa,
                                                      int doa_loss, float coef_sed, float w_doa,
                                                      const float* __restrict__ den_dev, float* __restrict__ dloss_rows,
                                                      float* __restrict__ dsed_pre, float* __restrict__ ddoa_pre,
-                                                     float* __restrict__ rowpart, int rows, int nc) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
+                                                     double* __restrict__ blockpart, int rows, int nc) {
+    __shared__ float rs[64][2];
+    const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int r = min(blockIdx.x * 64 + rl, rows - 1);       // rows past the end recompute the last row and store nothing
+    const bool live = blockIdx.x * 64 + rl < rows;
     const float* p = sed + (size_t)r * nc;
     const float* ys = y_sed + (size_t)r * nc;
     float bsum = 0.f;
-    for (int c = 0; c < nc; ++c) {
+    for (int c = q; c < nc; c += 4) {
         const float pv = p[c], y = ys[c];
         const float pc = fminf(fmaxf(pv, BCE_EPS), 1.f - BCE_EPS);
         bsum += -(y * logf(pc + BCE_EPS) + (1.f - y) * logf(1.f - pc + BCE_EPS));
-        if (dsed_pre) {
+        if (dsed_pre && live) {
             const bool pass = (pv >= BCE_EPS) && (pv <= 1.f - BCE_EPS);
             const float dldp = pass ? -(y / (pc + BCE_EPS) - (1.f - y) / (1.f - pc + BCE_EPS)) : 0.f;
             dsed_pre[(size_t)r * nc + c] = coef_sed * dldp * pv * (1.f - pv);
@@ -80,35 +92,44 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
     float dsum = 0.f;
     if (doa_loss == 0) {
         const float inv = 1.f / (float)(3 * nc);
-        for (int k = 0; k < 3 * nc; ++k) {
+        for (int k = q; k < 3 * nc; k += 4) {
             const float e = yd[k] - d[k];
             dsum += e * e;
-            if (ddoa_pre) ddoa_pre[(size_t)r * 3 * nc + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
+            if (ddoa_pre && live) ddoa_pre[(size_t)r * 3 * nc + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
         }
-        dsum *= inv;
-        if (dloss_rows) dloss_rows[r] = dsum;
+        dsum = loss_quad_sum(dsum) * inv;
+        if (dloss_rows && live && q == 0) dloss_rows[r] = dsum;
     } else {
         const float den = den_dev[0];
-        for (int c = 0; c < nc; ++c) {
+        for (int c = q; c < nc; c += 4) {
             const float a = yd[c], b = yd[nc + c], e3 = yd[2 * nc + c];
             const float m = rintf(a * a + b * b + e3 * e3);
             for (int k = 0; k < 3; ++k) {
                 const int i = k * nc + c;
                 const float e = yd[i] - d[i];
                 dsum += e * e * m;
-                if (ddoa_pre) ddoa_pre[(size_t)r * 3 * nc + i] = w_doa * (-2.f * e * m / den) * (1.f - d[i] * d[i]);
+                if (ddoa_pre && live) ddoa_pre[(size_t)r * 3 * nc + i] = w_doa * (-2.f * e * m / den) * (1.f - d[i] * d[i]);
             }
         }
+        dsum = loss_quad_sum(dsum);
     }
-    rowpart[(size_t)r * 2 + 0] = bsum;
-    rowpart[(size_t)r * 2 + 1] = dsum;
+    bsum = loss_quad_sum(bsum);
+    if (q == 0) { rs[rl][0] = live ? bsum : 0.f; rs[rl][1] = live ? dsum : 0.f; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int i = 0; i < 64; ++i) s += (double)rs[i][threadIdx.x];
+        blockpart[(size_t)blockIdx.x * 2 + threadIdx.x] = s;
+    }
 }
 
-__global__ void losses_finalize_kernel(const double* __restrict__ sums, int doa_loss, double n_sed,
+__global__ void losses_finalize_kernel(const double* __restrict__ blockpart, int nblocks, int doa_loss, double n_sed,
                                        const float* __restrict__ den_dev, float* __restrict__ sloss,
                                        float* __restrict__ dloss) {
-    if (sloss) sloss[0] = (float)(sums[0] / n_sed);
-    if (doa_loss == 1 && dloss) dloss[0] = (float)(sums[1] / (double)den_dev[0]);
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = 0; i < nblocks; ++i) { s0 += blockpart[2 * i]; s1 += blockpart[2 * i + 1]; }
+    if (sloss) sloss[0] = (float)(s0 / n_sed);
+    if (doa_loss == 1 && dloss) dloss[0] = (float)(s1 / (double)den_dev[0]);
 }
 
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
@@ -118,12 +139,12 @@ int launch_losses(hipStream_t st, const float* sed, const float* doa, const floa
     // BCE is a mean over rows*nc elements.  With the Keras MSE *function* the per-row loss tensor
     // sloss*w0 + mse[b,s]*w1 is summed by tape.gradient, which multiplies the BCE term by rows.
     const float coef_sed = w_sed * sed_grad_scale * (doa_loss == 0 ? (float)rows : 1.f) / ((float)rows * (float)nc);
-    double* sums = reinterpret_cast<double*>(scratch + (size_t)rows * 2);
-    hipLaunchKernelGGL(losses_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss,
-                       coef_sed, w_doa, den_dev, doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, scratch, rows, nc);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, st, scratch, rows, 2, sums);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(1), 0, st, sums, doa_loss, (double)rows * nc, den_dev, sloss,
-                       dloss);
+    double* blockpart = reinterpret_cast<double*>(scratch);      // [nblocks][2]: rows / 32 doubles of the 2 * rows floats
+    const int nblocks = (rows + 63) / 64;
+    hipLaunchKernelGGL(losses_kernel, dim3(nblocks), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss, coef_sed, w_doa, den_dev,
+                       doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(1), 0, st, blockpart, nblocks, doa_loss, (double)rows * nc, den_dev,
+                       sloss, dloss);
     return 0;
 }
 
