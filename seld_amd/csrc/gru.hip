@@ -196,6 +196,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const int cp = lane & 15;                       // column part of the mat-vec
     const int j0 = 4 * (4 * wave + (lane >> 4));    // first of this lane's 4 outputs
     const int jm = j0 + (cp & 3), qr = cp >> 2;     // unit / role (z, r, h, -) of this lane in the gate stage
+    const bool b0 = cp & 1, b1 = cp & 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* stage = smem;                          // [2][GRUB_CH][GRUB_ROW]
     float* gl = smem + 2 * GRUB_CH * GRUB_ROW;    // [2][GRUB_GL]
@@ -303,13 +304,18 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                     s2[a] = pk_fma(g23, ut[a][2 * c4 + 1], s2[a]);
                 }
             }
-            float s[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) s[a] = s2[a].x + s2[a].y;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) s[a] = row16_allsum(s[a]);
-            const int sel = cp & 3;
-            const float mine = sel == 0 ? s[0] : (sel == 1 ? s[1] : (sel == 2 ? s[2] : s[3]));
+            // 4 partial sums x 16 lanes -> lane cp keeps the total of output cp & 3.  Fold instead of four all-reduces: with
+            // its xor-1 neighbour a lane trades the two outputs of the other parity (2 adds), with its xor-2 neighbour the
+            // remaining foreign one (1 add), then the quads of the row are summed (2 adds): 5 cross-lane adds + 6 selects
+            // where four 16-lane all-reduces took 16 + the final select chain.
+            const float s0 = s2[0].x + s2[0].y, s1 = s2[1].x + s2[1].y, s2_ = s2[2].x + s2[2].y, s3 = s2[3].x + s2[3].y;
+            const float k1 = b0 ? s1 : s0, g1 = b0 ? s0 : s1, k2 = b0 ? s3 : s2_, g2 = b0 ? s2_ : s3;
+            const float a01 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g1), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+            const float a23 = k2 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g2), 0xB1, 0xF, 0xF, true));
+            const float kk = b1 ? a23 : a01, gg = b1 ? a01 : a23;
+            float mine = kk + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gg), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+            mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
+            mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
             carry = dh * c_zs + mine;
             ++step;
         };
