@@ -561,20 +561,16 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         for (int hd = 0; hd < 2; ++hd) {
             const float* a = feat;
             Head& Hd = c->heads[hd];
+            float* outp = hd == 0 ? sed : doa;
             for (size_t j = 0; j < Hd.layers.size(); ++j) {
                 DenseL& D = Hd.layers[j];
                 const bool lastl = (j + 1 == Hd.layers.size());
                 float* y = D.y;
+                // the head's output layer also writes the caller's copy (no device-to-device copy afterwards)
                 if (!(merged0 && j == 0))
-                    launch_gemm(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, D.out, rows, D.out, D.in, 0,
-                                lastl ? Hd.act : 0, 0);
+                    launch_gemm_mirror(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, lastl ? outp : nullptr, D.out,
+                                       rows, D.out, D.in, 0, lastl ? Hd.act : 0);
                 a = y;
-            }
-            float* outp = hd == 0 ? sed : doa;
-            if (outp) {
-                DenseL& D = Hd.layers.back();
-                if (hipMemcpyAsync(outp, D.y, (size_t)rows * D.out * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-                    return fail(c, SELD_ERR_HIP, "output copy failed");
             }
         }
     }

@@ -98,6 +98,8 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ld
                 int ldc, int M, int N, int K, int transb, int act, int accumulate);
 int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0, const float* B1, int ldb, const float* bias0,
                        const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int transb, int act);
+int launch_gemm_mirror(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, float* mirror,
+                       int ldc, int M, int N, int K, int transb, int act);
 int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda, const float* B0, const float* B1, int ldb,
                        const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate);
 // split-bf16 GEMM (gemm_sb.hip): weights pre-split into bf16 planes by launch_gemm_split_b (up to 16 operands per launch),

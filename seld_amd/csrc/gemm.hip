@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias1, float* __restrict__ C1, int mode) {
     // mode 0: C = act(A B + bias) (+C).   mode 1 (two products sharing A): column tiles >= ceil(N/64) compute
     // C1 = act(A B1 + bias1).   mode 2 (one product over a concatenated K): C = act(A B + A1 B1 + bias) (+C), K % 32 == 0.
+    // mode 3: mode 0, and the result is also stored to C1 (same leading dimension): the caller's copy of a head output.
     const int ntx = (N + 63) >> 6;
     const bool second = mode == 1 && (int)blockIdx.x >= ntx;
     if (second) { Bm = B1; bias = bias1; C = C1; }
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 float* p = C + (size_t)row * ldc + col;
                 if (accumulate) v += *p;
                 *p = v;
+                if (mode == 3) C1[(size_t)row * ldc + col] = v;
             }
         }
     }
@@ -172,6 +174,12 @@ static int gemm_go(hipStream_t st, const float* A, int lda, const float* Bm, int
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
                 int ldc, int M, int N, int K, int transb, int act, int accumulate) {
     return gemm_go(st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, transb, act, accumulate, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+// C = act(A B + bias), also stored to `mirror` (same ldc) when it is not null
+int launch_gemm_mirror(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, float* mirror,
+                       int ldc, int M, int N, int K, int transb, int act) {
+    return gemm_go(st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, transb, act, 0, nullptr, nullptr, nullptr, mirror, mirror ? 3 : 0);
 }
 
 // two products that share A in one launch: C0 = act(A B0 + bias0), C1 = act(A B1 + bias1) (same shapes and leading dimensions)

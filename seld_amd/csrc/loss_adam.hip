@@ -123,11 +123,15 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
     }
 }
 
-__global__ void losses_finalize_kernel(const double* __restrict__ blockpart, int nblocks, int doa_loss, double n_sed,
-                                       const float* __restrict__ den_dev, float* __restrict__ sloss,
-                                       float* __restrict__ dloss) {
+// one wave: lane l adds the partials l, l + 64, ... in order, then a fixed xor tree over the lanes (same bits every run)
+__global__ __launch_bounds__(64) void losses_finalize_kernel(const double* __restrict__ blockpart, int nblocks, int doa_loss, double n_sed,
+                                                             const float* __restrict__ den_dev, float* __restrict__ sloss,
+                                                             float* __restrict__ dloss) {
     double s0 = 0.0, s1 = 0.0;
-    for (int i = 0; i < nblocks; ++i) { s0 += blockpart[2 * i]; s1 += blockpart[2 * i + 1]; }
+    for (int i = threadIdx.x; i < nblocks; i += 64) { s0 += blockpart[2 * i]; s1 += blockpart[2 * i + 1]; }
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) { s0 += __shfl_xor(s0, w); s1 += __shfl_xor(s1, w); }
+    if (threadIdx.x) return;
     if (sloss) sloss[0] = (float)(s0 / n_sed);
     if (doa_loss == 1 && dloss) dloss[0] = (float)(s1 / (double)den_dev[0]);
 }
@@ -143,7 +147,7 @@ int launch_losses(hipStream_t st, const float* sed, const float* doa, const floa
     const int nblocks = (rows + 63) / 64;
     hipLaunchKernelGGL(losses_kernel, dim3(nblocks), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss, coef_sed, w_doa, den_dev,
                        doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(1), 0, st, blockpart, nblocks, doa_loss, (double)rows * nc, den_dev,
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, st, blockpart, nblocks, doa_loss, (double)rows * nc, den_dev,
                        sloss, dloss);
     return 0;
 }
