@@ -64,7 +64,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             u[g][p].x = U[(size_t)(32 * q + 2 * p) * GRU_G + g * GRU_U + j];
             u[g][p].y = U[(size_t)(32 * q + 2 * p + 1) * GRU_G + g * GRU_U + j];
         }
-    const float bz = brec[j], br = brec[GRU_U + j], bh = brec[2 * GRU_U + j];
+    const bool odd = q & 1;
+    const int zr_off = (odd ? GRU_U : 0) + j;
+    const float bzr = brec[zr_off], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
     const unsigned sel0 = q == 0 ? ~0u : 0u, sel1 = q == 1 ? ~0u : 0u, sel2 = q == 2 ? ~0u : 0u, sel3 = q == 3 ? ~0u : 0u;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         auto do_step = [&](int i) {
             const int row = dir ? n - 1 - i : i;
             const int t = tlo + row;
-            const float gxz = gb[row * GRU_G + j], gxr = gb[row * GRU_G + GRU_U + j], gxh = gb[row * GRU_G + 2 * GRU_U + j];
+            // lanes q = 0, 2 of a quad finish the update gate, lanes 1, 3 the reset gate: each reads only its own input term
+            const float gxzr = gb[row * GRU_G + zr_off], gxh = gb[row * GRU_G + 2 * GRU_U + j];
             const float* hp = &hl[step & 1][36 * q];
             f32x2 az2 = {0.f, 0.f}, ar2 = {0.f, 0.f}, ah2 = {0.f, 0.f};   // (even k, odd k) partial sums
 #pragma unroll
@@ -118,10 +121,18 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 az2 = pk_fma(h01, u[0][2 * k4], az2); ar2 = pk_fma(h01, u[1][2 * k4], ar2); ah2 = pk_fma(h01, u[2][2 * k4], ah2);
                 az2 = pk_fma(h23, u[0][2 * k4 + 1], az2); ar2 = pk_fma(h23, u[1][2 * k4 + 1], ar2); ah2 = pk_fma(h23, u[2][2 * k4 + 1], ah2);
             }
-            float az = az2.x + az2.y, ar = ar2.x + ar2.y, ah = ah2.x + ah2.y;
-            az = quad_sum(az); ar = quad_sum(ar); ah = quad_sum(ah);
-            const float z = sigmoid_(gxz + az + bz);
-            const float r = sigmoid_(gxr + ar + br);
+            const float az = az2.x + az2.y, ar = ar2.x + ar2.y;
+            float ah = ah2.x + ah2.y;
+            // fold the z and r sums instead of two quad sums: with its xor-1 neighbour a lane trades the sum it does not
+            // finish (even lanes keep z, odd lanes r), then the xor-2 halves are added: 2 cross-lane adds for both gates,
+            // ONE sigmoid per lane, and two quad_perm moves hand z and r back to all four lanes
+            float zr = (odd ? ar : az) +
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? az : ar), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+            zr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zr), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+            ah = quad_sum(ah);
+            const float sg = sigmoid_(gxzr + zr + bzr);
+            const float z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xA0 /*quad_perm [0,0,2,2]*/, 0xF, 0xF, true));
+            const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, true));
             const float ghh = ah + bh;
             const float hh = tanh_(gxh + r * ghh);
             const float hn = z * h_own + (1.f - z) * hh;
