@@ -271,33 +271,45 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     __syncthreads();
     float carry = 0.f;    // carry of unit jm
     int step = 0;
+    // Everything in a step's gate gradients except the factor dh = dout*h_other + carry is known before the step's carry
+    // is: a_z = dh*kz, a_r = dh*kr, a_h = dh*kh, a_h*r = dh*khr with kh = (1-z)(1-hh^2), kz = (h_prev-hh) z (1-z),
+    // kr = kh*gh*r*(1-r), khr = kh*r.  pre() forms this lane's two coefficients (its role qr picks them) for the NEXT step
+    // while the current step's mat-vec runs; the chain behind the carry is then one add and two multiplies.
+    const int cidx = (qr < 3 ? qr : 0) * GRU_U + jm;
+    const int gl_slot = 28 * (cidx / 24) + cidx % 24;
+    float k_do = 0.f, k_x = 0.f, k_h = 0.f, k_z = 0.f, c_zs = 0.f;
+    auto pre = [&](const float* sbuf, int row) {
+        const float* rp = sbuf + row * GRUB_ROW + jm;
+        k_do = rp[0] * rp[128];
+        const float c_z = rp[256], c_r = rp[384], c_hh = rp[512], c_gh = rp[640], hp = rp[768];
+        const float kh = (1.f - c_z) * (1.f - c_hh * c_hh);
+        const float kz = (hp - c_hh) * c_z * (1.f - c_z);
+        const float kr = kh * c_gh * c_r * (1.f - c_r);
+        k_x = qr == 0 ? kz : (qr == 1 ? kr : kh);
+        k_h = qr == 0 ? kz : (qr == 1 ? kr : kh * c_r);
+        k_z = c_z;
+    };
+    {
+        int n0, tlo0;
+        chunk_rows(0, n0, tlo0);
+        pre(stage, dir ? 0 : n0 - 1);
+    }
     for (int c = 0; c < nchunks; ++c) {
         int n, tlo;
         chunk_rows(c, n, tlo);
         issue(min(c + 1, nchunks - 1));   // unconditional: see gru_fwd_kernel
         const float* sb = stage + (c & 1) * GRUB_CH * GRUB_ROW;
-        float dh = 0.f, c_zs = 0.f;
+        float dh = 0.f;
         float* gw = nullptr;
-        auto part1 = [&](int i) {   // gate gradients of step i -> LDS vector + global
+        auto part1 = [&](int i) {   // gate gradients of step i -> LDS vector + global: dh times the coefficients pre() prepared
             const int row = dir ? i : n - 1 - i;
             const int t = tlo + row;
-            const float* rp = sb + row * GRUB_ROW + jm;
-            const float c_do = rp[0] * rp[128];
-            const float c_z = rp[256], c_r = rp[384], c_hh = rp[512], c_gh = rp[640], hp = rp[768];
-            dh = c_do + carry;
-            c_zs = c_z;
-            const float dhh = dh * (1.f - c_z);
-            const float dzg = dh * (hp - c_hh);
-            const float a_h = dhh * (1.f - c_hh * c_hh);
-            const float a_z = dzg * c_z * (1.f - c_z);
-            const float a_r = a_h * c_gh * c_r * (1.f - c_r);
-            const float a_hr = a_h * c_r;
+            dh = k_do + carry;
+            c_zs = k_z;
             gw = gl + (step & 1) * GRUB_GL;
             if (qr < 3) {
-                const int cidx = qr * GRU_U + jm;
-                const float vx = qr == 0 ? a_z : (qr == 1 ? a_r : a_h);
-                const float vh = qr == 0 ? a_z : (qr == 1 ? a_r : a_hr);
-                gw[28 * (cidx / 24) + cidx % 24] = vh;
+                const float vx = dh * k_x, vh = dh * k_h;
+                gw[gl_slot] = vh;
                 dgx[(size_t)t * GRU_G + cidx] = vx;
                 dgh[(size_t)t * GRU_G + cidx] = vh;
             }
@@ -333,11 +345,18 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         for (int i = 0; i < n - 1; ++i) {
             part1(i);
             lds_barrier();   // LDS-only barrier: never wait for the dgx/dgh stores
+            pre(sb, dir ? i + 1 : n - 2 - i);
             part2();
         }
         part1(n - 1);
         commit((c + 1) & 1);  // the only wait on the staged loads
         lds_barrier();
+        {
+            // first step of the next chunk (its rows were committed just above); after the last chunk: the same rows again, unused
+            int n2, tlo2;
+            chunk_rows(min(c + 1, nchunks - 1), n2, tlo2);
+            pre(stage + ((c + 1) & 1) * GRUB_CH * GRUB_ROW, dir ? 0 : n2 - 1);
+        }
         part2();
     }
 }
