@@ -349,6 +349,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);

@@ -52,6 +52,7 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
                                   const unsigned char* amax, const float* coef, float* slab, int* n_slab, int B, int H,
                                   int Cin, int pt, int pf);
 int conv_gram_dim(int Cin);
+extern int g_gram_bg_blocks;
 int conv_gram_slab_capacity();
 int conv_msparse_slab_capacity();
 int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background = 0);

@@ -145,10 +145,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __
 // a background launch asks for 112 KB of LDS per block — it cannot land on a CU that runs a recurrence block — and for
 // at most 128 blocks (swept 64..192: 128 disturbs the input-projection GEMMs and the second GRU layer least while still
 // finishing well before the first block's backward needs G, ~2 ms later).
+int g_gram_bg_blocks = 128;   // workgroups of the background launch (swept: fewer stretch it over later kernels, more crowd the recurrence)
 int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background) {
     if ((Cin != 7 && Cin != 10) || B <= 0 || H <= 0) return -2;
     const int ntiles = B * ((H + 3) / 4);
-    const int cap = background ? 128 : GRAM_MAX_BLOCKS;
+    const int cap = background ? g_gram_bg_blocks : GRAM_MAX_BLOCKS;
     const int grid = ntiles < cap ? ntiles : cap;
     const size_t lds_floor = background ? (size_t)112 * 1024 : 0;
     if (Cin == 7) {
@@ -310,8 +311,18 @@ __global__ __launch_bounds__(256) void conv_first_assemble_kernel(const float* _
     const double mu = coef[co], is = coef[64 + co], sc = coef[128 + co], c1 = coef[256 + co], c2 = coef[320 + co];
     const double ka = -sc * c2 * is, kb = -sc * c1 - ka * mu;
     auto gs = [&](int r, int c) -> double { return (r >> 5) <= (c >> 5) ? G[(size_t)r * KP + c] : G[(size_t)c * KP + r]; };
-    double t = gs(k, K) * (double)bias[co];
-    for (int k2 = 0; k2 < K; ++k2) t += gs(k, k2) * (double)W[k2 * 64 + co];
+    // four interleaved partial sums (fixed order): the 63 loads of a row no longer wait on one dependent FMA chain
+    double t0 = gs(k, K) * (double)bias[co], t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    int k2 = 0;
+#pragma unroll 2
+    for (; k2 + 3 < K; k2 += 4) {
+        t0 += gs(k, k2) * (double)W[k2 * 64 + co];
+        t1 += gs(k, k2 + 1) * (double)W[(k2 + 1) * 64 + co];
+        t2 += gs(k, k2 + 2) * (double)W[(k2 + 2) * 64 + co];
+        t3 += gs(k, k2 + 3) * (double)W[(k2 + 3) * 64 + co];
+    }
+    for (; k2 < K; ++k2) t0 += gs(k, k2) * (double)W[k2 * 64 + co];
+    const double t = (t0 + t1) + (t2 + t3);
     const float v = (float)(ka * t + gs(k, K) * kb + (double)M[k * 64 + co]);
     if (k < K) dW[k * 64 + co] = v;
     else db[co] = v;
