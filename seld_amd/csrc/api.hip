@@ -64,6 +64,8 @@ struct seld_ctx {
     hipEvent_t ev_gram = nullptr;
     int conv1_split_bf16 = 1;              // 1: the z-free first-block forward on bf16 MFMA with exactly split operands (conv_pool_sb.hip)
     int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
+    int heads_fused = 1;                   // 1: heads of two LINEAR-then-activated layers run as one product with W1 W2 (see heads_lin)
+    float *weff = nullptr, *dy_all = nullptr, *headF = nullptr;   // [K + 1][NT], [rows][NT], [K][NT] + [NT]
     int gemm_split_bf16 = 1;               // 1: GRU input projections / heads' first Conv1D (and their input gradients) on the
                                            //    split-bf16 GEMM (gemm_sb.hip) where the shapes allow; 0: exact-fp32 MFMA GEMM
     unsigned short* gsplit = nullptr;      // pre-split weight operands of those products, refreshed by every forward
@@ -316,6 +318,12 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             c->h0sp_bwd[hd] = q; q += gemm_sb_split_elems(D.in, D.out);
         }
     }
+    {
+        const int nt = c->heads[0].layers.back().out + c->heads[1].layers.back().out, k = c->heads[0].layers[0].in;
+        ALLOC(c->weff, (size_t)(k + 1) * nt);
+        ALLOC(c->dy_all, rows * (size_t)nt);
+        ALLOC(c->headF, (size_t)k * nt + nt);
+    }
     ALLOC(c->loss_scratch, (size_t)loss_scratch_floats((int)rows));
     ALLOC(c->den_dev, 4); ALLOC(c->loss_out, rows + 4);
 #undef ALLOC
@@ -348,6 +356,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!c || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "heads_fused")) { c->heads_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
@@ -425,6 +434,28 @@ static bool heads_sb(const seld_ctx* c) {
            (S0.in % 128) == 0 && (S0.out % 128) == 0;
 }
 
+// Heads of the form Dense(h, linear) -> Dense(n, act) on shared features (seldnet.json: Conv1D(128, 1) then the output Dense):
+// y = act(feat (W1 W2) + (b1 W2 + b2)).  The 128-wide hidden tensor is never formed, forward or backward: the products
+// shrink from K = N = 128 to N = 12 + 36 columns in one launch, and all four weight gradients of a head follow from
+// F = feat^T dy and colsum(dy) (gemm.hip, heads_grad_kernel).  Same mathematics, different association of the fp32 sums.
+static bool heads_lin(const seld_ctx* c) {
+    const Head &Hs = c->heads[0], &Hdo = c->heads[1];
+    if (!c->heads_fused || Hs.layers.size() != 2 || Hdo.layers.size() != 2) return false;
+    const DenseL &S0 = Hs.layers[0], &D0 = Hdo.layers[0];
+    return S0.in == D0.in && S0.out == D0.out && Hs.layers[1].out + Hdo.layers[1].out <= 64 && (S0.in & 3) == 0 &&
+           ((Hs.layers[1].out + Hdo.layers[1].out) & 3) == 0;
+}
+static int prepare_heads_weff(seld_ctx* c, hipStream_t st) {
+    const float *w1[2], *b1[2], *w2[2], *b2[2];
+    int n[2];
+    for (int hd = 0; hd < 2; ++hd) {
+        const DenseL &L0 = c->heads[hd].layers[0], &L1 = c->heads[hd].layers[1];
+        w1[hd] = c->params + L0.w_off; b1[hd] = c->params + L0.b_off; w2[hd] = c->params + L1.w_off; b2[hd] = c->params + L1.b_off;
+        n[hd] = L1.out;
+    }
+    return launch_heads_weff(st, w1, b1, w2, b2, n, c->heads[0].layers[0].in, c->heads[0].layers[0].out, c->weff);
+}
+
 // one launch splits every weight operand the split-bf16 GEMMs of this step will read (the weights change every step)
 static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orientation) {
     const float* src[16]; unsigned short* dst[16]; int ldb[16], tb[16], K[16], N[16];
@@ -442,7 +473,7 @@ static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orien
             if (with_grad_orientation && add(c->params + G.k_off[d], c->ksp_bwd[i][d], 384, 1, 384, G.in_feat)) return -1;   // din = dgx K^T
         }
     }
-    if (heads_sb(c))
+    if (heads_sb(c) && !heads_lin(c))
         for (int hd = 0; hd < 2; ++hd) {
             const DenseL& D = c->heads[hd].layers[0];
             if (add(c->params + D.w_off, c->h0sp_fwd[hd], D.out, 0, D.in, D.out)) return -1;
@@ -456,6 +487,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     const int B = c->B, S = c->S;
     const int rows = B * S;
     if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
+    if (heads_lin(c) && prepare_heads_weff(c, st)) return fail(c, SELD_ERR_UNSUPPORTED, "heads_weff");
     if (c->conv64_split_bf16) {   // 64 -> 64 conv weights: forward planes and (when a backward follows) the flipped ones, one launch
         const float* w[8]; unsigned short* dst[8]; int flip[8];
         int n = 0;
@@ -552,6 +584,14 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // the first layers of the two heads read the same features: one launch when their shapes agree (seldnet.json:
         // Conv1D(128) in both) and neither is the head's output layer
         DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+        if (heads_lin(c)) {
+            DenseL &S1 = c->heads[0].layers[1], &D1 = c->heads[1].layers[1];
+            const int nt = S1.out + D1.out;
+            if (launch_gemm_heads(st, feat, S0.in, c->weff, c->weff + (size_t)S0.in * nt, S1.y, D1.y, sed, doa, rows, S1.out, D1.out,
+                                  S0.in, c->heads[0].act, c->heads[1].act))
+                return fail(c, SELD_ERR_UNSUPPORTED, "gemm_heads");
+            return check_launch(c, "forward");
+        }
         const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out;
         if (merged0 && heads_sb(c) && gemm_sb_usable(feat, S0.in, S0.out, S0.in))
             launch_gemm_sb(st, feat, nullptr, S0.in, c->h0sp_fwd[0], c->h0sp_fwd[1], c->params + S0.b_off, c->params + D0.b_off, S0.y,
@@ -600,9 +640,14 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
     }
     float* sl = sloss ? sloss : c->loss_out;
     float* dl = dloss ? dloss : c->loss_out + 4;
+    // fused linear heads: both pre-activation gradients side by side in one [rows][n_sed + n_doa] buffer (the K axis of dfeat)
+    const bool lin = heads_lin(c);
+    const int n0 = c->heads[0].layers.back().out, nt = n0 + c->heads[1].layers.back().out;
     launch_losses(st, c->heads[0].layers.back().y, c->heads[1].layers.back().y, y_sed, y_doa, cfg->doa_loss, cfg->w_sed,
-                  cfg->w_doa, cfg->sed_grad_scale, c->den_dev, sl, dl, want_grads ? c->heads[0].layers.back().dy : nullptr,
-                  want_grads ? c->heads[1].layers.back().dy : nullptr, c->loss_scratch, c->B, c->S, nc);
+                  cfg->w_doa, cfg->sed_grad_scale, c->den_dev, sl, dl,
+                  want_grads ? (lin ? c->dy_all : c->heads[0].layers.back().dy) : nullptr,
+                  want_grads ? (lin ? c->dy_all + n0 : c->heads[1].layers.back().dy) : nullptr, c->loss_scratch, c->B, c->S, nc,
+                  lin ? nt : 0, lin ? nt : 0);
     return check_launch(c, "losses");
 }
 
@@ -641,9 +686,29 @@ static int backward_impl(seld_ctx* c, const float* x) {
     {
         PROF2(c, "heads_bwd");
         float* dfeat = c->feat_grad;
+        DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+        if (heads_lin(c)) {
+            // dfeat = [dy_sed | dy_doa] Weff^T (K = 48), then on the side stream F = feat^T dy, colsum(dy) and the four
+            // gradients of each head from them
+            const int nt = c->heads[0].layers[1].out + c->heads[1].layers[1].out, K = S0.in;
+            launch_gemm(st, c->dy_all, nt, c->weff, nt, nullptr, dfeat, K, rows, K, nt, 1, 0, 0);
+            fork_side(c);
+            int ns = 0;
+            launch_gemm_tn(c->side, Glast.out, K, c->dy_all, nt, c->tn_slab_side, &ns, rows, K, nt, 0, 0, 1);
+            launch_reduce_slabs2(c->side, c->tn_slab_side, ns, (int64_t)K * nt + nt, c->headF, (int64_t)K * nt, c->headF + (size_t)K * nt, nt);
+            const float *w1[2], *b1[2], *w2[2];
+            float *dw1[2], *db1[2], *dw2[2], *db2[2];
+            int n[2];
+            for (int hd = 0; hd < 2; ++hd) {
+                const DenseL &L0 = c->heads[hd].layers[0], &L1 = c->heads[hd].layers[1];
+                w1[hd] = c->params + L0.w_off; b1[hd] = c->params + L0.b_off; w2[hd] = c->params + L1.w_off;
+                dw1[hd] = c->grads + L0.w_off; db1[hd] = c->grads + L0.b_off; dw2[hd] = c->grads + L1.w_off; db2[hd] = c->grads + L1.b_off;
+                n[hd] = L1.out;
+            }
+            launch_heads_grad(c->side, w1, b1, w2, dw1, db1, dw2, db2, n, K, S0.out, c->headF, c->headF + (size_t)K * nt);
+        } else {
         // the gradient w.r.t. the shared features is the sum over the two heads' first layers: one product over the
         // concatenated K axis when their shapes agree (out % 32 == 0), otherwise two launches with accumulation
-        DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
         const bool merged0 = S0.in == D0.in && S0.out == D0.out && (S0.out & 31) == 0;
         for (int hd = 0; hd < 2; ++hd) {
             Head& Hd = c->heads[hd];
@@ -668,6 +733,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 const float* ain = j == 0 ? Glast.out : Hd.layers[j - 1].y;
                 wgrad_dense(c, c->side, c->tn_slab_side, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, D.b_off, 0, 0);
             }
+        }
         }
     }
     // ---- GRU layers, last to first

@@ -101,6 +101,13 @@ int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0,
                        const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int transb, int act);
 int launch_gemm_mirror(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, float* mirror,
                        int ldc, int M, int N, int K, int transb, int act);
+int launch_gemm_heads(hipStream_t st, const float* A, int lda, const float* Bm, const float* bias, float* C0, float* C1, float* M0,
+                      float* M1, int M, int n0, int n1, int K, int act0, int act1);
+int launch_heads_weff(hipStream_t st, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                      const int* n, int K, int Hd, float* weff);
+int launch_heads_grad(hipStream_t st, const float* const* w1, const float* const* b1, const float* const* w2, float* const* dw1,
+                      float* const* db1, float* const* dw2, float* const* db2, const int* n, int K, int Hd, const float* F,
+                      const float* cs);
 int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda, const float* B0, const float* B1, int ldb,
                        const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate);
 // split-bf16 GEMM (gemm_sb.hip): weights pre-split into bf16 planes by launch_gemm_split_b (up to 16 operands per launch),
@@ -134,7 +141,8 @@ struct seld_loss_cfg;
 int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scratch, int rows, int nc);
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
-                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc);
+                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, int ld_sed = 0,
+                  int ld_doa = 0);
 int loss_scratch_floats(int rows);
 int launch_adam(hipStream_t st, float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
                 float beta1, float beta2, float eps);

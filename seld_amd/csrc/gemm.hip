@@ -18,10 +18,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ C,
                                                        int ldc, int M, int N, int K, int act, int accumulate,
                                                        const float* __restrict__ A1, const float* __restrict__ B1,
-                                                       const float* __restrict__ bias1, float* __restrict__ C1, int mode) {
+                                                       const float* __restrict__ bias1, float* __restrict__ C1, int mode,
+                                                       float* __restrict__ M0, float* __restrict__ M1, int nsplit) {
     // mode 0: C = act(A B + bias) (+C).   mode 1 (two products sharing A): column tiles >= ceil(N/64) compute
     // C1 = act(A B1 + bias1).   mode 2 (one product over a concatenated K): C = act(A B + A1 B1 + bias) (+C), K % 32 == 0.
     // mode 3: mode 0, and the result is also stored to C1 (same leading dimension): the caller's copy of a head output.
+    // mode 4 (both heads' outputs from one product, launch_gemm_heads): columns < nsplit get activation act & 15 and go to
+    // C [M][nsplit] (and M0), the others activation act >> 4 and go to C1 [M][N - nsplit] (and M1).
     const int ntx = (N + 63) >> 6;
     const bool second = mode == 1 && (int)blockIdx.x >= ntx;
     if (second) { Bm = B1; bias = bias1; C = C1; }
@@ -145,6 +148,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const int row = m0 + wr * 32 + mfma_row(r, hi);
             if (row < M) {
                 float v = (acc[r] + acc1[r]) + bv;
+                if (mode == 4) {
+                    const bool first = col < nsplit;
+                    const int a_ = first ? (act & 15) : (act >> 4);
+                    if (a_ == 1) v = 1.f / (1.f + expf(-v));
+                    else if (a_ == 2) v = tanhf(v);
+                    const size_t o_ = first ? (size_t)row * nsplit + col : (size_t)row * (N - nsplit) + (col - nsplit);
+                    (first ? C : C1)[o_] = v;
+                    float* m_ = first ? M0 : M1;
+                    if (m_) m_[o_] = v;
+                    continue;
+                }
                 if (act == 1) v = 1.f / (1.f + expf(-v));
                 else if (act == 2) v = tanhf(v);
                 float* p = C + (size_t)row * ldc + col;
@@ -158,16 +172,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 static int gemm_go(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, int ldc, int M,
                    int N, int K, int transb, int act, int accumulate, const float* A1, const float* B1, const float* bias1, float* C1,
-                   int mode) {
+                   int mode, float* M0 = nullptr, float* M1 = nullptr, int nsplit = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
     if (mode == 2 && (K & 31)) return -2;
     dim3 grid((N + 63) / 64 * (mode == 1 ? 2 : 1), (M + 63) / 64);
     if (transb)
         hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
-                           bias1, C1, mode);
+                           bias1, C1, mode, M0, M1, nsplit);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
-                           bias1, C1, mode);
+                           bias1, C1, mode, M0, M1, nsplit);
     return 0;
 }
 
@@ -180,6 +194,81 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ld
 int launch_gemm_mirror(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C, float* mirror,
                        int ldc, int M, int N, int K, int transb, int act) {
     return gemm_go(st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, transb, act, 0, nullptr, nullptr, nullptr, mirror, mirror ? 3 : 0);
+}
+
+// both heads' outputs in one product: [C0 | C1] = act0 / act1 (A [W0 | W1] + [b0 | b1]) with the weights already concatenated
+// (Bm [K][n0 + n1], bias [n0 + n1]); C0 [M][n0], C1 [M][n1] and optional copies M0 / M1
+int launch_gemm_heads(hipStream_t st, const float* A, int lda, const float* Bm, const float* bias, float* C0, float* C1, float* M0,
+                      float* M1, int M, int n0, int n1, int K, int act0, int act1) {
+    return gemm_go(st, A, lda, Bm, n0 + n1, bias, C0, 0, M, n0 + n1, K, 0, act0 | (act1 << 4), 0, nullptr, nullptr, nullptr, C1, 4, M0, M1, n0);
+}
+
+// ---- two linear layers in a row (the heads: Conv1D(128, 1) then Dense(n), no activation between): y2 = act(x Weff + beff) with
+// Weff = W1 W2, beff = b1 W2 + b2, and every gradient follows from F = x^T dy2 and cs = colsum(dy2) (api.hip, heads_fused):
+//   dW2 = W1^T F + b1 (x) cs,  db2 = cs,  dW1 = F W2^T,  db1 = cs W2^T,  dx = dy2 Weff^T.
+// weff_all [K + 1][NT]: rows 0..K-1 = [W1s W2s | W1d W2d], row K = [b1s W2s + b2s | b1d W2d + b2d]   (NT = n0 + n1)
+struct HeadsLin { const float *w1[2], *b1[2], *w2[2], *b2[2]; int n[2]; int K, Hd; };
+__global__ __launch_bounds__(64) void heads_weff_kernel(HeadsLin h, float* __restrict__ weff) {
+    const int k = blockIdx.x, NT = h.n[0] + h.n[1];        // row k of Weff (k == K: the bias row)
+    const int col = threadIdx.x;
+    if (col >= NT) return;
+    const int hd = col >= h.n[0], n = col - (hd ? h.n[0] : 0), N = h.n[hd];
+    const float* w1 = h.w1[hd];
+    const float* w2 = h.w2[hd];
+    double s = 0.0;
+    for (int j = 0; j < h.Hd; ++j) s += (double)(k < h.K ? w1[(size_t)k * h.Hd + j] : h.b1[hd][j]) * (double)w2[(size_t)j * N + n];
+    if (k == h.K) s += (double)h.b2[hd][n];
+    weff[(size_t)k * NT + col] = (float)s;
+}
+int launch_heads_weff(hipStream_t st, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                      const int* n, int K, int Hd, float* weff) {
+    if (n[0] + n[1] > 64) return -1;
+    HeadsLin h;
+    for (int i = 0; i < 2; ++i) { h.w1[i] = w1[i]; h.b1[i] = b1[i]; h.w2[i] = w2[i]; h.b2[i] = b2[i]; h.n[i] = n[i]; }
+    h.K = K; h.Hd = Hd;
+    hipLaunchKernelGGL(heads_weff_kernel, dim3(K + 1), dim3(64), 0, st, h, weff);
+    return 0;
+}
+
+// gradients of both heads' four tensors from F [K][NT] and cs [NT] (double accumulation, one thread per output element)
+struct HeadsGrad { const float *w1[2], *b1[2], *w2[2]; float *dw1[2], *db1[2], *dw2[2], *db2[2]; int n[2]; int K, Hd; };
+__global__ __launch_bounds__(256) void heads_grad_kernel(HeadsGrad h, const float* __restrict__ F, const float* __restrict__ cs) {
+    const int NT = h.n[0] + h.n[1];
+    const int hd = blockIdx.y, N = h.n[hd], c0 = hd ? h.n[0] : 0;
+    const int nW1 = h.K * h.Hd, nW2 = h.Hd * N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nW1) {                                   // dW1[k][j] = sum_n F[k][c0 + n] W2[j][n]
+        const int k = i / h.Hd, j = i - k * h.Hd;
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)F[(size_t)k * NT + c0 + n] * (double)h.w2[hd][(size_t)j * N + n];
+        h.dw1[hd][i] = (float)s;
+    } else if (i < nW1 + nW2) {                      // dW2[j][n] = sum_k W1[k][j] F[k][c0 + n] + b1[j] cs[c0 + n]
+        const int e = i - nW1, j = e / N, n = e - j * N;
+        double s = (double)h.b1[hd][j] * (double)cs[c0 + n];
+        for (int k = 0; k < h.K; ++k) s += (double)h.w1[hd][(size_t)k * h.Hd + j] * (double)F[(size_t)k * NT + c0 + n];
+        h.dw2[hd][e] = (float)s;
+    } else if (i < nW1 + nW2 + h.Hd) {               // db1[j] = sum_n cs[c0 + n] W2[j][n]
+        const int j = i - nW1 - nW2;
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)cs[c0 + n] * (double)h.w2[hd][(size_t)j * N + n];
+        h.db1[hd][j] = (float)s;
+    } else if (i < nW1 + nW2 + h.Hd + N) {           // db2 = cs
+        const int n = i - nW1 - nW2 - h.Hd;
+        h.db2[hd][n] = cs[c0 + n];
+    }
+}
+int launch_heads_grad(hipStream_t st, const float* const* w1, const float* const* b1, const float* const* w2, float* const* dw1,
+                      float* const* db1, float* const* dw2, float* const* db2, const int* n, int K, int Hd, const float* F,
+                      const float* cs) {
+    HeadsGrad h;
+    for (int i = 0; i < 2; ++i) {
+        h.w1[i] = w1[i]; h.b1[i] = b1[i]; h.w2[i] = w2[i]; h.dw1[i] = dw1[i]; h.db1[i] = db1[i]; h.dw2[i] = dw2[i]; h.db2[i] = db2[i];
+        h.n[i] = n[i];
+    }
+    h.K = K; h.Hd = Hd;
+    const int nmax = K * Hd + Hd * (n[0] > n[1] ? n[0] : n[1]) + Hd + 64;
+    hipLaunchKernelGGL(heads_grad_kernel, dim3((nmax + 255) / 256, 2), dim3(256), 0, st, h, F, cs);
+    return 0;
 }
 
 // two products that share A in one launch: C0 = act(A B0 + bias0), C1 = act(A B1 + bias1) (same shapes and leading dimensions)

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
                                                      int doa_loss, float coef_sed, float w_doa,
                                                      const float* __restrict__ den_dev, float* __restrict__ dloss_rows,
                                                      float* __restrict__ dsed_pre, float* __restrict__ ddoa_pre,
-                                                     double* __restrict__ blockpart, int rows, int nc) {
+                                                     double* __restrict__ blockpart, int rows, int nc, int ld_sed, int ld_doa) {
     __shared__ float rs[64][2];
     const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;
     const int r = min(blockIdx.x * 64 + rl, rows - 1);       // rows past the end recompute the last row and store nothing
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
         if (dsed_pre && live) {
             const bool pass = (pv >= BCE_EPS) && (pv <= 1.f - BCE_EPS);
             const float dldp = pass ? -(y / (pc + BCE_EPS) - (1.f - y) / (1.f - pc + BCE_EPS)) : 0.f;
-            dsed_pre[(size_t)r * nc + c] = coef_sed * dldp * pv * (1.f - pv);
+            dsed_pre[(size_t)r * ld_sed + c] = coef_sed * dldp * pv * (1.f - pv);
         }
     }
     const float* d = doa + (size_t)r * 3 * nc;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
         for (int k = q; k < 3 * nc; k += 4) {
             const float e = yd[k] - d[k];
             dsum += e * e;
-            if (ddoa_pre && live) ddoa_pre[(size_t)r * 3 * nc + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
+            if (ddoa_pre && live) ddoa_pre[(size_t)r * ld_doa + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
         }
         dsum = loss_quad_sum(dsum) * inv;
         if (dloss_rows && live && q == 0) dloss_rows[r] = dsum;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
                 const int i = k * nc + c;
                 const float e = yd[i] - d[i];
                 dsum += e * e * m;
-                if (ddoa_pre && live) ddoa_pre[(size_t)r * 3 * nc + i] = w_doa * (-2.f * e * m / den) * (1.f - d[i] * d[i]);
+                if (ddoa_pre && live) ddoa_pre[(size_t)r * ld_doa + i] = w_doa * (-2.f * e * m / den) * (1.f - d[i] * d[i]);
             }
         }
         dsum = loss_quad_sum(dsum);
@@ -138,7 +138,10 @@ __global__ __launch_bounds__(64) void losses_finalize_kernel(const double* __res
 
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
-                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc) {
+                  float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, int ld_sed,
+                  int ld_doa) {
+    if (ld_sed <= 0) ld_sed = nc;          // row strides of the two gradient outputs (a shared [rows][4 nc] buffer: 4 nc each)
+    if (ld_doa <= 0) ld_doa = 3 * nc;
     const int rows = B * S;
     // BCE is a mean over rows*nc elements.  With the Keras MSE *function* the per-row loss tensor
     // sloss*w0 + mse[b,s]*w1 is summed by tape.gradient, which multiplies the BCE term by rows.
@@ -146,7 +149,7 @@ int launch_losses(hipStream_t st, const float* sed, const float* doa, const floa
     double* blockpart = reinterpret_cast<double*>(scratch);      // [nblocks][2]: rows / 32 doubles of the 2 * rows floats
     const int nblocks = (rows + 63) / 64;
     hipLaunchKernelGGL(losses_kernel, dim3(nblocks), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss, coef_sed, w_doa, den_dev,
-                       doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc);
+                       doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc, ld_sed, ld_doa);
     hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, st, blockpart, nblocks, doa_loss, (double)rows * nc, den_dev,
                        sloss, dloss);
     return 0;

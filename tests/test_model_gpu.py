@@ -57,7 +57,9 @@ def test_forward_inference(seldnet_config, B, T):
                                                (2, 50, "MSE", {"conv1_gram": 0, "conv1_pool_fused": 0}),   # ... and the unfused pooling
                                                (2, 50, "MSE", {"conv64_split_bf16": 0}),                   # fp32-MFMA 64->64 convs
                                                (3, 100, "MSE", {"gemm_split_bf16": 0}),                    # fp32-MFMA GRU / head GEMMs
-                                               (3, 100, "MSE", {"conv1_split_bf16": 0})])                  # fp32-MFMA first-block forward
+                                               (3, 100, "MSE", {"conv1_split_bf16": 0}),                   # fp32-MFMA first-block forward
+                                               (3, 100, "MSE", {"heads_fused": 0}),                        # heads layer by layer
+                                               (2, 50, "MMSE", {"heads_fused": 0})])
 def test_train_step(seldnet_config, B, T, doa_loss, opts):
     O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
     for k, v in opts.items():
