@@ -64,6 +64,7 @@ def kernel_work(name, B, T, F=64, C=7):
         "gru_bwd": ("hbm", 2 * 4 * rows * (128 + 128 + 512 + 128 + 768)),
         "gru_inproj_gemm": ("mfma", 2 * 2 * rows * 128 * 384),
         "gru_bwd_gemms": ("mfma", 2 * 2 * rows * 128 * 384),   # main stream: the two input-gradient GEMMs of a layer
+        # reference op count (two Dense layers per head); the default build computes them as one 48-column product (heads_fused)
         "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
         "adam": ("hbm", 4 * 7 * 513840),
     }
