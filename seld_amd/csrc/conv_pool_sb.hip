@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
     for (int idx = tid; idx < (9 * CIN + 1) * 64; idx += 256) {
         const int k = idx >> 6, co = idx & 63;
         const bool isb = k == 9 * CIN;
-        const float v = isb ? (bias ? bias[co] : 0.f) : w[idx];
+        // output channels with gamma < 0 are computed NEGATED (weights and bias): their window extreme is then a maximum like
+        // everyone else's, with no per-value sign flip in the reduction; the stored extreme and the sum are flipped back
+        const float v0_ = isb ? (bias ? bias[co] : 0.f) : w[idx];
+        const float v = gamma[co] < 0.f ? -v0_ : v0_;
         const int kk = isb ? 4 * CP + CIN : (k / CIN) * CP + (k % CIN);
         const unsigned u = __float_as_uint(v);
         const float r = v - __uint_as_float(u & 0xffff0000u);
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         CPSB_COMMIT()
     }
     __syncthreads();
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    f32x2s s1p[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2p[2] = {{0.f, 0.f}, {0.f, 0.f}};
     // A fragment of k-step s: lane (li, kg) reads the 8 slots [c0, c0 + 8) of pixel (row + dy, bin + dx) with
     // k0 = 16 s + 8 kg, tap = min(k0 / CP, 8) (past tap 8 the weights are zero: any finite pixel will do), c0 = k0 % CP
 #define CPSB_TAP(s_, g_) ((16 * (s_) + 8 * (g_)) / CP > 8 ? 8 : (16 * (s_) + 8 * (g_)) / CP)
@@ -142,12 +146,7 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
     // window reduction of one accumulator register of one channel half: conv_pool.hip's CP_DRAIN without the z store
 #define CPSB_DRAIN(r_, c_, Y0, Y1, Y2, Y3, Y4)                                                          \
     {                                                                                                   \
-        const float v0 = Y0[r_], v1 = Y1[r_], v2 = Y2[r_], v3 = Y3[r_], v4 = Y4[r_];                    \
-        s1[c_] += (v0 + v1) + (v2 + v3) + v4;                                                           \
-        s2[c_] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, fmaf(v4, v4, s2[c_])))));          \
-        const float w0 = __uint_as_float(__float_as_uint(v0) ^ smask[c_]), w1 = __uint_as_float(__float_as_uint(v1) ^ smask[c_]); \
-        const float w2 = __uint_as_float(__float_as_uint(v2) ^ smask[c_]), w3 = __uint_as_float(__float_as_uint(v3) ^ smask[c_]); \
-        const float w4 = __uint_as_float(__float_as_uint(v4) ^ smask[c_]);                              \
+        const float w0 = Y0[r_], w1 = Y1[r_], w2 = Y2[r_], w3 = Y3[r_], w4 = Y4[r_];                    \
         const float hi5 = fmaxf(fmaxf(fmaxf(w0, w1), fmaxf(w2, w3)), w4);                               \
         const bool take_ = ((r_) & 3) == 0 || hi5 > best;     /* strict: the first extreme in scan order wins ties */ \
         if (WRITE_AMAX) {    /* training: remember WHERE the extreme is: position row * 4 + column of the window */ \
@@ -162,7 +161,20 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
             if (WRITE_AMAX) (amax + (er + (size_t)((2 * ((r_) >> 2)) * 64 + 32 * (c_))))[lane_e] = (unsigned char)bpos; \
         }                                                                                               \
     }
+    // BN statistics of one accumulator tile: packed adds / FMAs over register pairs (any pairing sums to the same totals)
+#define CPSB_STATS(c_, Y)                                                                               \
+    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                 \
+        const f32x2s y2 = {Y[r], Y[r + 1]};                                                             \
+        s1p[c_] += y2;                                                                                  \
+        s2p[c_] = __builtin_elementwise_fma(y2, y2, s2p[c_]);                                           \
+    }
+#ifdef CPSB_TIMING
+    long long tm_top = 0, tm_mfma = 0, tm_drain = 0, tm_commit = 0;
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
+#ifdef CPSB_TIMING
+        const long long c0 = clock64();
+#endif
         const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * 10;
         const int nxt = tile + gridDim.x;
         CPSB_ISSUE(nxt < ntiles ? nxt : tile)
@@ -172,6 +184,9 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         const size_t er = ((size_t)(b * HP + tg / 5) * 16 + 8 * strip) * 64;
         float best = 0.f;
         int bpos = 0;
+#ifdef CPSB_TIMING
+        const long long c1 = clock64();
+#endif
         f32x16 accA0 = zero16(), accA1 = zero16(), accA2 = zero16(), accA3 = zero16(), accA4 = zero16();
         f32x16 accB0 = zero16(), accB1 = zero16(), accB2 = zero16(), accB3 = zero16(), accB4 = zero16();
 #pragma unroll
@@ -187,18 +202,31 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
             CPSB_ROW(3, accA3, accB3)
             CPSB_ROW(4, accA4, accB4)
         }
+#ifdef CPSB_TIMING
+        const long long c2 = clock64();
+#endif
         if (live) {
+            CPSB_STATS(0, accA0) CPSB_STATS(0, accA1) CPSB_STATS(0, accA2) CPSB_STATS(0, accA3) CPSB_STATS(0, accA4)
+            CPSB_STATS(1, accB0) CPSB_STATS(1, accB1) CPSB_STATS(1, accB2) CPSB_STATS(1, accB3) CPSB_STATS(1, accB4)
 #pragma unroll
             for (int r = 0; r < 16; ++r) CPSB_DRAIN(r, 0, accA0, accA1, accA2, accA3, accA4)
 #pragma unroll
             for (int r = 0; r < 16; ++r) CPSB_DRAIN(r, 1, accB0, accB1, accB2, accB3, accB4)
         }
+#ifdef CPSB_TIMING
+        const long long c3 = clock64();
+#endif
         // single patch buffer: everyone is done reading it, then the prefetched tile replaces it
         lds_barrier();
         CPSB_COMMIT()
         lds_barrier();
+#ifdef CPSB_TIMING
+        const long long c4 = clock64();
+        tm_top += c1 - c0; tm_mfma += c2 - c1; tm_drain += c3 - c2; tm_commit += c4 - c3;
+#endif
     }
 #undef CPSB_DRAIN
+#undef CPSB_STATS
 #undef CPSB_ROW
 #undef CPSB_MFMA
 #undef CPSB_AOFF
@@ -207,8 +235,11 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
 #undef CPSB_COMMIT
 #undef CPSB_SLOT
     if (stat_partial) {
+        float s1[2], s2[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            s1[c] = __uint_as_float(__float_as_uint(s1p[c].x + s1p[c].y) ^ smask[c]);     // negated channels: flip the sum back
+            s2[c] = s2p[c].x + s2p[c].y;
             s1[c] += __shfl_xor(s1[c], 32);
             s2[c] += __shfl_xor(s2[c], 32);
         }
@@ -220,6 +251,13 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         }
         __syncthreads();
         if (tid < 128) stat_partial[(size_t)blockIdx.x * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+#ifdef CPSB_TIMING
+        __syncthreads();
+        if (tid == 0) {      // diagnostic build (tools/tune_conv1.py): the first statistics slots carry wave 0's phase cycles instead
+            float* o = stat_partial + (size_t)blockIdx.x * 128;
+            o[0] = (float)tm_top; o[1] = (float)tm_mfma; o[2] = (float)tm_drain; o[3] = (float)tm_commit;
+        }
+#endif
     }
 }
 

@@ -57,3 +57,7 @@ if os.environ.get("CPOOL_TIMING"):      # library built with -DCPOOL_TIMING: sta
         lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(zz) if zz is not None else None, P(ze), P(am) if zz is not None else None, P(st), B, H, Cin)
         v = st[:6].cpu().numpy() / 512 / 18.75
         print("z stored    " if zz is not None else "z not stored", "cycles per tile (wave 0 mean): top %.0f  phaseA %.0f  phaseB+drainA %.0f  commit %.0f  drainB %.0f  barrier %.0f  total %.0f" % (*v, v.sum()))
+if os.environ.get("CPSB_TIMING"):       # library built with -DCPSB_TIMING (conv_pool_sb.hip): phase cycles of wave 0, z not stored
+    lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), None, P(ze), P(am), P(st), B, H, Cin)
+    v = st[:4].cpu().numpy() / 512 / 18.75
+    print("split-bf16, z not stored: cycles per tile (wave 0 mean): top %.0f  mfma loop %.0f  window reduction %.0f  barrier+commit+barrier %.0f  total %.0f" % (*v, v.sum()))
