@@ -89,7 +89,8 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
 // mode 0: C0 = act(A0 B0 + bias0).
 // mode 1 (two products sharing A): column groups >= N/128 compute C1 = act(A0 B1 + bias1).
 // mode 2 (one product over a concatenated K axis): C0 = act(A0 B0 + A1 B1 + bias0).
-__global__ __launch_bounds__(256, 3) void gemm_sb_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
+template <int NG>   // 4: K = 128, one product (or two sharing A): every A row of the tile is requested up front; 0: runtime loop
+__global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
@@ -166,6 +167,41 @@ __global__ __launch_bounds__(256, 3) void gemm_sb_kernel(const float* __restrict
         GSB_MFMA(al, bh0, acc0); GSB_MFMA(al, bh1, acc1); GSB_MFMA(al, bh2, acc2); GSB_MFMA(al, bh3, acc3);   /* lo*hi  */ \
         GSB_MFMA(am, bm0, acc0); GSB_MFMA(am, bm1, acc1); GSB_MFMA(am, bm2, acc2); GSB_MFMA(am, bm3, acc3);   /* mid*mid */ \
     }
+    if constexpr (NG == 4) {
+        // K = 128 = 4 chunks.  A chunk's 48 MFMAs (0.64 us) are shorter than a global load's round trip (~2 us under load),
+        // so with one chunk of prefetch each of the 4 chunks waited for its rows.  All 16 float4 of the lane's row are in
+        // flight from the start instead, and the B chunks two ahead (statically named sets; fully unrolled so that the
+        // waits are counted vmcnt(N), not the vmcnt(0) hipcc emits across a loop back-edge).
+        float4 pa[4][4];
+        u32x4 pb[2][6];
+#define GSB_LDA(c_) { const float4* ap_ = reinterpret_cast<const float4*>(A0 + aoff + (size_t)(c_) * GSB_KC); \
+                      pa[c_][0] = ap_[0]; pa[c_][1] = ap_[1]; pa[c_][2] = ap_[2]; pa[c_][3] = ap_[3]; }
+#define GSB_LDB(c_, set_) { const u32x4* bp_ = reinterpret_cast<const u32x4*>(Bs0 + ((size_t)(c_) * 3 * N + n0) * GSB_KC); \
+                            const size_t ps_ = (size_t)N * GSB_KC / 8;                                                       \
+                            pb[set_][0] = bp_[tid]; pb[set_][1] = bp_[tid + 256]; pb[set_][2] = bp_[ps_ + tid];              \
+                            pb[set_][3] = bp_[ps_ + tid + 256]; pb[set_][4] = bp_[2 * ps_ + tid]; pb[set_][5] = bp_[2 * ps_ + tid + 256]; }
+#define GSB_STB(buf_, set_) { u32x4* d_ = reinterpret_cast<u32x4*>(Bl[buf_]);                                  \
+                              d_[tid] = pb[set_][0]; d_[tid + 256] = pb[set_][1]; d_[512 + tid] = pb[set_][2]; \
+                              d_[512 + tid + 256] = pb[set_][3]; d_[1024 + tid] = pb[set_][4]; d_[1024 + tid + 256] = pb[set_][5]; }
+        // chunk 0 of A and B came through the generic prologue (ca*, Bl[0]); request the rest
+        GSB_LDB(1, 1)
+        GSB_LDA(1) GSB_LDA(2) GSB_LDA(3)
+        pa[0][0] = ca0; pa[0][1] = ca1; pa[0][2] = ca2; pa[0][3] = ca3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 2 < 4) GSB_LDB(g + 2, g & 1)        // its set was stored to LDS one iteration ago (chunk 0: in the prologue)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short* bl = Bl[g & 1];
+            GSB_STEP(pa[g][0], pa[g][1], boff0)
+            GSB_STEP(pa[g][2], pa[g][3], boff1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < 4) GSB_STB((g + 1) & 1, (g + 1) & 1)
+            lds_barrier();
+        }
+#undef GSB_LDA
+#undef GSB_LDB
+#undef GSB_STB
+    } else
     for (int g = 0; g < ng; ++g) {
         // always issue (the last chunk re-reads itself): a conditional issue would make the in-flight registers a phi and
         // put the wait for the loads right at the merge
@@ -218,6 +254,7 @@ __global__ __launch_bounds__(256, 3) void gemm_sb_kernel(const float* __restrict
 // M = 19200): K = 2 x 384, N = 128: 37 us against 52 us; K = 128, N = 2 x 384: 38 us against 35 us — the launcher
 // picks by the number of column groups.  (Prefetching three chunks ahead and placing the next chunk's split / LDS stores
 // in the MFMA gaps with sched_group_barrier were both measured slower than this plain form.)
+template <int NG>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
 __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
@@ -282,6 +319,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         GSB_MFMA(ah, bh, acc0); GSB_MFMA(ah, bm, acc1); GSB_MFMA(am, bh, acc0);                                 \
         GSB_MFMA(ah, bl_, acc1); GSB_MFMA(al_, bh, acc0); GSB_MFMA(am, bm, acc1);                               \
     }
+    if constexpr (NG == 0) {
     for (int g = 0; g < ng; ++g) {
         G16_ISSUE(min(g + 1, ng - 1))
         __builtin_amdgcn_sched_barrier(0);
@@ -292,6 +330,34 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
         G16_COMMIT((g + 1) & 1)
         lds_barrier();
+    }
+    } else {
+        // One chunk's MFMAs (0.64 us) are shorter than a global load's round trip (~2 us under load): with one chunk of
+        // prefetch every chunk waited for its loads (24 chunks x 2 us = the 48 us this kernel took at K = 2 x 384).  Here
+        // three chunks are in flight in statically named register sets; the loop is fully unrolled because across a loop
+        // back-edge hipcc's waitcnt bookkeeping falls back to vmcnt(0), which would wait for all of them.
+        float4 pa[4];
+        u32x4 pb0[4], pb1[4];
+#define G16_ISSUE_S(g_, set_) { G16_ISSUE(g_) pa[set_] = na; pb0[set_] = nb0; pb1[set_] = nb1; }
+#define G16_COMMIT_S(buf_, set_) { na = pa[set_]; nb0 = pb0[set_]; nb1 = pb1[set_]; G16_COMMIT(buf_) }
+        // chunk 0 is already committed (above); request chunks 1..3
+        if (NG > 1) G16_ISSUE_S(1, 1)
+        if (NG > 2) G16_ISSUE_S(2, 2)
+        if (NG > 3) G16_ISSUE_S(3, 3)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const unsigned short* al = Al[g & 1];
+            const unsigned short* bl = Bl[g & 1];
+            __builtin_amdgcn_sched_barrier(0);
+            G16_STEP(foff0)
+            G16_STEP(foff1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) G16_COMMIT_S((g + 1) & 1, (g + 1) & 3)       // waits for chunk g + 1 only: g + 2, g + 3 stay in flight
+            if (g + 4 < NG) G16_ISSUE_S(g + 4, g & 3)                    // into the set chunk g + 0 ... was committed from
+            lds_barrier();
+        }
+#undef G16_ISSUE_S
+#undef G16_COMMIT_S
     }
 #undef G16_ISSUE
 #undef G16_COMMIT
@@ -320,10 +386,22 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     // few column groups: not enough row tiles to give every SIMD more than one wave -> the 16-wave form
     const bool wide = grid.x >= 2;
     if ((g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide)
-        hipLaunchKernelGGL(gemm_sb_kernel, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode,
-                           g_gsb_dbg & 3);
-    else
-        hipLaunchKernelGGL(gemm_sb16_kernel, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
-                           mode);
+        if (K == 128 && mode != 2 && !(g_gsb_dbg & 32))
+            hipLaunchKernelGGL(gemm_sb_kernel<4>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
+                               mode, g_gsb_dbg & 3);
+        else
+            hipLaunchKernelGGL(gemm_sb_kernel<0>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
+                               mode, g_gsb_dbg & 3);
+    else {
+        const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
+#define G16_GO(NG_) hipLaunchKernelGGL(gemm_sb16_kernel<NG_>, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode)
+        if (g_gsb_dbg & 16) G16_GO(0);
+        else if (ng == 24) G16_GO(24);       // the GRU input gradients: K = 2 x 384
+        else if (ng == 12) G16_GO(12);
+        else if (ng == 8) G16_GO(8);
+        else if (ng == 4) G16_GO(4);
+        else G16_GO(0);
+#undef G16_GO
+    }
     return 0;
 }
