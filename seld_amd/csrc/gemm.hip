@@ -286,7 +286,7 @@ int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda
 // ------------------------------------------------------------------------------------------------
 // TN: out[k1][n] = sum_m A[m][k1] * B[m][n].  A-operand[i=k1][kk=m], B-operand[kk=m][j=n]: both tiles
 // are read with the lane index on the contiguous axis, so the LDS images are plain row-major copies.
-#define TN_MAX_SPLITS 64
+#define TN_MAX_SPLITS 128
 int gemm_tn_max_splits() { return TN_MAX_SPLITS; }
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
                    int M, int K1, int N, int S, int shift, int want_bias) {
     if (M <= 0 || K1 <= 0 || N <= 0) return -1;
-    int splits = (M + 511) / 512;
+    // Rows per split: the loop prefetches one 32-row chunk ahead, i.e. every chunk costs a load round trip (~2 us) unless other
+    // blocks of the CU cover it: short splits = many co-resident blocks (16 KB of LDS each) and few dependent chunks per block
+    int splits = (M + 159) / 160;
     if (splits > TN_MAX_SPLITS) splits = TN_MAX_SPLITS;
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
