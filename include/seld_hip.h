@@ -250,7 +250,8 @@ int seld_k_gemm_pair_k(const float* A0, const float* A1, const float* B0, const 
  * run for the GRU input projections and the heads' first Conv1D. */
 int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                    const float* bias1, float* C0, float* C1, int M, int N, int K, int transb, int act, int mode);
-/* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels); colsum (may be NULL): [N] = sum_m B[m,:]
+/* C[K1,N] = A[M,K1]^T * B[M,N] (weight gradients of Dense / GRU kernels; K1 = 128 with N % 128 == 0 runs on the split-bf16
+ * kernel with transposed LDS reads, gemm_tn_sb.hip, unless seld_k_set_option("gemm_tn_split_bf16", 0)); colsum (may be NULL): [N] = sum_m B[m,:]
  * (the matching bias gradient, produced by the same launch) */
 int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N);
 /* Bidirectional(GRU(128, reset_after=True), merge_mode='mul') recurrence (modules.py:311-316).

@@ -673,7 +673,8 @@ int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float*
 static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A, int lda, const float* Bm, int ldb, int M,
                         int K1, int N, int64_t w_off, int64_t b_off, int S, int shift) {
     int ns = 0;
-    launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1);
+    if (c->gemm_split_bf16 && gemm_tn_sb_usable(A, lda, Bm, ldb, K1, N)) launch_gemm_tn_sb(st, A, lda, Bm, ldb, slab, &ns, M, N, S, shift, 1);
+    else launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1);
     launch_reduce_slabs2(st, slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
 }
 

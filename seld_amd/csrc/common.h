@@ -124,6 +124,10 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
                    int M, int K1, int N, int S, int shift, int want_bias);
+// split-bf16 form with transposed LDS reads (gemm_tn_sb.hip): K1 = 128, N % 128 == 0; same slabs as launch_gemm_tn
+int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N);
+int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,
+                      int shift, int want_bias);
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b);
 int gemm_tn_max_splits();

@@ -10,6 +10,7 @@
 namespace {
 int g_conv64_split_bf16 = 1;
 int g_conv1_split_bf16 = 1;
+int g_gemm_tn_sb = 1;
 struct Scratch {
     std::vector<void*> p;
     float* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, n * sizeof(float) + 256) != hipSuccess) return nullptr; p.push_back(q); return (float*)q; }
@@ -33,6 +34,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_split_bf16")) { g_conv1_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
     return SELD_ERR_INVALID;
 }
@@ -266,7 +268,9 @@ int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int
     float* slab = s.get((size_t)gemm_tn_max_splits() * ((size_t)K1 * N + N));
     if (!slab) return SELD_ERR_NOMEM;
     int ns = 0;
-    if (launch_gemm_tn(0, A, K1, Bm, N, slab, &ns, M, K1, N, 0, 0, colsum ? 1 : 0)) return SELD_ERR_INVALID;
+    if (g_gemm_tn_sb && gemm_tn_sb_usable(A, K1, Bm, N, K1, N)) {
+        if (launch_gemm_tn_sb(0, A, K1, Bm, N, slab, &ns, M, N, 0, 0, colsum ? 1 : 0)) return SELD_ERR_INVALID;
+    } else if (launch_gemm_tn(0, A, K1, Bm, N, slab, &ns, M, K1, N, 0, 0, colsum ? 1 : 0)) return SELD_ERR_INVALID;
     if (colsum) launch_reduce_slabs2(0, slab, ns, (int64_t)K1 * N + N, C, (int64_t)K1 * N, colsum, N);
     else launch_reduce_slabs(0, slab, ns, (int64_t)K1 * N + N, C, (int64_t)K1 * N, 0);
     return done();

@@ -283,20 +283,29 @@ def test_gemm_split_bf16_refuses_unsupported_shapes(seld_lib):
         assert seld_lib.seld_k_gemm_sb(ptr(t), None, ptr(t), None, None, None, ptr(t), None, 64, N, K, 0, 0, 0) != 0
 
 
-@pytest.mark.parametrize("M,K1,N", [(1200, 128, 384), (333, 128, 12), (100, 128, 36), (40, 30, 50)])
+@pytest.mark.parametrize("M,K1,N", [(1200, 128, 384), (333, 128, 12), (100, 128, 36), (40, 30, 50), (37, 128, 128), (19200, 128, 384)])
 def test_gemm_tn(seld_lib, M, K1, N):
+    """Weight-gradient products A^T B (+ column sums).  K1 = 128 with N % 128 == 0 runs on the split-bf16 kernel with transposed
+    LDS reads (gemm_tn_sb.hip) by default; the f32-input kernel is checked on the same inputs."""
     rng = np.random.default_rng(6)
-    A = rng.standard_normal((M, K1)).astype(np.float32)
-    Bm = rng.standard_normal((M, N)).astype(np.float32)
+    A = (rng.standard_normal((M, K1)) * np.exp2(rng.integers(-5, 6, size=(M, K1)))).astype(np.float32)
+    Bm = (rng.standard_normal((M, N)) * np.exp2(rng.integers(-5, 6, size=(M, N)))).astype(np.float32)
     Cd = torch.full((K1, N), float("nan"), device="cuda")
     cs = torch.full((N,), float("nan"), device="cuda")
     Ad, Bd = dev(A), dev(Bm)
-    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), ptr(cs), M, K1, N) == 0
-    check(f"gemm_tn {M,K1,N}", Cd.cpu().numpy(), A.astype(np.float64).T @ Bm.astype(np.float64))
-    check(f"gemm_tn colsum {M,K1,N}", cs.cpu().numpy(), Bm.astype(np.float64).sum(0))
-    Cd.fill_(float("nan"))
-    assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), None, M, K1, N) == 0
-    check(f"gemm_tn (no colsum) {M,K1,N}", Cd.cpu().numpy(), A.astype(np.float64).T @ Bm.astype(np.float64))
+    ref = A.astype(np.float64).T @ Bm.astype(np.float64)
+    for mode in (1, 0):
+        assert seld_lib.seld_k_set_option(b"gemm_tn_split_bf16", mode) == 0
+        try:
+            Cd.fill_(float("nan")); cs.fill_(float("nan"))
+            assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), ptr(cs), M, K1, N) == 0
+            check(f"gemm_tn {M,K1,N} mode{mode}", Cd.cpu().numpy(), ref)
+            check(f"gemm_tn colsum {M,K1,N} mode{mode}", cs.cpu().numpy(), Bm.astype(np.float64).sum(0))
+            Cd.fill_(float("nan"))
+            assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), None, M, K1, N) == 0
+            check(f"gemm_tn (no colsum) {M,K1,N} mode{mode}", Cd.cpu().numpy(), ref)
+        finally:
+            seld_lib.seld_k_set_option(b"gemm_tn_split_bf16", 1)
 
 
 def _gru_ref(gx, U, brec, reverse):
