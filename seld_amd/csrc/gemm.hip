@@ -215,8 +215,19 @@ __global__ __launch_bounds__(64) void heads_weff_kernel(HeadsLin h, float* __res
     const int hd = col >= h.n[0], n = col - (hd ? h.n[0] : 0), N = h.n[hd];
     const float* w1 = h.w1[hd];
     const float* w2 = h.w2[hd];
-    double s = 0.0;
-    for (int j = 0; j < h.Hd; ++j) s += (double)(k < h.K ? w1[(size_t)k * h.Hd + j] : h.b1[hd][j]) * (double)w2[(size_t)j * N + n];
+    // four interleaved partial sums (fixed order): the loads of a row do not wait on one dependent FMA chain
+    const float* a = k < h.K ? w1 + (size_t)k * h.Hd : h.b1[hd];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+#pragma unroll 2
+    for (; j + 3 < h.Hd; j += 4) {
+        s0 += (double)a[j] * (double)w2[(size_t)j * N + n];
+        s1 += (double)a[j + 1] * (double)w2[(size_t)(j + 1) * N + n];
+        s2 += (double)a[j + 2] * (double)w2[(size_t)(j + 2) * N + n];
+        s3 += (double)a[j + 3] * (double)w2[(size_t)(j + 3) * N + n];
+    }
+    for (; j < h.Hd; ++j) s0 += (double)a[j] * (double)w2[(size_t)j * N + n];
+    double s = (s0 + s1) + (s2 + s3);
     if (k == h.K) s += (double)h.b2[hd][n];
     weff[(size_t)k * NT + col] = (float)s;
 }
@@ -239,14 +250,27 @@ __global__ __launch_bounds__(256) void heads_grad_kernel(HeadsGrad h, const floa
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nW1) {                                   // dW1[k][j] = sum_n F[k][c0 + n] W2[j][n]
         const int k = i / h.Hd, j = i - k * h.Hd;
-        double s = 0.0;
-        for (int n = 0; n < N; ++n) s += (double)F[(size_t)k * NT + c0 + n] * (double)h.w2[hd][(size_t)j * N + n];
-        h.dw1[hd][i] = (float)s;
+        double s0 = 0.0, s1 = 0.0;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+            s0 += (double)F[(size_t)k * NT + c0 + n] * (double)h.w2[hd][(size_t)j * N + n];
+            s1 += (double)F[(size_t)k * NT + c0 + n + 1] * (double)h.w2[hd][(size_t)j * N + n + 1];
+        }
+        if (n < N) s0 += (double)F[(size_t)k * NT + c0 + n] * (double)h.w2[hd][(size_t)j * N + n];
+        h.dw1[hd][i] = (float)(s0 + s1);
     } else if (i < nW1 + nW2) {                      // dW2[j][n] = sum_k W1[k][j] F[k][c0 + n] + b1[j] cs[c0 + n]
         const int e = i - nW1, j = e / N, n = e - j * N;
-        double s = (double)h.b1[hd][j] * (double)cs[c0 + n];
-        for (int k = 0; k < h.K; ++k) s += (double)h.w1[hd][(size_t)k * h.Hd + j] * (double)F[(size_t)k * NT + c0 + n];
-        h.dw2[hd][e] = (float)s;
+        double s0 = (double)h.b1[hd][j] * (double)cs[c0 + n], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 3 < h.K; k += 4) {
+            s0 += (double)h.w1[hd][(size_t)k * h.Hd + j] * (double)F[(size_t)k * NT + c0 + n];
+            s1 += (double)h.w1[hd][(size_t)(k + 1) * h.Hd + j] * (double)F[(size_t)(k + 1) * NT + c0 + n];
+            s2 += (double)h.w1[hd][(size_t)(k + 2) * h.Hd + j] * (double)F[(size_t)(k + 2) * NT + c0 + n];
+            s3 += (double)h.w1[hd][(size_t)(k + 3) * h.Hd + j] * (double)F[(size_t)(k + 3) * NT + c0 + n];
+        }
+        for (; k < h.K; ++k) s0 += (double)h.w1[hd][(size_t)k * h.Hd + j] * (double)F[(size_t)k * NT + c0 + n];
+        h.dw2[hd][e] = (float)((s0 + s1) + (s2 + s3));
     } else if (i < nW1 + nW2 + h.Hd) {               // db1[j] = sum_n cs[c0 + n] W2[j][n]
         const int j = i - nW1 - nW2;
         double s = 0.0;
