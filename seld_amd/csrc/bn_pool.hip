@@ -139,6 +139,7 @@ int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, 
 // tensors alone (2 x 79 MB instead of the 1.57 GB of Z for layer 1).  Channels with scale == 0
 // (gamma == 0: y is constant, xhat not recoverable from p) fall back to scanning the window of Z.
 // Thread (slot = tid>>4, g = tid&15) walks pooled pixels slot, slot+16*gridDim, ...
+template <bool EXT>   // EXT: `z` holds the pooled EXTREME of z per window (zext of conv_pool*.hip); p is then not read at all
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ p,
                                                                  const float* __restrict__ dp,
                                                                  const float* __restrict__ mean,
@@ -159,16 +160,23 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
     const bool degenerate = (sc[0] == 0.f) | (sc[1] == 0.f) | (sc[2] == 0.f) | (sc[3] == 0.f);
     float sdy[4] = {0.f, 0.f, 0.f, 0.f}, sdx[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t pp = (int64_t)blockIdx.x * 16 + slot; pp < npool; pp += (int64_t)gridDim.x * 16) {
-        const float4 pv4 = reinterpret_cast<const float4*>(p)[pp * 16 + g];
         const float4 d4 = reinterpret_cast<const float4*>(dp)[pp * 16 + g];
-        const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-        float zsel[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) zsel[c] = (pv[c] - sh[c]) / sc[c];
-        if (PT < 0) {        // z holds the pooled EXTREME of z per window (zext of conv_pool.hip): the routed element itself
+        const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        float pv[4], zsel[4];
+        if (EXT) {
+            // the routed element itself; the pooled activation is max(0, fmaf(zext, scale, shift)) (bn_relu_ext), so its sign —
+            // all that is needed of it here — comes from the same fmaf: one 79 MB read fewer than loading p
             const float4 ze = reinterpret_cast<const float4*>(z)[pp * 16 + g];
             zsel[0] = ze.x; zsel[1] = ze.y; zsel[2] = ze.z; zsel[3] = ze.w;
-        } else if (degenerate) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pv[c] = fmaf(zsel[c], sc[c], sh[c]);
+        } else {
+            const float4 pv4 = reinterpret_cast<const float4*>(p)[pp * 16 + g];
+            pv[0] = pv4.x; pv[1] = pv4.y; pv[2] = pv4.z; pv[3] = pv4.w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zsel[c] = (pv[c] - sh[c]) / sc[c];
+        }
+        if (!EXT && degenerate) {
             const int fp = (int)(pp % Wp);
             const int tp = (int)((pp / Wp) % Hp);
             const int b = (int)(pp / ((int64_t)Wp * Hp));
@@ -207,9 +215,13 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, co
     const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
     int64_t blocks = (npool + 15) / 16;
     if (blocks > BN_MAX_PARTIAL) blocks = BN_MAX_PARTIAL;
-    // z_is_pooled_extreme: `z` is zext [B,H/pt,W/pf,C] (no full-resolution z exists); signalled to the kernel as PT < 0
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, p, dp, mean, invstd, scale,
-                       shift, partial, npool, H, W, z_is_pooled_extreme ? -pt : pt, pf);
+    // z_is_pooled_extreme: `z` is zext [B,H/pt,W/pf,C] (no full-resolution z exists): the EXT instantiation, which never reads p
+    if (z_is_pooled_extreme)
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, z, p, dp, mean, invstd, scale,
+                           shift, partial, npool, H, W, pt, pf);
+    else
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, z, p, dp, mean, invstd, scale,
+                           shift, partial, npool, H, W, pt, pf);
     *npartial = (int)blocks;
     return 0;
 }
