@@ -130,15 +130,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from oracle import seldnet_oracle as O  # synthetic data generator only; never in the timed path
     from seld_amd import losses, models, train
+    from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only
 
     B, T = args.batch, args.frames
     model = models.seldnet((B, T, 64, 7), SELDNET_CONFIG, device=local)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         model.set_option(key, int(val))
-    x, ys, yd = O.synthetic_batch(B, T, seed=1234 + rank)
+    x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
     dev = torch.device("cuda", local)
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
     opt = train.Adam(1e-3)

@@ -79,3 +79,12 @@ def test_dataset_with_device_transforms_keeps_labels_unsplit(tmp_path):
     assert xb.shape == (8, 300, 64, 7) and yb.shape == (8, 60, 48) and len(ds.device_transforms) == 1
     with pytest.raises(ValueError):
         dl.seldnet_data_to_dataloader(x, y, sample_transforms=[lambda a, b: (a, b)])
+
+
+def test_synthetic_batch_matches_the_oracles_generator():
+    """bench.py draws its batch from seld_amd.synthetic (the product side may not import oracle/); the oracle keeps its own copy
+    for the tests: both must produce the same arrays from a seed."""
+    from oracle.seldnet_oracle import synthetic_batch as oracle_batch
+    from seld_amd.synthetic import synthetic_batch
+    for got, want in zip(synthetic_batch(2, 50, seed=7), oracle_batch(2, 50, seed=7)):
+        assert got.dtype == want.dtype and np.array_equal(got, want)
