@@ -290,10 +290,12 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     // matrix); whenever the main stream has a kernel ready it should get the CUs
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    // the events only order work between streams of THIS device: no system-scope fence on record (it cost ~4 us of main-stream
+    // bubble per fork); host reads go through hipStreamSynchronize, peers through RCCL kernels that run on this device
     if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
     }
