@@ -75,6 +75,8 @@ struct seld_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
+    float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
+    int fin_doa_loss = 0;
     std::vector<void*> allocs;
     std::string err;
     int prof = 0;   // 0 off, 1 major kernel groups, 2 every group
@@ -488,17 +490,61 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
     const int rows = B * S;
-    if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
-    if (heads_lin(c) && prepare_heads_weff(c, st)) return fail(c, SELD_ERR_UNSUPPORTED, "heads_weff");
-    if (c->conv64_split_bf16) {   // 64 -> 64 conv weights: forward planes and (when a backward follows) the flipped ones, one launch
-        const float* w[8]; unsigned short* dst[8]; int flip[8];
-        int n = 0;
-        for (size_t i = 1; i < c->conv.size(); ++i) {
-            if (n + 2 > 8) { launch_split_weights_batch(st, n, w, dst, flip); n = 0; }
-            w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_fwd[i]; flip[n++] = 0;
-            if (save) { w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_bwd[i]; flip[n++] = 1; }
+    // every weight-only pre-pass of the step in ONE launch (prep.hip): the split-bf16 planes of the GEMM and 64 -> 64 conv
+    // weights (with the gradient orientations / flipped taps when a backward follows) and the folded head weights
+    {
+        GemmSplitJobs a; SplitWeightJobs b; HeadsLin h;
+        int na = 0, nb = 0;
+        bool fits = true;
+        auto adda = [&](const float* w, unsigned short* d, int ld, int transb, int k, int nn) {
+            if (na == GSB_MAX_JOBS) { fits = false; return; }
+            a.src[na] = w; a.dst[na] = d; a.ldb[na] = ld; a.transb[na] = transb; a.K[na] = k; a.N[na] = nn; ++na;
+        };
+        for (size_t i = 0; i < c->gru.size(); ++i) {
+            const GruL& G = c->gru[i];
+            if (!gru_sb(c, G)) continue;
+            for (int d = 0; d < 2; ++d) {
+                adda(c->params + G.k_off[d], c->ksp_fwd[i][d], 384, 0, G.in_feat, 384);                // gx = feat K
+                if (save) adda(c->params + G.k_off[d], c->ksp_bwd[i][d], 384, 1, 384, G.in_feat);      // din = dgx K^T
+            }
         }
-        if (n && launch_split_weights_batch(st, n, w, dst, flip)) return fail(c, SELD_ERR_UNSUPPORTED, "split_weights");
+        if (heads_sb(c) && !heads_lin(c))
+            for (int hd = 0; hd < 2; ++hd) {
+                const DenseL& D = c->heads[hd].layers[0];
+                adda(c->params + D.w_off, c->h0sp_fwd[hd], D.out, 0, D.in, D.out);
+                if (save) adda(c->params + D.w_off, c->h0sp_bwd[hd], D.out, 1, D.out, D.in);
+            }
+        a.njobs = na;
+        if (c->conv64_split_bf16)
+            for (size_t i = 1; i < c->conv.size(); ++i) {
+                if (nb + 2 > 8) { fits = false; break; }
+                b.w[nb] = c->params + c->conv[i].w_off; b.dst[nb] = c->wsp_fwd[i]; b.flip[nb++] = 0;
+                if (save) { b.w[nb] = c->params + c->conv[i].w_off; b.dst[nb] = c->wsp_bwd[i]; b.flip[nb++] = 1; }
+            }
+        const bool lin = heads_lin(c);
+        if (lin)
+            for (int hd = 0; hd < 2; ++hd) {
+                const DenseL &L0 = c->heads[hd].layers[0], &L1 = c->heads[hd].layers[1];
+                h.w1[hd] = c->params + L0.w_off; h.b1[hd] = c->params + L0.b_off; h.w2[hd] = c->params + L1.w_off;
+                h.b2[hd] = c->params + L1.b_off; h.n[hd] = L1.out;
+                h.K = L0.in; h.Hd = L0.out;
+            }
+        if (fits && (!lin || h.K + 1 <= 4 * 144)) {
+            if (launch_weight_prep(st, a, na, b, nb, h, lin ? c->weff : nullptr)) return fail(c, SELD_ERR_UNSUPPORTED, "weight_prep");
+        } else {      // more jobs than one launch takes (not a seldnet.json shape): the stand-alone kernels
+            if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
+            if (lin && prepare_heads_weff(c, st)) return fail(c, SELD_ERR_UNSUPPORTED, "heads_weff");
+            if (c->conv64_split_bf16) {
+                const float* w[8]; unsigned short* dst[8]; int flip[8];
+                int n = 0;
+                for (size_t i = 1; i < c->conv.size(); ++i) {
+                    if (n + 2 > 8) { launch_split_weights_batch(st, n, w, dst, flip); n = 0; }
+                    w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_fwd[i]; flip[n++] = 0;
+                    if (save) { w[n] = c->params + c->conv[i].w_off; dst[n] = c->wsp_bwd[i]; flip[n++] = 1; }
+                }
+                if (n && launch_split_weights_batch(st, n, w, dst, flip)) return fail(c, SELD_ERR_UNSUPPORTED, "split_weights");
+            }
+        }
     }
     const float* in = x;
     for (size_t i = 0; i < c->conv.size(); ++i) {
@@ -627,7 +673,7 @@ int seld_forward(seld_ctx* c, const float* x, float* sed, float* doa, int traini
 }
 
 static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg, float* sloss,
-                      float* dloss, bool want_grads) {
+                      float* dloss, bool want_grads, bool defer_finalize = false) {
     hipStream_t st = c->stream;
     const int rows = c->B * c->S, nc = c->arch.n_classes;
     if (cfg->doa_loss != SELD_DOA_MSE && cfg->doa_loss != SELD_DOA_MMSE) return fail(c, SELD_ERR_INVALID, "bad doa_loss");
@@ -649,7 +695,8 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
                   cfg->w_doa, cfg->sed_grad_scale, c->den_dev, sl, dl,
                   want_grads ? (lin ? c->dy_all : c->heads[0].layers.back().dy) : nullptr,
                   want_grads ? (lin ? c->dy_all + n0 : c->heads[1].layers.back().dy) : nullptr, c->loss_scratch, c->B, c->S, nc,
-                  lin ? nt : 0, lin ? nt : 0);
+                  lin ? nt : 0, lin ? nt : 0, defer_finalize ? 1 : 0);
+    if (defer_finalize) { c->fin_sl = sl; c->fin_dl = dl; c->fin_doa_loss = cfg->doa_loss; }
     return check_launch(c, "losses");
 }
 
@@ -849,6 +896,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
             dp = c->conv[i - 1].dp;
         }
     }
+    // the deferred loss scalars (run_losses): the side stream is ordered behind the losses kernel by every fork above
+    if (c->fin_sl)
+        launch_losses_finalize(c->side, c->fin_doa_loss, c->den_dev, c->fin_sl, c->fin_dl, c->loss_scratch, c->B, c->S, c->arch.n_classes);
+    c->fin_sl = nullptr;
     // join: the side stream's weight gradients must be complete before Adam / the DP all-reduce
     hipEventRecord(c->ev_join, c->side);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
@@ -871,7 +922,8 @@ int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const fl
     HIPCHK(c, hipSetDevice(c->device));
     int rc = forward_impl(c, x, sed, doa, 1, true);
     if (rc) return rc;
-    rc = run_losses(c, y_sed, y_doa, cfg, sloss, dloss, true);
+    // the scalar loss values are finalized on the side stream at the end of the backward pass: nothing in it waits for them
+    rc = run_losses(c, y_sed, y_doa, cfg, sloss, dloss, true, true);
     if (rc) return rc;
     return backward_impl(c, x);
 }

@@ -27,6 +27,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define SELD_BN_EPS 1e-3f
 #define SELD_BN_MOMENTUM 0.99f
 
+// ---- per-step weight pre-passes: job descriptors (kernel arguments by value) and the merged launch (prep.hip) ----------------
+#define GSB_MAX_JOBS 16
+struct GemmSplitJobs {
+    int njobs;
+    const float* src[GSB_MAX_JOBS];
+    unsigned short* dst[GSB_MAX_JOBS];
+    int ldb[GSB_MAX_JOBS], transb[GSB_MAX_JOBS], K[GSB_MAX_JOBS], N[GSB_MAX_JOBS];
+};
+struct SplitWeightJobs { const float* w[8]; unsigned short* dst[8]; int flip[8]; };
+struct HeadsLin { const float *w1[2], *b1[2], *w2[2], *b2[2]; int n[2]; int K, Hd; };
+// one launch for all three kinds (any of them may be empty: na / nb = 0, weff = nullptr)
+int launch_weight_prep(hipStream_t st, const GemmSplitJobs& a, int na, const SplitWeightJobs& b, int nb, const HeadsLin& h, float* weff);
+
 // ---- launcher prototypes (implemented in the .hip files; used by api.hip) -------------------
 struct ConvFirstArgs { const float* x; const float* w; const float* bias; float* z; float* stat_partial; int B, H; };
 
@@ -146,7 +159,9 @@ int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scrat
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
                   float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, int ld_sed = 0,
-                  int ld_doa = 0);
+                  int ld_doa = 0, int defer_finalize = 0);
+int launch_losses_finalize(hipStream_t st, int doa_loss, const float* den_dev, float* sloss, float* dloss, float* scratch, int B, int S,
+                           int nc);
 int loss_scratch_floats(int rows);
 int launch_adam(hipStream_t st, float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
                 float beta1, float beta2, float eps);

@@ -13,6 +13,7 @@
 // MFMAs, split at commit time into three bf16 planes in LDS (row stride 144 B: conflict-free 16-B fragment
 // reads); the tap's weights come pre-split and pre-transposed ([co][ci]) from split_weights_kernel.
 #include "common.h"
+#include "prep.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -53,24 +54,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 
 // several weight tensors in one launch; flip = the input-gradient form: tap 8 - tap with in / out swapped
 // (wt[tap][co][ci] = w[8 - tap][ci][co], conv.hip flip_weights_kernel) split directly from the unflipped tensor
-struct SplitWeightJobs { const float* w[8]; unsigned short* dst[8]; int flip[8]; };
-__global__ __launch_bounds__(256) void split_weights_batch_kernel(SplitWeightJobs jobs) {
-    const int job = blockIdx.y;
-    const float* __restrict__ w = jobs.w[job];
-    unsigned short* __restrict__ wsp = jobs.dst[job];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 9 * 4096) return;
-    const int tap = idx >> 12, rem = idx & 4095, out = rem >> 6, in = rem & 63;
-    const float x = jobs.flip[job] ? w[(8 - tap) * 4096 + out * 64 + in] : w[tap * 4096 + in * 64 + out];
-    const unsigned u = __float_as_uint(x);
-    const float r = x - __uint_as_float(u & 0xffff0000u);
-    const unsigned v = __float_as_uint(r);
-    const float s = r - __uint_as_float(v & 0xffff0000u);
-    unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;
-    o[0] = (unsigned short)(u >> 16);
-    o[4096] = (unsigned short)(v >> 16);
-    o[2 * 4096] = (unsigned short)(__float_as_uint(s) >> 16);
-}
+__global__ __launch_bounds__(256) void split_weights_batch_kernel(SplitWeightJobs jobs) { split_weights_body(jobs, blockIdx.y, blockIdx.x); }
 
 int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, unsigned short* const* dst, const int* flip) {
     if (n <= 0 || n > 8) return -1;

@@ -6,6 +6,7 @@
 //   reduce_slabs_kernel       out[i] (+)= sum_z slab[z][i]                          (deterministic combine)
 // v_mfma_f32_32x32x2_f32 is exact fp32, so these meet the 1e-4 parity bar without a split scheme.
 #include "common.h"
+#include "prep.h"
 
 #define GT_LDA 65  // transposed A tile: [k][row], +1 pad (transposing b32 writes are <=2-way conflicted)
 
@@ -207,30 +208,7 @@ int launch_gemm_heads(hipStream_t st, const float* A, int lda, const float* Bm, 
 // Weff = W1 W2, beff = b1 W2 + b2, and every gradient follows from F = x^T dy2 and cs = colsum(dy2) (api.hip, heads_fused):
 //   dW2 = W1^T F + b1 (x) cs,  db2 = cs,  dW1 = F W2^T,  db1 = cs W2^T,  dx = dy2 Weff^T.
 // weff_all [K + 1][NT]: rows 0..K-1 = [W1s W2s | W1d W2d], row K = [b1s W2s + b2s | b1d W2d + b2d]   (NT = n0 + n1)
-struct HeadsLin { const float *w1[2], *b1[2], *w2[2], *b2[2]; int n[2]; int K, Hd; };
-__global__ __launch_bounds__(64) void heads_weff_kernel(HeadsLin h, float* __restrict__ weff) {
-    const int k = blockIdx.x, NT = h.n[0] + h.n[1];        // row k of Weff (k == K: the bias row)
-    const int col = threadIdx.x;
-    if (col >= NT) return;
-    const int hd = col >= h.n[0], n = col - (hd ? h.n[0] : 0), N = h.n[hd];
-    const float* w1 = h.w1[hd];
-    const float* w2 = h.w2[hd];
-    // four interleaved partial sums (fixed order): the loads of a row do not wait on one dependent FMA chain
-    const float* a = k < h.K ? w1 + (size_t)k * h.Hd : h.b1[hd];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int j = 0;
-#pragma unroll 2
-    for (; j + 3 < h.Hd; j += 4) {
-        s0 += (double)a[j] * (double)w2[(size_t)j * N + n];
-        s1 += (double)a[j + 1] * (double)w2[(size_t)(j + 1) * N + n];
-        s2 += (double)a[j + 2] * (double)w2[(size_t)(j + 2) * N + n];
-        s3 += (double)a[j + 3] * (double)w2[(size_t)(j + 3) * N + n];
-    }
-    for (; j < h.Hd; ++j) s0 += (double)a[j] * (double)w2[(size_t)j * N + n];
-    double s = (s0 + s1) + (s2 + s3);
-    if (k == h.K) s += (double)h.b2[hd][n];
-    weff[(size_t)k * NT + col] = (float)s;
-}
+__global__ __launch_bounds__(64) void heads_weff_kernel(HeadsLin h, float* __restrict__ weff) { heads_weff_body(h, weff, blockIdx.x, threadIdx.x); }
 int launch_heads_weff(hipStream_t st, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
                       const int* n, int K, int Hd, float* weff) {
     if (n[0] + n[1] > 64) return -1;

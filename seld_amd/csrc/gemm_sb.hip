@@ -14,13 +14,13 @@
 // barrier per chunk; the next chunk's A rows and B planes are in flight (registers) while the current one is
 // multiplied.  Column groups are the fast grid index so the blocks that share rows of A run together.
 #include "common.h"
+#include "prep.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define GSB_KC 32
 #define GSB_BN 128
-#define GSB_MAX_JOBS 16
 
 // exact 3-way truncation split of two floats, packed as bf16 pairs (element 0 in the low half) — as conv_sb.hip
 __device__ __forceinline__ void gsb_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
@@ -38,33 +38,7 @@ __device__ __forceinline__ void gsb_split3_pair(float x0, float x1, unsigned& h,
 // piece' = piece ^ ((n >> 2) & 3): the image of one (chunk, plane, 128-column group) is the 8 KB the GEMM copies
 // verbatim into LDS, already swizzled so that each 16-lane group of a ds_read_b128 (lanes {0-3,12-15,20-27}, ...: 64-B rows put
 // column n on slot 4 (n & 3) + piece' of the 256-B bank row) covers all 16 slots.
-struct GemmSplitJobs {
-    int njobs;
-    const float* src[GSB_MAX_JOBS];
-    unsigned short* dst[GSB_MAX_JOBS];
-    int ldb[GSB_MAX_JOBS], transb[GSB_MAX_JOBS], K[GSB_MAX_JOBS], N[GSB_MAX_JOBS];
-};
-
-__global__ __launch_bounds__(256) void gemm_split_b_kernel(GemmSplitJobs jobs) {
-    const int job = blockIdx.y;
-    const int K = jobs.K[job], N = jobs.N[job], ldb = jobs.ldb[job], transb = jobs.transb[job];
-    const float* __restrict__ src = jobs.src[job];
-    unsigned short* __restrict__ dst = jobs.dst[job];
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < K * N; idx += gridDim.x * 256) {
-        // the fast index follows the contiguous axis of the source
-        const int k = transb ? idx % K : idx / N, n = transb ? idx / K : idx % N;
-        const float x = transb ? src[(size_t)n * ldb + k] : src[(size_t)k * ldb + n];
-        const unsigned u = __float_as_uint(x);
-        const float r = x - __uint_as_float(u & 0xffff0000u);
-        const unsigned v = __float_as_uint(r);
-        const float s = r - __uint_as_float(v & 0xffff0000u);
-        const int c = k >> 5, kk = k & 31, piece = (kk >> 3) ^ ((n >> 2) & 3);
-        unsigned short* o = dst + ((size_t)c * 3 * N + n) * GSB_KC + piece * 8 + (kk & 7);
-        o[0] = (unsigned short)(u >> 16);
-        o[(size_t)N * GSB_KC] = (unsigned short)(v >> 16);
-        o[(size_t)2 * N * GSB_KC] = (unsigned short)(__float_as_uint(s) >> 16);
-    }
-}
+__global__ __launch_bounds__(256) void gemm_split_b_kernel(GemmSplitJobs jobs) { gemm_split_b_body(jobs, blockIdx.y, blockIdx.x, gridDim.x); }
 
 size_t gemm_sb_split_elems(int K, int N) { return (size_t)3 * K * N; }   // bf16 elements of one pre-split operand
 

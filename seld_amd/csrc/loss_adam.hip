@@ -136,10 +136,12 @@ __global__ __launch_bounds__(64) void losses_finalize_kernel(const double* __res
     if (doa_loss == 1 && dloss) dloss[0] = (float)(s1 / (double)den_dev[0]);
 }
 
+int launch_losses_finalize(hipStream_t st, int doa_loss, const float* den_dev, float* sloss, float* dloss, float* scratch, int B, int S,
+                           int nc);
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,
                   float* sloss, float* dloss, float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, int ld_sed,
-                  int ld_doa) {
+                  int ld_doa, int defer_finalize) {
     if (ld_sed <= 0) ld_sed = nc;          // row strides of the two gradient outputs (a shared [rows][4 nc] buffer: 4 nc each)
     if (ld_doa <= 0) ld_doa = 3 * nc;
     const int rows = B * S;
@@ -150,8 +152,17 @@ int launch_losses(hipStream_t st, const float* sed, const float* doa, const floa
     const int nblocks = (rows + 63) / 64;
     hipLaunchKernelGGL(losses_kernel, dim3(nblocks), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss, coef_sed, w_doa, den_dev,
                        doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc, ld_sed, ld_doa);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, st, blockpart, nblocks, doa_loss, (double)rows * nc, den_dev,
-                       sloss, dloss);
+    if (!defer_finalize) launch_losses_finalize(st, doa_loss, den_dev, sloss, dloss, scratch, B, S, nc);
+    return 0;
+}
+
+// the scalar loss values from the per-block partials launch_losses left in `scratch` (which must be untouched in between): a
+// training step runs this after the backward pass — nothing in the backward waits for the scalars
+int launch_losses_finalize(hipStream_t st, int doa_loss, const float* den_dev, float* sloss, float* dloss, float* scratch, int B, int S,
+                           int nc) {
+    const int rows = B * S, nblocks = (rows + 63) / 64;
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const double*>(scratch), nblocks, doa_loss,
+                       (double)rows * nc, den_dev, sloss, dloss);
     return 0;
 }
 
