@@ -35,6 +35,10 @@ PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 SPLIT_BF16_GROUPS = {"conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "conv3_fwd", "conv3_dgrad", "conv3_wgrad",
                      "gru_inproj_gemm", "gru_bwd_gemms"}   # with the default options (seld_set_option)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+# GRU recurrence (gru.hip): S dependent steps per launch; the floor of a step is the VALU issue time of its two waves per
+# SIMD — per wave 48 v_pk_fma_f32 + ~23 (forward) / ~37 (BPTT) other VALU + 6 (0) transcendental instructions at the
+# measured two-waves-per-SIMD issue rates (tools/valu_probe.hip: 6.5 / 5.9 / 8 cycles) — no LDS, barrier or dependency stall.
+GRU_ISSUE_CYCLES_PER_STEP = {"gru_fwd": 2 * (48 * 6.5 + 23 * 5.9 + 6 * 8), "gru_bwd": 2 * (48 * 6.5 + 37 * 5.9)}
 
 
 def kernel_work(name, B, T, F=64, C=7):
@@ -83,31 +87,100 @@ def host_cores():
     return n
 
 
-def cpu_baseline(B, T, steps):
-    """Oracle train step (PyTorch-CPU fp32 restatement) on the host cores: bounded sample."""
+def cpu_baseline(B_gpu, T, steps, warmup, budget_s):
+    """the oracle's train step (PyTorch-CPU fp32 restatement of the reference semantics, NOT the
+    reference's TensorFlow) on the host cores: `warmup` warm-ups, median of `steps` steps, at B=2 (BASELINE configs[0],
+    the reference's own CPU-runnable case) and at the GPU batch.  The GPU-batch leg times fewer steps (>= 3) when `steps`
+    of them would exceed `budget_s`, so that the default bench still finishes in minutes; what was run is in `sample`."""
     from oracle import seldnet_oracle as O
     spec = O.Spec.from_config(SELDNET_CONFIG)
     w, st = O.random_weights(spec, 0)
-    x, ys, yd = O.synthetic_batch(B, T)
     cores = host_cores()
     torch.set_num_threads(cores)
-    O.train_step(spec, w, st, x, ys, yd)  # warm-up
-    ts = []
-    for _ in range(steps):
+
+    def leg(B, n_warm, n_steps, budget):
+        x, ys, yd = O.synthetic_batch(B, T)
         t0 = time.perf_counter()
         O.train_step(spec, w, st, x, ys, yd)
-        ts.append(time.perf_counter() - t0)
-    best = float(np.median(ts))
-    return {"value": B / best, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"oracle train_step, B={B} clips of [T={T},64,7], median of {steps} steps after 1 warm-up "
-                      f"({best:.2f} s/step, {cores} threads); PyTorch-CPU restatement of the reference semantics, not the reference's TF"}
+        first = time.perf_counter() - t0
+        if budget is not None:
+            n_steps = max(3, min(n_steps, int(budget / max(first, 1e-3)) - n_warm))
+            n_warm = max(1, min(n_warm, int(0.25 * budget / max(first, 1e-3))))
+        for _ in range(n_warm - 1):
+            O.train_step(spec, w, st, x, ys, yd)
+        ts = []
+        for _ in range(n_steps):
+            t0 = time.perf_counter()
+            O.train_step(spec, w, st, x, ys, yd)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        return {"value": round(B / med, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+                "sample": f"oracle train_step, B={B} clips of [T={T},64,7], median of {n_steps} steps after {n_warm} warm-ups "
+                          f"({med:.2f} s/step, {cores} threads); PyTorch-CPU restatement of the reference semantics, not the reference's TF"}
+
+    small = leg(2, warmup, steps, None)
+    big = leg(B_gpu, warmup, steps, budget_s) if B_gpu != 2 else small
+    big["b2"] = small         # configs[0]: the plumbing case
+    return big
+
+
+def box_peaks(dev_index):
+    """peaks read on the box, printed next to the constants the roofline fractions use.  Derived from the
+    device properties (CU count, engine / memory clocks, bus width): fp32 MFMA = CUs x 4 SIMDs x 64 FLOP/clk x clock; dense
+    bf16 MFMA = 16 x that; HBM = 2 x memory clock x bus width / 8."""
+    p = torch.cuda.get_device_properties(dev_index)
+    out = {"name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+           "total_memory_GB": round(p.total_memory / 1e9, 1)}
+    clk = getattr(p, "clock_rate", None)                 # kHz
+    mclk, bus = getattr(p, "memory_clock_rate", None), getattr(p, "memory_bus_width", None)
+    if clk:
+        out["engine_clock_MHz"] = clk / 1e3
+        out["derived_f32_mfma_TFLOPS"] = round(p.multi_processor_count * 4 * 64 * clk * 1e3 / 1e12, 1)
+        out["derived_bf16_mfma_TFLOPS"] = round(16 * p.multi_processor_count * 4 * 64 * clk * 1e3 / 1e12, 1)
+    if mclk and bus:
+        out["memory_clock_MHz"], out["memory_bus_bits"] = mclk / 1e3, bus
+        out["derived_hbm_GBps"] = round(2 * mclk * 1e3 * bus / 8 / 1e9, 1)
+    out["constants_used"] = {"f32_mfma_TFLOPS": PEAK_F32_MFMA_TFLOPS, "bf16_mfma_TFLOPS": PEAK_BF16_MFMA_TFLOPS,
+                             "split_bf16_TFLOPS": round(PEAK_SPLIT_BF16_TFLOPS, 1), "hbm_GBps": PEAK_HBM_GBPS,
+                             "source": "/opt/skills/guides/MI355X_MICROARCH.md"}
+    return out
+
+
+def features_leg(dev, clips=8, reps=6):
+    """The on-device feature stage (feature_extractor.extract_features, feature_extractor.py:53-88) on 60-s FOA clips
+    [4, 1 440 000] -> [3001, 64, 7]: clips/s and the achieved ALGORITHMIC HBM rate (23 040 000 B of wav in +
+    5 376 000 B of features out = 28 416 000 B per clip) of the extraction launches, timed with HIP events on their stream."""
+    from seld_amd import feature_extractor as FE
+    n = 1440000
+    rng = np.random.default_rng(0)
+    wavs = [torch.as_tensor((rng.standard_normal((4, n)) * 0.1).astype(np.float32)).to(dev) for _ in range(clips)]
+    fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=dev.index)
+    st = torch.cuda.current_stream(dev)
+    for wv in wavs[:2]:
+        fx(wv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.synchronize()
+    e0.record(st)           # the extraction launches go to torch's current stream (FeatureExtractor.__call__)
+    for _ in range(reps):
+        for wv in wavs:
+            out = fx(wv)
+    e1.record(st)
+    st.synchronize()
+    per = e0.elapsed_time(e1) / 1e3 / (reps * clips)
+    bytes_clip = 4 * n * 4 + 3000 * 64 * 7 * 4
+    assert tuple(out.shape) == (3001, 64, 7) and bool(torch.isfinite(out).all())
+    ach = bytes_clip / per / 1e9
+    return {"stage": "feature_extractor foa n_fft 1024 / win 960 / hop 480 -> [3001,64,7], 60-s clips resident in HBM",
+            "clips_per_s": round(1 / per, 1), "ms_per_clip": round(per * 1e3, 4), "algorithmic_bytes_per_clip": bytes_clip,
+            "roofline": {"kernel": "feat_frame", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps (default 40: a >= 100 ms timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE.json configs[1])")
     ap.add_argument("--frames", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,8 +188,11 @@ def main():
     ap.add_argument("--timing-level", type=int, default=1, help="1: major kernel groups (default), 2: every group")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=0|1",
                     help="kernel-selection option of the C library (seld_set_option), for A/B runs; the default build is the product")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="cpu_baseline: timed steps per batch size (median), after --cpu-warmup")
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+                    help="cpu_baseline at the GPU batch: fewer than --cpu-steps steps are timed (never fewer than 3) if they would exceed this")
+    ap.add_argument("--no-features", action="store_true", help="skip the feature-stage leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,12 +242,31 @@ def main():
         y_p, sl, dl = train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     model.lib.seld_profile_enable(model.ctx, 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.isfinite(float(sl.item())), "non-finite loss"
+    comm = None
+    if world > 1:
+        # exposed communication per step and rank: the same steps again without the gradient all-reduce (timing aid only:
+        # replicas then drift apart, nothing is reported from them but the time)
+        model.lib.seld_profile_enable(model.ctx, 0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt, allreduce=False)
+        torch.cuda.synchronize()
+        local_no_comm = time.perf_counter() - t1
+        barrier()
+        both = torch.tensor([elapsed_local, local_no_comm], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(both) for _ in range(world)]
+        dist.all_gather(allr, both)
+        comm = {"exposed_ms_per_step_by_rank": [round(float((a[0] - a[1]).item()) / args.steps * 1e3, 4) for a in allr],
+                "ms_per_step_without_allreduce_by_rank": [round(float(a[1].item()) / args.steps * 1e3, 4) for a in allr],
+                "note": "timed region repeated with the gradient all-reduce skipped; exposed = with - without, per rank"}
 
     if rank == 0:
         import ctypes as C
@@ -182,6 +277,8 @@ def main():
             model.lib.seld_profile_get(model.ctx, i, name, 64, C.byref(n), C.byref(ms))
             kernels.append((name.value.decode(), int(n.value), float(ms.value)))
         roofline, breakdown, per_kernel = None, {}, {}
+        mhz = C.c_double()
+        valu_clock_mhz = float(mhz.value) if model.lib.seld_k_valu_clock_mhz(2 * B, C.byref(mhz)) == 0 else None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
 
@@ -199,10 +296,18 @@ def main():
                 path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
             else:
                 ach, peak, unit = amount / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s"
+            extra = {}
+            if name in GRU_ISSUE_CYCLES_PER_STEP and valu_clock_mhz:
+                # the recurrence is a serial chain on 2B of the 256 CUs: HBM (what north_star asks to see) is not what bounds it
+                floor_ms = (T // 5) * GRU_ISSUE_CYCLES_PER_STEP[name] / (valu_clock_mhz * 1e3)
+                extra = {"latency_floor_ms": round(floor_ms, 4), "frac_of_latency_floor": round(floor_ms / (avg_s * 1e3), 4),
+                         "latency_model": f"{T // 5} dependent steps x {GRU_ISSUE_CYCLES_PER_STEP[name]:.0f} VALU issue cycles "
+                                          f"(2 waves per SIMD) / {valu_clock_mhz:.0f} MHz measured under a VALU-only load on {2 * B} CUs",
+                         "cycles_per_step": round(avg_s * valu_clock_mhz * 1e6 / (T // 5), 1)}
             return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name, {}).get("hbm_bytes_per_launch"),
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": n // args.steps,
-                    **({"mfma_path": path} if path else {})}
+                    **({"mfma_path": path} if path else {}), **extra}
 
         if kernels:
             for name, n, ms in kernels:
@@ -222,8 +327,15 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
             "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
         }
+        out["peaks_on_box"] = box_peaks(local)
+        if comm:
+            out["comm"] = comm
+        if world == 1 and not args.no_features:
+            out["features"] = features_leg(dev)
+            ft = traffic_tab.get("feat_frame", {}).get("hbm_bytes_per_launch")
+            out["features"]["roofline"]["traffic"] = ft
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

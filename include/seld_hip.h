@@ -272,6 +272,16 @@ int seld_k_losses(const float* sed, const float* doa, const float* y_sed, const 
 /* Keras Adam update (train.py:311,34); step is 1-based */
 int seld_k_adam(float* theta, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                 float beta2, float eps, int64_t step);
+/* Test aid (tests/test_model_gpu.py::test_parity_given_identical_routing): after seld_train_fwd_bwd, the routing decision the
+ * backward pass took for every pooled element of conv block `block` — MaxPooling2D's argmax as window position row*pf + col and
+ * ReLU's gate (pooled value > 0) — as two device byte arrays [B, H/pt, W/pf, 64].  MaxPoolGrad / ReluGrad of the reference
+ * (layers.py:33-37 + simple_conv_block) take the same decisions from their own fp32 values; windows whose two largest elements
+ * are within one rounding of each other may decide differently.  Synchronises the ctx stream. */
+int seld_debug_pool_routing(seld_ctx* ctx, int block, unsigned char* pos, unsigned char* gate);
+/* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`
+ * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
+ * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */
+int seld_k_valu_clock_mhz(int blocks, double* mhz);
 
 #ifdef __cplusplus
 }

@@ -187,6 +187,13 @@ def maxpool_nhwc(a, pool):
     return F.max_pool2d(a.permute(0, 3, 1, 2), kernel_size=tuple(pool), stride=tuple(pool)).permute(0, 2, 3, 1)
 
 
+def pool_windows(y, pool):
+    """[B,H,W,C] -> [B,H/pt,W/pf,C,pt*pf]: the elements of every pooling window, position = row*pf + col."""
+    B, H, W, C = y.shape
+    pt, pf = pool
+    return y.reshape(B, H // pt, pt, W // pf, pf, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // pt, W // pf, C, pt * pf)
+
+
 def gru_direction(x, kernel, rec_kernel, bias, reverse: bool, return_aux: bool = False):
     """Keras GRU(units, reset_after=True, return_sequences=True) over [B,S,I] (modules.py:312-315).
     reverse=True is Bidirectional's backward layer: consume time-reversed input, output re-reversed."""
@@ -215,9 +222,15 @@ def bigru_mul(x, w, prefix):
 
 # --------------------------------------------------------------------------- model
 def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor], x, training: bool,
-            taps: dict | None = None):
+            taps: dict | None = None, routing: dict | None = None, record_routing: dict | None = None):
     """models.seldnet forward (models.py:18-32). x [B,T,F,C] -> sed [B,S,nc], doa [B,S,3nc].
-    Returns (sed, doa, new_state). `taps` (optional dict) receives intermediate tensors."""
+    Returns (sed, doa, new_state). `taps` (optional dict) receives intermediate tensors.
+
+    Test aids for full-size parity (tests/test_model_gpu.py::test_parity_given_identical_routing): MaxPool(ReLU(.)) of block i
+    is a ROUTING decision per pooled element — which window position passes (argmax) and whether it passes at all (> 0).
+    `routing[i] = (pos int64 [B,H/pt,W/pf,C], gate bool same shape)` replaces the block's own decision by a given one (the
+    function stays differentiable: the gradient then flows exactly where the given routing says); `record_routing[i]`
+    receives the free decision (pos, gate) and the fp64 margin behind it (top1 - top2 of the window, |top1|)."""
     new_st = {}
     h = x
     for i in range(len(spec.filters)):
@@ -225,7 +238,19 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
         y, m, v = batchnorm(z, w[f"bn{i}.gamma"], w[f"bn{i}.beta"],
                             st[f"bn{i}.moving_mean"], st[f"bn{i}.moving_variance"], training)
         new_st[f"bn{i}.moving_mean"], new_st[f"bn{i}.moving_variance"] = m, v
-        h = maxpool_nhwc(torch.relu(y), spec.pools[i])
+        if routing is not None and i in routing:
+            pos, gate = routing[i]
+            yw = pool_windows(y, spec.pools[i])
+            h = torch.where(gate, yw.gather(-1, pos.unsqueeze(-1)).squeeze(-1), torch.zeros((), dtype=y.dtype))
+        else:
+            h = maxpool_nhwc(torch.relu(y), spec.pools[i])
+        if record_routing is not None:
+            with torch.no_grad():
+                yw = pool_windows(y.detach(), spec.pools[i])
+                k = min(2, yw.shape[-1])
+                top, idx = yw.topk(k, dim=-1)
+                gap = top[..., 0] - top[..., 1] if k == 2 else torch.full_like(top[..., 0], float("inf"))
+                record_routing[i] = {"pos": idx[..., 0], "gate": top[..., 0] > 0, "gap": gap, "top": top[..., 0], "windows": yw}
         if taps is not None:
             taps[f"conv{i}.z"] = z
             taps[f"pool{i}"] = h
@@ -330,7 +355,8 @@ def test_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, doa_loss="MSE", d
 
 
 def train_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, *, doa_loss="MSE", loss_weight=(1.0, 1000.0),
-               lr=1e-3, step=1, m=None, v=None, agc=False, dtype=torch.float32, want_taps=False):
+               lr=1e-3, step=1, m=None, v=None, agc=False, dtype=torch.float32, want_taps=False, routing=None,
+               record_routing=None):
     """train.trainstep (train.py:22-36). Returns dict with outputs, losses, flat grads,
     updated flat weights / BN state / Adam slots."""
     tr, nt = variable_specs(spec)
@@ -338,7 +364,8 @@ def train_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, *, doa_loss="MSE
     w = unflatten(fw, tr)
     st = unflatten(_as_t(flat_state, dtype), nt)
     taps = {} if want_taps else None
-    sed, doa, new_st = forward(spec, w, st, _as_t(x, dtype), training=True, taps=taps)
+    sed, doa, new_st = forward(spec, w, st, _as_t(x, dtype), training=True, taps=taps, routing=routing,
+                               record_routing=record_routing)
     obj, sloss, dloss = losses_and_objective(sed, doa, _as_t(y_sed, dtype), _as_t(y_doa, dtype), doa_loss, loss_weight)
     (g,) = torch.autograd.grad(obj, fw)
     with torch.no_grad():

@@ -117,6 +117,8 @@ SIGNATURES = {
     "seld_k_gru_bwd": (_I, [_P] * 11 + [_I] * 3),
     "seld_k_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
+    "seld_debug_pool_routing": (_I, [_P, _I, _P, _P]),
+    "seld_k_valu_clock_mhz": (_I, [_I, C.POINTER(C.c_double)]),
 }
 
 _lib = None

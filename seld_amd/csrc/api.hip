@@ -948,6 +948,20 @@ int seld_train_step(seld_ctx* c, const float* x, const float* y_sed, const float
     return seld_adam_step(c, lr, 0.9f, 0.999f, 1e-7f, agc);
 }
 
+// ---------------------------------------------------------------------------------------------- test aid
+int seld_debug_pool_routing(seld_ctx* c, int block, unsigned char* pos, unsigned char* gate) {
+    if (!c || !pos || !gate || block < 0 || block >= (int)c->conv.size()) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const ConvL& L = c->conv[block];
+    // the first block routes by the positions its forward recorded (with or without the pre-BN tensor); the others by the
+    // scan bn_pool_bwd_dz repeats over the stored pre-BN tensor
+    const bool recorded = block == 0 && L.amax && (c->gram_active || (L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1)));
+    if (launch_pool_routing(c->stream, L.z, L.p, recorded ? L.amax : nullptr, L.scale, L.shift, pos, gate, c->B, L.H, L.W, L.pt, L.pf))
+        return fail(c, SELD_ERR_UNSUPPORTED, "pool_routing");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "pool_routing");
+}
+
 // ---------------------------------------------------------------------------------------------- profiling
 int seld_profile_enable(seld_ctx* c, int on) { if (!c) return SELD_ERR_INVALID; c->prof = on < 0 ? 0 : (on > 2 ? 2 : on); return SELD_OK; }
 int seld_profile_count(const seld_ctx* c) { return c ? (int)c->timers.size() : -1; }

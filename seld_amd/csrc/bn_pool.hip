@@ -311,3 +311,60 @@ int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const
                        scale, shift, c1c2, dz, npool, H, W, pt, pf);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Test aid (seld_debug_pool_routing): the routing decision bn_pool_bwd_dz takes for every pooled element — the window position
+// (i * PF + j, first maximum of y = fmaf(z, scale, shift) in scan order, strict >) and whether it passes the ReLU (max > 0).
+__global__ __launch_bounds__(256) void pool_routing_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, unsigned char* __restrict__ pos,
+                                                           unsigned char* __restrict__ gate, int64_t npool, int H, int W, int PT,
+                                                           int PF) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npool * 16) return;
+    const int g = (int)(gid & 15);
+    const int64_t pp = gid >> 4;
+    const int Wp = W / PF, Hp = H / PT;
+    const int fp = (int)(pp % Wp);
+    const int tp = (int)((pp / Wp) % Hp);
+    const int b = (int)(pp / ((int64_t)Wp * Hp));
+    const float4 sc4 = reinterpret_cast<const float4*>(scale)[g];
+    const float4 sh4 = reinterpret_cast<const float4*>(shift)[g];
+    float ym[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int am[4] = {0, 0, 0, 0};
+    const size_t base = (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + g * 4;
+    for (int i = 0; i < PT; ++i)
+        for (int j = 0; j < PF; ++j) {
+            const float4 zv = *reinterpret_cast<const float4*>(z + base + ((size_t)i * W + j) * 64);
+            const float4 y = fma4(zv, sc4, sh4);
+            const int p = i * PF + j;
+            if (y.x > ym[0]) { ym[0] = y.x; am[0] = p; }
+            if (y.y > ym[1]) { ym[1] = y.y; am[1] = p; }
+            if (y.z > ym[2]) { ym[2] = y.z; am[2] = p; }
+            if (y.w > ym[3]) { ym[3] = y.w; am[3] = p; }
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        pos[gid * 4 + c] = (unsigned char)am[c];
+        gate[gid * 4 + c] = ym[c] > 0.f ? 1 : 0;
+    }
+}
+
+// gate only, from the pooled activation (first block without its pre-BN tensor: positions are the recorded amax)
+__global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict__ p, unsigned char* __restrict__ gate, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gate[i] = p[i] > 0.f ? 1 : 0;
+}
+
+int launch_pool_routing(hipStream_t st, const float* z, const float* p, const unsigned char* amax, const float* scale,
+                        const float* shift, unsigned char* pos, unsigned char* gate, int B, int H, int W, int pt, int pf) {
+    if (H % pt || W % pf || pt * pf > 255) return -2;
+    const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
+    if (amax) {          // recorded positions + sign of the pooled activation
+        if (hipMemcpyAsync(pos, amax, (size_t)npool * 64, hipMemcpyDeviceToDevice, st) != hipSuccess) return -3;
+        hipLaunchKernelGGL(pool_gate_kernel, dim3((unsigned)((npool * 64 + 255) / 256)), dim3(256), 0, st, p, gate, npool * 64);
+    } else {
+        hipLaunchKernelGGL(pool_routing_kernel, dim3((unsigned)((npool * 16 + 255) / 256)), dim3(256), 0, st, z, scale, shift, pos,
+                           gate, npool, H, W, pt, pf);
+    }
+    return 0;
+}

@@ -103,6 +103,8 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, co
                               int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme = 0);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C);
+int launch_pool_routing(hipStream_t st, const float* z, const float* p, const unsigned char* amax, const float* scale,
+                        const float* shift, unsigned char* pos, unsigned char* gate, int B, int H, int W, int pt, int pf);
 int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,
                           const float* scale, const float* shift, const float* c1c2, float* dz,
                           int B, int H, int W, int C, int pt, int pf);

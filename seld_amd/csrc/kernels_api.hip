@@ -2,6 +2,7 @@
 // kernel family of the hot path on caller-provided device buffers so the parity tests can compare it
 // with the oracle in isolation.  Null stream; scratch is allocated and freed per call (test use only).
 #include "common.h"
+#include <algorithm>
 #include "../../include/seld_hip.h"
 #include <vector>
 #include <math.h>
@@ -319,6 +320,41 @@ int seld_k_adam(float* theta, const float* g, float* m, float* v, int64_t n, flo
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     launch_adam(0, theta, g, m, v, n, lr_t, beta1, beta2, eps);
     return done();
+}
+
+// VALU-only load on `blocks` CUs (the recurrence's shape); lane 0 of every block reports shader cycles and 100 MHz ticks
+__global__ __launch_bounds__(512) void valu_clock_kernel(unsigned long long* out, int iters, float seed) {
+    float a = seed + threadIdx.x * 1e-9f, b = seed * 0.5f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a = fmaf(a, 1.0000001f, 1e-9f);
+        b = fmaf(b, 0.9999999f, 1e-9f);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[3 * blockIdx.x] = c1 - c0;
+        out[3 * blockIdx.x + 1] = r1 - r0;
+        out[3 * blockIdx.x + 2] = (unsigned long long)__float_as_uint(a + b);   // keeps the loop alive
+    }
+}
+
+int seld_k_valu_clock_mhz(int blocks, double* mhz) {
+    if (!mhz || blocks < 1 || blocks > 1024) return SELD_ERR_INVALID;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, (size_t)blocks * 3 * sizeof(unsigned long long)) != hipSuccess) return SELD_ERR_NOMEM;
+    std::vector<unsigned long long> h((size_t)blocks * 3);
+    for (int rep = 0; rep < 2; ++rep)      // the second launch is measured (clocks settled)
+        hipLaunchKernelGGL(valu_clock_kernel, dim3(blocks), dim3(512), 0, 0, d, 200000, 1.0f);
+    const bool ok = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+    hipFree(d);
+    if (!ok) return SELD_ERR_HIP;
+    std::vector<double> r;
+    for (int i = 0; i < blocks; ++i)
+        if (h[3 * i + 1]) r.push_back(100.0 * (double)h[3 * i] / (double)h[3 * i + 1]);
+    if (r.empty()) return SELD_ERR_HIP;
+    std::sort(r.begin(), r.end());
+    *mhz = r[r.size() / 2];
+    return SELD_OK;
 }
 
 }  // extern "C"

@@ -34,6 +34,18 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         raise ValueError("dropout_rate > 0 has no kernel (seldnet.json uses 0.0)")
     gru = list(model_config["SECOND_ARGS"]["units"])
     sed, doa = list(model_config["SED_ARGS"]["units"]), list(model_config["DOA_ARGS"]["units"])
+    # simple_dense_block honours these keys (modules.py:350-376); the head kernels are per-step LINEAR layers (Conv1D with
+    # kernel_size 1 and no activation, which is what lets W1 W2 fold into one product), so anything else must fail loudly
+    # instead of training a different network.  `kernel_regularizer` is accepted: it only feeds model.losses, which
+    # train.trainstep (train.py:22-36) never adds to the objective.
+    for key in ("SED_ARGS", "DOA_ARGS"):
+        ha = model_config[key]
+        if ha.get("dense_activation") not in (None, "linear"):
+            raise ValueError(f"{key}['dense_activation']={ha.get('dense_activation')!r}: the head kernels are linear (None / 'linear')")
+        if int(ha.get("kernel_size", 1)) != 1:
+            raise ValueError(f"{key}['kernel_size']={ha.get('kernel_size')!r}: the head kernels are per-step (kernel_size 1)")
+        if ha.get("dropout_rate", 0):
+            raise ValueError(f"{key}['dropout_rate'] > 0 has no kernel (seldnet.json uses none)")
     for lst, name in ((filters, "filters"), (gru, "SECOND units"), (sed, "SED units"), (doa, "DOA units")):
         if len(lst) > _lib.MAX_LAYERS:
             raise ValueError(f"{name}: at most {_lib.MAX_LAYERS} layers")

@@ -40,7 +40,7 @@ def _loss_outputs(model: SeldNet, doa_loss, B: int):
 
 
 def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: Adam, agc: bool = False,
-              process_group=None):
+              process_group=None, allreduce: bool = True):
     """reference train.trainstep (train.py:22-36) -> (y_p, sloss, dloss).
 
     With torch.distributed initialised (one process per GPU) the flat gradient buffer is summed over
@@ -63,7 +63,7 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     cfg = _cfg(doa_loss, loss_weight, sed_scale, den)
     _lib.check(model.lib.seld_train_fwd_bwd(model.ctx, x.data_ptr(), ys.data_ptr(), yd.data_ptr(), C.byref(cfg),
                                             sed.data_ptr(), doa.data_ptr(), sloss.data_ptr(), dloss.data_ptr()), model.ctx)
-    if world > 1:
+    if world > 1 and allreduce:      # allreduce=False: timing aid only (bench.py measures the exposed communication time with it)
         parallel.allreduce_gradients(model.grad_tensor(), process_group, model)
     _lib.check(model.lib.seld_adam_step(model.ctx, optimizer.learning_rate, optimizer.beta_1, optimizer.beta_2,
                                         optimizer.epsilon, int(bool(agc))), model.ctx)

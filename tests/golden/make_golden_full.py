@@ -1,0 +1,112 @@
+"""Generates tests/golden/seldnet_full_b32_t3000_{mse,mmse}.npz: the HEADLINE configuration (BASELINE.json configs[1]:
+seldnet.json, 32 clips of [3000,64,7]) evaluated once by the CPU oracle in fp64, in the build container.
+
+Run from the repo root (needs ~30 GB of host memory, ~3 min on 8 cores):  python tests/golden/make_golden_full.py
+
+Stored per case (KB-sized; inputs and weights are regenerated from seeds by the test):
+  * train outputs: strided samples of sed / doa, sloss, dloss (the [B,S] rows in MSE mode: a strided sample);
+  * per trainable variable: an evenly strided gradient sample (<= 512 elements; conv0.kernel whole), its indices are
+    recomputed by `sample_index`, the gradient's l2 norm and max |.|;
+  * BN moving statistics after the step (all 384), a strided sample of the post-Adam weights;
+  * `bar_fp32`: per variable, max|g32 - g64| / max|g64| of the SAME oracle evaluated in fp32 -- what two evaluations of
+    the reference's own arithmetic differ by at this size.  tests/test_model_gpu.py::test_full_batch_vs_golden holds the HIP
+    path to max(1e-4, bar) per variable.
+The reference cannot be imported here (TensorFlow absent), so these vectors pin the oracle restatement,
+not TensorFlow: parity stays "unpinned" in the sense of DESIGN.md §0."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import seldnet_oracle as O  # noqa: E402
+from __graft_entry__ import SELDNET_CONFIG  # noqa: E402
+
+B, T = 32, 3000
+MAX_SAMPLE = 512
+
+
+def sample_index(name: str, n: int) -> np.ndarray:
+    """Indices (into the variable's flat gradient) that the fixture stores."""
+    if name == "conv0.kernel" or n <= MAX_SAMPLE:
+        return np.arange(n)
+    return np.linspace(0, n - 1, MAX_SAMPLE).astype(np.int64)
+
+
+def out_sample_index(n: int, k: int = 4096) -> np.ndarray:
+    return np.linspace(0, n - 1, min(n, k)).astype(np.int64)
+
+
+def near_ties(spec, taps, wd):
+    """[n_conv][4]: per conv block, the number of pooling windows (window = one pooled element) of the fp64 forward whose
+    routing an fp32 evaluation can flip: columns = (top1 > 0 and top1 - top2 < d) for d = 1e-6, 1e-5, then |top1| < d for the
+    same d (the ReLU gate).  Each flip moves one whole routed gradient element: the mechanism behind `bar_fp32`."""
+    rows = []
+    for i, pool in enumerate(spec.pools):
+        z = taps.pop(f"conv{i}.z")
+        Bz, H, Wd, C = z.shape
+        m, v = z.mean(axis=(0, 1, 2)), z.var(axis=(0, 1, 2))
+        sc = wd[f"bn{i}.gamma"].numpy().astype(np.float64) / np.sqrt(v + O.BN_EPS)
+        sh = wd[f"bn{i}.beta"].numpy().astype(np.float64) - m * sc
+        row = np.zeros(4, np.int64)
+        for b in range(Bz):          # clip by clip: bounded memory
+            y = z[b] * sc + sh
+            y = y.reshape(H // pool[0], pool[0], Wd // pool[1], pool[1], C).transpose(0, 2, 4, 1, 3).reshape(-1, pool[0] * pool[1])
+            y.partition(y.shape[1] - 2, axis=1) if y.shape[1] > 1 else None
+            t1 = y[:, -1]
+            t2 = y[:, -2] if y.shape[1] > 1 else np.full_like(t1, -np.inf)
+            for j, d in enumerate((1e-6, 1e-5)):
+                row[j] += int(((t1 > 0) & (t1 - t2 < d)).sum())
+                row[2 + j] += int((np.abs(t1) < d).sum())
+        rows.append(row)
+        del z
+    return np.array(rows)
+
+
+def main():
+    spec = O.Spec.from_config(SELDNET_CONFIG)
+    tr, _ = O.variable_specs(spec)
+    for dl in ("MSE", "MMSE"):
+        w, st = O.random_weights(spec, 0)
+        x, ys, yd = O.synthetic_batch(B, T, seed=1234)
+        kw = dict(doa_loss=dl, loss_weight=(1.0, 1000.0), lr=1e-3, step=1)
+        r = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float64, want_taps=(dl == "MSE"), **kw)
+        out = {"meta": np.array([B, T, {"MSE": 0, "MMSE": 1}[dl]])}
+        if dl == "MSE":
+            out["near_ties"] = near_ties(spec, r.pop("taps"), O.unflatten(torch.as_tensor(w), tr))
+        g32 = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float32, **kw)["grad"]
+        off = 0
+        bars, norms, maxes = [], [], []
+        for name, shape in tr:
+            k = int(np.prod(shape))
+            g = r["grad"][off:off + k]
+            out["g." + name] = g[sample_index(name, k)]
+            norms.append(np.linalg.norm(g))
+            maxes.append(np.abs(g).max())
+            bars.append(np.abs(g32[off:off + k].astype(np.float64) - g).max() / max(np.abs(g).max(), 1e-300))
+            off += k
+        out["grad_norms"], out["grad_max"], out["bar_fp32"] = np.array(norms), np.array(maxes), np.array(bars)
+        out["sed"] = r["sed"].reshape(-1)[out_sample_index(r["sed"].size)]
+        out["doa"] = r["doa"].reshape(-1)[out_sample_index(r["doa"].size)]
+        out["sloss"] = r["sloss"]
+        dlv = np.asarray(r["dloss"]).reshape(-1)
+        out["dloss"] = dlv[out_sample_index(dlv.size)]
+        out["dloss_sum"] = dlv.sum()
+        out["new_state"] = r["new_state"]
+        out["new_w"] = r["new_w"][out_sample_index(r["new_w"].size)]
+        # samples as float32 (6e-8 relative: far below the 1e-4 bar), scalars / norms / bars as float64: ~100 KB per case
+        f64 = ("grad_norms", "grad_max", "bar_fp32", "sloss", "dloss_sum")
+        out = {k: (v if k in ("meta", "near_ties") else np.asarray(v, np.float64 if k in f64 else np.float32)) for k, v in out.items()}
+        path = os.path.join(ROOT, "tests", "golden", f"seldnet_full_b32_t3000_{dl.lower()}.npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path), "bytes")
+        if "near_ties" in out:
+            print("  near-tie windows per conv block [gap<1e-6, gap<1e-5, |top|<1e-6, |top|<1e-5]:", out["near_ties"].tolist())
+        for (name, _), b in zip(tr, bars):
+            print("  %-28s fp32-oracle bar %.3e" % (name, b))
+
+
+if __name__ == "__main__":
+    main()

@@ -88,3 +88,21 @@ def test_synthetic_batch_matches_the_oracles_generator():
     from seld_amd.synthetic import synthetic_batch
     for got, want in zip(synthetic_batch(2, 50, seed=7), oracle_batch(2, 50, seed=7)):
         assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
+    """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376); the HIP heads are
+    linear per-step layers, so any other value must raise instead of silently training a different network."""
+    import copy
+    from seld_amd import models
+    a = models._arch_from_config(seldnet_config, 7, 64)
+    assert (a.n_sed_dense, a.n_doa_dense, a.n_classes) == (1, 1, 12)
+    ok = copy.deepcopy(seldnet_config)
+    ok["SED_ARGS"].update(dense_activation="linear", kernel_size=1, dropout_rate=0, kernel_regularizer={"l1": 0.0, "l2": 1e-3})
+    models._arch_from_config(ok, 7, 64)      # the regulariser only feeds model.losses, which train.trainstep never adds
+    for head in ("SED_ARGS", "DOA_ARGS"):
+        for key, val in (("dense_activation", "relu"), ("kernel_size", 3), ("dropout_rate", 0.2)):
+            bad = copy.deepcopy(seldnet_config)
+            bad[head][key] = val
+            with pytest.raises(ValueError):
+                models._arch_from_config(bad, 7, 64)

@@ -414,3 +414,107 @@ def test_full_size_batch_consistency(seldnet_config):
         res.append((g, y_p[0].cpu().numpy().copy()))
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("mode", ["mse", "mmse"])
+def test_full_batch_vs_golden(seldnet_config, mode):
+    """The HEADLINE configuration (BASELINE.json configs[1]: 32 clips of [3000,64,7]) against the fp64 oracle evaluated once
+    in the build container (tests/golden/make_golden_full.py): outputs, losses, BN state, the post-Adam weights and every
+    variable's gradient, variable by variable.  Bar per variable: 1e-4, or — where two evaluations of the reference's own
+    arithmetic differ by more at this size — 3 x the fp32-oracle-vs-fp64-oracle error stored in the fixture (`bar_fp32`):
+    at 20 M pooling windows a handful of windows have their two largest elements (or their maximum and 0) within one fp32
+    rounding of each other (`near_ties` in the fixture: 49 first-block windows with an fp64 margin below 1e-6), and every such
+    routing flip moves one whole gradient element.  WHICH of them flip is chance (7 here, profiles/r02_routing_flips_b32.log),
+    so an fp32 evaluation lands within a small factor of another one's error, not below it: the factor 3.  That the flips
+    are all there is to it is test_parity_given_identical_routing's job."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from seld_amd import losses, train
+    spec_ = importlib.util.spec_from_file_location("make_golden_full", os.path.join(ROOT, "tests", "golden", "make_golden_full.py"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"seldnet_full_b32_t3000_{mode}.npz"))
+    B, T, dl = (int(v) for v in z["meta"])
+    assert (B, T) == (32, 3000)
+    O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
+    mg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mg)       # sample_index / out_sample_index: the fixture's sampling rule
+    doa_loss = [losses.MSE, losses.MMSE][dl]
+    y_p, sl, dlo = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), doa_loss, (1.0, 1000.0), train.Adam(1e-3))
+    sed, doa = y_p[0].cpu().numpy().reshape(-1), y_p[1].cpu().numpy().reshape(-1)
+    check("full sed", sed[mg.out_sample_index(sed.size)], z["sed"])
+    check("full doa", doa[mg.out_sample_index(doa.size)], z["doa"])
+    check("full sloss", sl.cpu().numpy(), z["sloss"])
+    dlv = dlo.cpu().numpy().reshape(-1)
+    check("full dloss", dlv[mg.out_sample_index(dlv.size)], z["dloss"])
+    check("full dloss sum", dlv.astype(np.float64).sum(), z["dloss_sum"])
+    g = model.get_grads().astype(np.float64)
+    over = []
+    for i, (n, off, sh) in enumerate(model.variables):
+        k = int(np.prod(sh))
+        gv = g[off:off + k]
+        if n.startswith("conv") and n.endswith("bias"):
+            # exactly 0 in exact arithmetic (a bias in front of training-mode BatchNorm): rounding noise on both sides
+            assert np.abs(gv).max() <= 1e-3 * z["grad_max"].max(), n
+            continue
+        bar = max(1e-4, float(z["bar_fp32"][i]))
+        e = np.abs(gv[mg.sample_index(n, k)] - z["g." + n]).max() / z["grad_max"][i]
+        en = abs(np.linalg.norm(gv) - z["grad_norms"][i]) / z["grad_norms"][i]
+        print(f"[parity] full grad {n:28s} rel_err={e:.3e} norm_err={en:.3e} bar={bar:.3e} (fp32 oracle: {z['bar_fp32'][i]:.3e})")
+        if e > bar or en > bar:
+            over.append((n, e, en, bar))
+    assert not over, over
+    w1, st1 = model.get_weights()
+    check("full BN moving stats", st1, z["new_state"])
+    check("full post-Adam weights", w1[mg.out_sample_index(w1.size)], z["new_w"], tol=2e-3)
+
+
+def test_parity_given_identical_routing(seldnet_config):
+    """What "1e-4 at full clip length" can mean for the conv stack.  MaxPool(ReLU(BN(.))) takes one ROUTING
+    decision per pooled element (which window position passes, and whether it passes 0); among millions of windows a few have
+    their two largest elements within one fp32 rounding of each other, an fp32 evaluation — this library, TensorFlow, the
+    oracle run in fp32 — may then decide differently from the fp64 oracle, and every such flip moves one whole gradient element
+    (tools/diag_routing_flips.py, profiles/r02_routing_flips_b32.log: 7 flips among 19.7 M first-block windows at B=32 put
+    3.5e-3 on conv0.kernel all by themselves).  So the claim is checked in two halves, at T = 3000:
+      (1) every decision the library takes differently from the free-running fp64 oracle is one fp32 cannot resolve: the
+          fp64 margin behind it (top1 - top2 of the window, or |top1| for the ReLU gate) is below 1e-5;
+      (2) GIVEN the library's decisions (seld_debug_pool_routing), the fp64 oracle's gradients agree with the library's to
+          1e-4 for every variable — no cancellation or summation error hides behind the flips."""
+    import ctypes as C
+    B, T = 4, 3000
+    O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
+    from seld_amd import _lib, losses, train
+    train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3), False)
+    g = model.get_grads()
+    routing = {}
+    H, W = T, 64
+    for i, (pt, pf) in enumerate(spec.pools):
+        shape = (B, H // pt, W // pf, 64)
+        pos = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        gate = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, i, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
+        routing[i] = (pos.cpu().to(torch.int64), gate.cpu().bool())
+        assert int(routing[i][0].max()) < pt * pf
+        H, W = H // pt, W // pf
+    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    free = {}
+    O.train_step(spec, w, st, x, ys, yd, record_routing=free, **kw)
+    n_flip = 0
+    for i in range(len(spec.pools)):
+        pos, gate = routing[i]
+        f = free[i]
+        both = gate & f["gate"]
+        arg = (pos != f["pos"]) & both
+        # the library's choice against the fp64 maximum of the same window: the margin fp32 would have had to resolve
+        chosen = f["windows"].gather(-1, pos.unsqueeze(-1)).squeeze(-1)
+        margin = (f["top"] - chosen)[arg]
+        gflip = gate != f["gate"]
+        gmargin = f["top"].abs()[gflip]
+        n_flip += int(arg.sum()) + int(gflip.sum())
+        print(f"[routing] block {i}: {pos.numel()} pooled elements, argmax flips {int(arg.sum())} (max fp64 margin "
+              f"{float(margin.max()) if margin.numel() else 0.0:.2e}), ReLU gate flips {int(gflip.sum())} "
+              f"(max |top| {float(gmargin.max()) if gmargin.numel() else 0.0:.2e})")
+        assert (margin < 1e-5).all() and (gmargin < 1e-5).all()
+        del f["windows"]
+    ref = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
+    print(f"[routing] {n_flip} decisions differ from the free-running fp64 oracle; gradients against the fp64 oracle WITH the library's routing:")
+    _per_var(model, "routed grad", g, ref["grad"])

@@ -26,6 +26,20 @@ def test_mic_gcc_perm_matches_oracle_and_identity():
     np.testing.assert_array_equal(TO.mic_gcc_perm(np.array([[1, 0, 3, 2]]))[0], [0, 4, 3, 2, 1, 5])
 
 
+def test_mic_gcc_perm_reference_known_answer_table():
+    """The reference's own 6-row known-answer table for mic_gcc_perm (transforms_test.py:64-73, data only): both the
+    product's host function and the oracle must reproduce every row."""
+    mic_perm = np.array([[1, 3, 0, 2], [3, 1, 2, 0], [1, 0, 3, 2], [2, 0, 3, 1], [0, 2, 1, 3], [3, 2, 1, 0]], np.int32)
+    res = np.array([[4, 0, 3, 2, 5, 1],
+                    [4, 5, 2, 3, 0, 1],
+                    [0, 4, 3, 2, 1, 5],
+                    [1, 5, 3, 2, 0, 4],
+                    [1, 0, 2, 3, 5, 4],
+                    [5, 4, 2, 3, 1, 0]], np.int32)
+    np.testing.assert_array_equal(TO.mic_gcc_perm(mic_perm), res)
+    np.testing.assert_array_equal(T.mic_gcc_perm(mic_perm), res)
+
+
 def test_channel_list_is_the_references_table():
     np.testing.assert_array_equal(np.array(T.channel_list), TO.CHANNEL_LIST)
     assert TO.CHANNEL_LIST.shape == (8, 2, 4)
