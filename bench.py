@@ -124,22 +124,20 @@ def cpu_baseline(B_gpu, T, steps, warmup, budget_s):
     return big
 
 
-def box_peaks(dev_index):
-    """peaks read on the box, printed next to the constants the roofline fractions use.  Derived from the
-    device properties (CU count, engine / memory clocks, bus width): fp32 MFMA = CUs x 4 SIMDs x 64 FLOP/clk x clock; dense
+def box_peaks(lib, dev_index):
+    """peaks read on the box, printed next to the constants the roofline fractions use.  Derived from
+    hipGetDeviceProperties (CU count, engine / memory clocks, bus width): fp32 MFMA = CUs x 4 SIMDs x 64 FLOP/clk x clock; dense
     bf16 MFMA = 16 x that; HBM = 2 x memory clock x bus width / 8."""
+    import ctypes as C
     p = torch.cuda.get_device_properties(dev_index)
-    out = {"name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
-           "total_memory_GB": round(p.total_memory / 1e9, 1)}
-    clk = getattr(p, "clock_rate", None)                 # kHz
-    mclk, bus = getattr(p, "memory_clock_rate", None), getattr(p, "memory_bus_width", None)
-    if clk:
-        out["engine_clock_MHz"] = clk / 1e3
-        out["derived_f32_mfma_TFLOPS"] = round(p.multi_processor_count * 4 * 64 * clk * 1e3 / 1e12, 1)
-        out["derived_bf16_mfma_TFLOPS"] = round(16 * p.multi_processor_count * 4 * 64 * clk * 1e3 / 1e12, 1)
-    if mclk and bus:
-        out["memory_clock_MHz"], out["memory_bus_bits"] = mclk / 1e3, bus
-        out["derived_hbm_GBps"] = round(2 * mclk * 1e3 * bus / 8 / 1e9, 1)
+    out = {"name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "total_memory_GB": round(p.total_memory / 1e9, 1)}
+    cu, clk, mclk, bus = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib.seld_device_clocks(dev_index, C.byref(cu), C.byref(clk), C.byref(mclk), C.byref(bus)) == 0:
+        out.update({"compute_units": cu.value, "engine_clock_MHz": clk.value / 1e3, "memory_clock_MHz": mclk.value / 1e3,
+                    "memory_bus_bits": bus.value,
+                    "derived_f32_mfma_TFLOPS": round(cu.value * 4 * 64 * clk.value * 1e3 / 1e12, 1),
+                    "derived_bf16_mfma_TFLOPS": round(16 * cu.value * 4 * 64 * clk.value * 1e3 / 1e12, 1),
+                    "derived_hbm_GBps": round(2 * mclk.value * 1e3 * bus.value / 8 / 1e9, 1)})
     out["constants_used"] = {"f32_mfma_TFLOPS": PEAK_F32_MFMA_TFLOPS, "bf16_mfma_TFLOPS": PEAK_BF16_MFMA_TFLOPS,
                              "split_bf16_TFLOPS": round(PEAK_SPLIT_BF16_TFLOPS, 1), "hbm_GBps": PEAK_HBM_GBPS,
                              "source": "/opt/skills/guides/MI355X_MICROARCH.md"}
@@ -327,7 +325,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
             "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
         }
-        out["peaks_on_box"] = box_peaks(local)
+        out["peaks_on_box"] = box_peaks(model.lib, local)
         if comm:
             out["comm"] = comm
         if world == 1 and not args.no_features:

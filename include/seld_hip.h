@@ -138,6 +138,9 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
                      int device, seld_feat** out);
 void seld_feat_destroy(seld_feat* f);
 const char* seld_feat_last_error(const seld_feat* f);
+/* kernel selection, for A/B runs and parity of the fallback: "wave_kernel" (default 1): one wave per frame with a radix-4 FFT
+ * in registers + LDS (n_fft 256 .. 1024); 0: the workgroup-per-frame radix-2 kernel that serves every other n_fft */
+int seld_feat_set_option(seld_feat* f, const char* key, int value);
 int64_t seld_feat_frames(const seld_feat* f, int64_t n_samples);
 int seld_feat_channels(const seld_feat* f);
 int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_samples, float* out, void* stream);
@@ -282,6 +285,9 @@ int seld_debug_pool_routing(seld_ctx* ctx, int block, unsigned char* pos, unsign
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */
 int seld_k_valu_clock_mhz(int blocks, double* mhz);
+/* hipGetDeviceProperties of `device`: compute units, engine clock (kHz), memory clock (kHz), memory bus width (bits) —
+ * bench.py prints the peaks they imply next to the constants its roofline fractions use. */
+int seld_device_clocks(int device, int* compute_units, int* clock_khz, int* mem_clock_khz, int* mem_bus_bits);
 
 #ifdef __cplusplus
 }

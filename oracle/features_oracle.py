@@ -134,3 +134,35 @@ def stockham_fft(x: np.ndarray) -> np.ndarray:
         b[..., 2 * j - k + m] = u - v
         a = b
     return a
+
+
+def stockham_fft_radix4(x: np.ndarray) -> np.ndarray:
+    """Index model of the wave-per-frame FFT of features.hip (feat_wave_kernel): radix-4 Stockham autosort passes,
+    L = 1, 4, 16, ... (every pass reads ALL its inputs, then writes: in place), one final radix-2 pass when log2 n is odd.
+    Pass with sub-transform length L: butterfly j in [0, n/4), k = j mod L, inputs a_q = src[j + q n/4] times
+    W_{4L}^{q k} = tw[q k n/(4L)], outputs dst[4 (j - k) + k + p L] = sum_q a_q (-i)^{p q}."""
+    n = x.shape[-1]
+    logn = int(math.log2(n))
+    assert 1 << logn == n and n >= 4
+    tw = np.exp(-2j * np.pi * np.arange(n) / n)
+    a = x.astype(np.complex128).copy()
+    L = 1
+    for _ in range(logn // 2):
+        b = np.empty_like(a)
+        j = np.arange(n // 4)
+        k = j & (L - 1)
+        v = [a[..., j + q * (n // 4)] * tw[q * k * (n // (4 * L))] for q in range(4)]
+        t0, t1, t2 = v[0] + v[2], v[0] - v[2], v[1] + v[3]
+        t3 = -1j * (v[1] - v[3])
+        o = 4 * (j - k) + k
+        b[..., o], b[..., o + L], b[..., o + 2 * L], b[..., o + 3 * L] = t0 + t2, t1 + t3, t0 - t2, t1 - t3
+        a = b
+        L *= 4
+    if logn & 1:
+        b = np.empty_like(a)
+        j = np.arange(n // 2)
+        k = j & (L - 1)
+        u, v = a[..., j], tw[k * (n // (2 * L))] * a[..., j + n // 2]
+        b[..., 2 * j - k], b[..., 2 * j - k + L] = u + v, u - v
+        a = b
+    return a

@@ -83,6 +83,7 @@ SIGNATURES = {
     "seld_feat_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "seld_feat_destroy": (None, [_P]),
     "seld_feat_last_error": (C.c_char_p, [_P]),
+    "seld_feat_set_option": (_I, [_P, C.c_char_p, _I]),
     "seld_feat_frames": (_L, [_P, _L]),
     "seld_feat_channels": (_I, [_P]),
     "seld_feat_extract": (_I, [_P, _P, _I, _L, _P, _P]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "seld_k_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
     "seld_debug_pool_routing": (_I, [_P, _I, _P, _P]),
+    "seld_device_clocks": (_I, [_I] + [C.POINTER(C.c_int)] * 4),
     "seld_k_valu_clock_mhz": (_I, [_I, C.POINTER(C.c_double)]),
 }
 

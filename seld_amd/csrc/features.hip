@@ -12,7 +12,9 @@
 #include "common.h"
 #include "../../include/seld_hip.h"
 
+#include <algorithm>
 #include <math.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -25,9 +27,20 @@ struct seld_feat {
     int* mel_count = nullptr;   // [n_mels]
     int* mel_off = nullptr;     // [n_mels] offset into mel_w
     float* mel_w = nullptr;     // packed weights
-    float* gmax = nullptr;      // 1 float: max dB of the clip (ordered-int atomics)
+    int n_melw = 0;             // number of packed weights
+    // the same filters for 16-byte reads (wave kernel): start rounded down to a multiple of 4 bins, weights zero-padded
+    int *mel_start4 = nullptr, *mel_cnt4 = nullptr, *mel_off4 = nullptr;
+    float* mel_w4 = nullptr;
+    int n_melw4 = 0, maxc4 = 0;
+    int* trips = nullptr;       // [16] per-slot loop bounds of the wave kernel
+    int dbg = 0;                // timing ablations of the wave kernel (tools/tune_features.py): 1 no loads, 2 no FFT passes, 4 no mel
+    int use_wave_kernel = 1;    // 0: the workgroup-per-frame radix-2 kernel for every size (A/B and parity of the fallback)
+    float* gmax = nullptr;      // [FEAT_MAX_PARTS]: per-workgroup maxima of the dB channels of the running clip (no atomics: thousands
+                                // of atomic maxima on ONE word serialise at ~88 per microsecond and were 40 % of the kernel)
     std::string err;
 };
+
+#define FEAT_MAX_PARTS 4096
 
 namespace {
 
@@ -42,7 +55,7 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 
 // MODE 0 = foa (4 mel-dB + 3 mel-IV), 1 = mic (4 mel-dB + 6 GCC)
 template <int MODE>
-__global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict__ wav, int64_t n_samples, int n_fft, int logn,
+__global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict__ wav, int64_t n_samples, int64_t n_frames, int n_fft, int logn,
                                                          int hop, int n_mels, const float* __restrict__ win,
                                                          const float2* __restrict__ tw_g, const int* __restrict__ mel_start,
                                                          const int* __restrict__ mel_count, const int* __restrict__ mel_off,
@@ -57,8 +70,9 @@ __global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict
     float* val = reinterpret_cast<float*>(tw + N / 2);    // foa: [7][NBP]; mic: [4][NBP] + phase [6][NBP] float2
     float* red = val + (MODE == 0 ? 7 * NBP : 4 * NBP + 12 * NBP);
     const int tid = threadIdx.x;
-    const int64_t t = blockIdx.x;
     for (int i = tid; i < N / 2; i += 256) tw[i] = tw_g[i];
+    float lmax = -INFINITY;
+    for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {      // grid <= FEAT_MAX_PARTS: one maximum per workgroup
     // ---- windowed, reflect-padded frame (torch.stft center=True): sample index t*hop + n - N/2
     const float* x0 = wav;
     const float* x1 = wav + n_samples;
@@ -130,7 +144,6 @@ __global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- sparse mel projection; thread (m = tid % n_mels.., g) handles channels g, g+4
-    float lmax = -INFINITY;
     const int nm_ch = MODE == 0 ? 7 : 4;
     for (int idx = tid; idx < n_mels * nm_ch; idx += 256) {
         const int c = idx / n_mels, m = idx - c * n_mels;
@@ -165,6 +178,8 @@ __global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict
             out[((size_t)t * n_mels + j) * C_OUT + 4 + p] = (pp[0].x + nyq + 2.f * acc) * invn;
         }
     }
+    __syncthreads();         // the next frame overwrites the buffers this one still reads
+    }
     // ---- clip-wide max of the dB channels (top_db clamp needs it)
     red[tid] = lmax;
     __syncthreads();
@@ -172,21 +187,374 @@ __global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict
         if (tid < w) red[tid] = fmaxf(red[tid], red[tid + w]);
         __syncthreads();
     }
-    if (tid == 0) atomic_max_float(gmax, red[0]);
+    if (tid == 0) gmax[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out, const float* __restrict__ gmax, int64_t n_tm,
-                                                         int c_out, float top_db) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_tm * 4) return;
-    const int64_t tm = i >> 2;
-    const int c = (int)(i & 3);
-    const float floor_db = gmax[0] - top_db;
-    float* p = out + tm * c_out + c;
-    *p = fmaxf(*p, floor_db);
+// ------------------------------------------------------------------------------------------------
+// Wave-per-frame kernel (n_fft 256 .. 1024; the default path).  One WAVE owns a frame end to end, so nothing in the frame's
+// chain — FFT passes, per-bin spectra, mel projection — needs a workgroup barrier: a wave's LDS instructions execute in
+// order, which makes every exchange between its lanes a plain write followed by a read.  The FFT is a radix-4 Stockham
+// autosort (oracle/features_oracle.py::stockham_fft_radix4 is the index model): log4(N) passes instead of log2(N), each lane
+// holds N/256 butterflies of both packed transforms in registers, a pass reads ALL its inputs and then writes IN PLACE (one
+// N-point buffer per transform), the first pass takes its inputs straight from global memory (windowed, reflect-padded).
+// The block's four waves share the twiddle / window / mel tables in LDS and walk the frames persistently.
+template <int LOGN>
+struct WF {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int NB4 = N / 256;           // radix-4 butterflies per lane and pass
+    static constexpr int NB2 = N / 128;           // radix-2 butterflies per lane (final pass when LOGN is odd)
+    static constexpr int P4 = LOGN / 2;
+    static constexpr bool HAS2 = (LOGN & 1) != 0;
+    static constexpr int NB = N / 2 + 1;
+    static constexpr int NBP = NB + 3;            // row stride of the per-bin value planes
+    static constexpr int NBI = (NB + 63) / 64;    // bins per lane
+};
+
+__device__ __forceinline__ float2 tw_at(const float2* tw, int t, int halfN) {   // exp(-2 pi i t / N), t in [0, N)
+    float2 w = tw[t & (halfN - 1)];
+    if (t & halfN) { w.x = -w.x; w.y = -w.y; }
+    return w;
+}
+// lanes of one wave exchange data through LDS with no barrier: LDS executes a wave's instructions in order; this only stops
+// the COMPILER from moving a lane's later read above its earlier write (to it they are unrelated addresses)
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+// radix-4 passes 1 .. P4-1 and the optional final radix-2 pass of NF transforms, in place on buf[f]; `v` holds pass 0's
+// inputs (element lane + 64 b + q N/4) when FROM_REGS, otherwise pass 0 reads them from buf[f] too
+template <int LOGN, int NF, bool FROM_REGS>
+__device__ __forceinline__ void wave_fft(float2 (&v)[NF][WF<LOGN>::NB4][4], float2* const (&buf)[NF], const float2* tw, int lane) {
+    using G = WF<LOGN>;
+    constexpr int N = G::N, NB4 = G::NB4, Q = N / 4;
+#pragma unroll
+    for (int s = 0; s < G::P4; ++s) {
+        const int L = 1 << (2 * s);
+        if (s > 0 || !FROM_REGS) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int b = 0; b < NB4; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[f][b][q] = buf[f][lane + 64 * b + q * Q];
+        }
+#pragma unroll
+        for (int b = 0; b < NB4; ++b) {
+            const int j = lane + 64 * b, k = j & (L - 1);
+            float2 w1 = make_float2(1.f, 0.f), w2 = w1, w3 = w1;
+            if (s > 0) {
+                const int ts = k * (N / (4 * L));
+                w1 = tw_at(tw, ts, N / 2); w2 = tw_at(tw, 2 * ts, N / 2); w3 = tw_at(tw, 3 * ts, N / 2);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float2 a0 = v[f][b][0];
+                const float2 a1 = s > 0 ? cmul(w1, v[f][b][1]) : v[f][b][1];
+                const float2 a2 = s > 0 ? cmul(w2, v[f][b][2]) : v[f][b][2];
+                const float2 a3 = s > 0 ? cmul(w3, v[f][b][3]) : v[f][b][3];
+                const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y), t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 t3 = make_float2(a1.y - a3.y, a3.x - a1.x);          // -i (a1 - a3)
+                v[f][b][0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                v[f][b][1] = make_float2(t1.x + t3.x, t1.y + t3.y);
+                v[f][b][2] = make_float2(t0.x - t2.x, t0.y - t2.y);
+                v[f][b][3] = make_float2(t1.x - t3.x, t1.y - t3.y);
+            }
+        }
+        WAVE_LDS_FENCE();        // every input of the pass is in registers before the first in-place write
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int b = 0; b < NB4; ++b) {
+                const int j = lane + 64 * b, k = j & (L - 1), o = 4 * (j - k) + k;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) buf[f][o + p * L] = v[f][b][p];
+            }
+        WAVE_LDS_FENCE();
+    }
+    if (G::HAS2) {               // L = N/2: k = j, twiddle tw[j]
+        constexpr int NB2 = G::NB2;
+        float2 u[NF][NB2], x[NF][NB2];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int b = 0; b < NB2; ++b) {
+                const int j = lane + 64 * b;
+                u[f][b] = buf[f][j];
+                x[f][b] = cmul(tw[j], buf[f][j + N / 2]);
+            }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int b = 0; b < NB2; ++b) {
+                const int j = lane + 64 * b;
+                buf[f][j] = make_float2(u[f][b].x + x[f][b].x, u[f][b].y + x[f][b].y);
+                buf[f][j + N / 2] = make_float2(u[f][b].x - x[f][b].x, u[f][b].y - x[f][b].y);
+            }
+        WAVE_LDS_FENCE();
+    }
 }
 
-__global__ void feat_init_max_kernel(float* gmax) { gmax[0] = -INFINITY; }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// windowed samples of channels (xa, xa + n_samples) of the frame that starts at sample s0 -> the first pass's registers
+// (element lane + 64 b + q N/4 of the packed complex input); reflect padding only where the frame leaves the clip
+template <int LOGN>
+__device__ __forceinline__ void feat_load_pair(float2 (&v)[1][WF<LOGN>::NB4][4], const float* xa, int, int64_t n_samples, int64_t s0,
+                                               bool interior, const float* win, int lane) {
+    constexpr int NB4 = WF<LOGN>::NB4, Q = WF<LOGN>::N / 4;
+    const float* xb = xa + n_samples;
+    if (interior) {
+        const float* pa = xa + s0;
+        const float* pb = xb + s0;
+#pragma unroll
+        for (int b = 0; b < NB4; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = lane + 64 * b + q * Q;
+                const float w = win[n];
+                v[0][b][q] = make_float2(w * pa[n], w * pb[n]);
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB4; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = lane + 64 * b + q * Q;
+                int64_t i = s0 + n;
+                if (i < 0) i = -i;
+                if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+                const float w = win[n];
+                v[0][b][q] = make_float2(w * xa[i], w * xb[i]);
+            }
+    }
+}
+
+#define FEAT_WAVES 6
+// LDS of one wave: ONE transform buffer; the same bytes later hold four per-bin value planes [4][NB + 3] and then the staged frame
+static size_t feat_wave_bytes(int n_fft, int n_mels, int c_out) {
+    const size_t fft = (size_t)n_fft * sizeof(float2), planes = (size_t)4 * (n_fft / 2 + 4) * sizeof(float);
+    const size_t stage = (size_t)n_mels * c_out * sizeof(float);
+    size_t m = fft > planes ? fft : planes;
+    if (stage > m) m = stage;
+    return (m + 15) & ~(size_t)15;
+}
+
+// Sequence per frame (foa): channels 0,1 -> FFT -> this lane's bins to registers (powers, Re(conj(W) Y)); channels 2,3 -> FFT in
+// the SAME buffer -> bins (powers, the other two intensity components, normalisation); the four power planes -> sparse mel + dB;
+// the three intensity planes -> sparse mel; the frame staged as [m][7] and stored as one contiguous run.  mic: the four spectra
+// stay in registers and three packed inverse transforms give the six GCC-PHAT cross-correlations.
+// The mel filters are read 16 bytes at a time: filter m covers cnt4[m] aligned float4 chunks of a plane from bin start4[m]
+// (a multiple of 4), its weights zero-padded to match (seld_feat_create).
+template <int MODE, int LOGN>
+__global__ __launch_bounds__(64 * FEAT_WAVES, MODE == 0 ? 3 : 2) void feat_wave_kernel(
+    const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, int n_melw4, int maxc4,
+    const float* __restrict__ win_g, const float2* __restrict__ tw_g, const int* __restrict__ mel_start4,
+    const int* __restrict__ mel_cnt4, const int* __restrict__ mel_off4, const float* __restrict__ mel_w4, float* __restrict__ out,
+    float* __restrict__ gmax, int wave_bytes, int dbg, const int* __restrict__ trips_g) {
+    using G = WF<LOGN>;
+    constexpr int N = G::N, NB = G::NB, NBP = G::NBP, NBI = G::NBI, NB4 = G::NB4;
+    constexpr int C_OUT = MODE == 0 ? 7 : 10;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);                  // [N/2]
+    float* win = smem + N;                                         // [N]
+    float* melw = win + N;                                         // [n_melw4] (a multiple of 4)
+    int* mst = reinterpret_cast<int*>(melw + n_melw4);             // [n_mels] start4 | cnt4 | offset
+    int* mct = mst + n_mels;
+    int* mof = mct + n_mels;
+    int* trips = mof + ((n_mels + 3) & ~3);                       // [16]
+    const int tid = threadIdx.x, lane_id = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wbase = reinterpret_cast<char*>(trips + 16) + (size_t)wave * wave_bytes;
+    float2* buf = reinterpret_cast<float2*>(wbase);
+    float* val = reinterpret_cast<float*>(wbase);
+    for (int i = tid; i < N / 2; i += 64 * FEAT_WAVES) tw[i] = tw_g[i];
+    for (int i = tid; i < N; i += 64 * FEAT_WAVES) win[i] = win_g[i];
+    for (int i = tid; i < n_melw4; i += 64 * FEAT_WAVES) melw[i] = mel_w4[i];
+    for (int i = tid; i < n_mels; i += 64 * FEAT_WAVES) { mst[i] = mel_start4[i]; mct[i] = mel_cnt4[i]; mof[i] = mel_off4[i]; }
+    __syncthreads();
+    // trips[q]: wave-uniform trip count of output slot q's filter loop = the longest filter among the slot's 64 outputs (slot q of
+    // the dB pass holds m = (lane + 64 q) >> 2, slot 8 + q of the intensity pass m = (lane + 64 q) / 3); built by seld_feat_create
+    if (tid < 16) trips[tid] = trips_g[tid];
+    __syncthreads();
+    float lmax = -INFINITY;
+    float2* const b1[1] = {buf};
+    for (int64_t t = (int64_t)blockIdx.x * FEAT_WAVES + wave; t < T; t += (int64_t)gridDim.x * FEAT_WAVES) {
+        // `lane` made opaque per frame: everything indexed by it (twiddles of every pass, window, table offsets) is otherwise
+        // hoisted out of this loop and held in ~100 registers for the one or two frames a wave sees
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const int64_t s0 = t * hop - N / 2;                        // first sample of the frame (torch.stft center=True)
+        const bool interior = s0 >= 0 && s0 + N <= n_samples;      // wave-uniform: no reflection needed
+        float2 v[1][NB4][4];
+        // Xa = (Z[k] + conj(Z[N-k]))/2 ; Xb = (Z[k] - conj(Z[N-k]))/(2i): this lane's bins k = lane + 64 i.  foa keeps only what the
+        // planes need (four powers, X0 until the second transform is done, three intensity components); mic keeps the four spectra.
+        float2 X0[NBI], X1[MODE == 1 ? NBI : 1], X2[MODE == 1 ? NBI : 1], X3[MODE == 1 ? NBI : 1];
+        float P[4][NBI], IV[MODE == 0 ? 3 : 1][NBI];
+        if (!(dbg & 1)) feat_load_pair<LOGN>(v, wav, 0, n_samples, s0, interior, win, lane);
+        if (!(dbg & 2)) wave_fft<LOGN, 1, true>(v, b1, tw, lane);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int k = lane + 64 * i, kk = k < NB ? k : 0, kn = (N - kk) & (N - 1);
+            const float2 a = buf[kk], b = buf[kn];
+            X0[i] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            const float2 x1 = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
+            P[0][i] = X0[i].x * X0[i].x + X0[i].y * X0[i].y;
+            P[1][i] = x1.x * x1.x + x1.y * x1.y;
+            if (MODE == 0) IV[1][i] = X0[i].x * x1.x + X0[i].y * x1.y;      // IVy <- ch1: Re(conj(W) X1)
+            else X1[i] = x1;
+        }
+        WAVE_LDS_FENCE();
+        if (!(dbg & 1)) feat_load_pair<LOGN>(v, wav + 2 * n_samples, 0, n_samples, s0, interior, win, lane);
+        if (!(dbg & 2)) wave_fft<LOGN, 1, true>(v, b1, tw, lane);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int k = lane + 64 * i, kk = k < NB ? k : 0, kn = (N - kk) & (N - 1);
+            const float2 a = buf[kk], b = buf[kn];
+            const float2 x2 = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            const float2 x3 = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
+            P[2][i] = x2.x * x2.x + x2.y * x2.y;
+            P[3][i] = x3.x * x3.x + x3.y * x3.y;
+            if (MODE == 0) {
+                // intensity vector Re(conj(W) X_i) / |.|: IVx <- ch3, IVy <- ch1, IVz <- ch2
+                const float ivx = X0[i].x * x3.x + X0[i].y * x3.y, ivy = IV[1][i], ivz = X0[i].x * x2.x + X0[i].y * x2.y;
+                // one reciprocal instead of three divisions (v_rcp_f32: 1 ulp; the parity bar is 1e-4 of the channel's maximum)
+                const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ivx * ivx + ivy * ivy + ivz * ivz), 1e-8f));
+                IV[0][i] = ivx * inv; IV[1][i] = ivy * inv; IV[2][i] = ivz * inv;
+            } else {
+                X2[i] = x2; X3[i] = x3;
+            }
+        }
+        WAVE_LDS_FENCE();
+        // ---- power planes [4][NBP] (pad entries zeroed: the filters read whole float4 chunks)
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int k = lane + 64 * i;
+            if (k < NB) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) val[c * NBP + k] = P[c][i];
+            }
+        }
+        if (lane < 4 * (NBP - NB)) val[(lane / (NBP - NB)) * NBP + NB + lane % (NBP - NB)] = 0.f;
+        WAVE_LDS_FENCE();
+        auto mel_dot = [&](int m, int c, int trips) -> float {
+            const int c4n = mct[m];
+            const float4* wv = reinterpret_cast<const float4*>(melw + mof[m]);
+            const float4* vv = reinterpret_cast<const float4*>(val + c * NBP + mst[m]);
+            float acc = 0.f;
+            for (int i = 0; i < trips; ++i)
+                if (i < c4n) {
+                    const float4 w = (dbg & 8) ? make_float4(1.f, 2.f, 3.f, (float)i) : wv[i], x = (dbg & 8) ? make_float4(1.f, 1.f, 1.f, 1.f) : vv[i];
+                    acc = fmaf(w.x, x.x, acc); acc = fmaf(w.y, x.y, acc); acc = fmaf(w.z, x.z, acc); acc = fmaf(w.w, x.w, acc);
+                }
+            return acc;
+        };
+        // log-mel: element (m = idx >> 2, c = idx & 3) of the frame, idx = lane + 64 q: 16 contiguous bytes per mel band
+        float* frame_out = out + (size_t)t * n_mels * C_OUT;
+        if (!(dbg & 4))
+        for (int q = 0; 64 * q < 4 * n_mels; ++q) {
+            const int idx = lane + 64 * q;
+            const int tr = __builtin_amdgcn_readfirstlane(trips[q]);
+            if (idx < 4 * n_mels) {
+                const float md = mel_dot(idx >> 2, idx & 3, tr);
+                const float o = (dbg & 32) ? md : 3.0102999566f * __builtin_amdgcn_logf(fmaxf(md, 1e-10f));   // 10 log10 x = 10 log10(2) log2 x (v_log_f32)
+                lmax = fmaxf(lmax, o);
+                if (!(dbg & 16)) frame_out[(idx >> 2) * C_OUT + (idx & 3)] = o;
+            }
+        }
+        WAVE_LDS_FENCE();
+        if (MODE == 0) {
+            // ---- the three intensity planes through the same filters, no dB
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const int k = lane + 64 * i;
+                if (k < NB) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) val[c * NBP + k] = IV[c][i];
+                }
+            }
+            WAVE_LDS_FENCE();                                      // (the pad entries are still zero)
+            if (!(dbg & 4))
+            for (int q = 0; 64 * q < 3 * n_mels; ++q) {
+                const int idx = lane + 64 * q;
+                const int tr = __builtin_amdgcn_readfirstlane(trips[8 + q]);
+                if (idx < 3 * n_mels) {
+                    const float md = mel_dot(idx / 3, idx % 3, tr);
+                    if (!(dbg & 16)) frame_out[(idx / 3) * C_OUT + 4 + idx % 3] = md;
+                    else lmax = fmaxf(lmax, md);
+                }
+            }
+        } else {
+            // ---- GCC-PHAT: cc = irfft(exp(i angle(conj(Xa) Xb))) for the 6 pairs, two pairs per complex transform:
+            // Z = P1 + i P2 on the Hermitian-extended spectrum, ifft(Z) = conj(fft(conj(Z))) / N = cc1 + i cc2
+            const float invn = 1.f / (float)N;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) {
+                    const int k = lane + 64 * i;
+                    float2 Pp[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int pr = 2 * g + h;                  // pair order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+                        const float2 xa = pr < 3 ? X0[i] : (pr < 5 ? X1[i] : X2[i]);
+                        const float2 xb = pr == 0 ? X1[i] : ((pr == 1 || pr == 3) ? X2[i] : X3[i]);
+                        const float rr = xa.x * xb.x + xa.y * xb.y, ri = xa.x * xb.y - xa.y * xb.x;
+                        const float m2 = rr * rr + ri * ri, inv = __builtin_amdgcn_rsqf(m2);
+                        Pp[h] = m2 > 0.f ? make_float2(rr * inv, ri * inv) : make_float2(1.f, 0.f);   // angle(0) = 0
+                    }
+                    if (k < NB) {
+                        const int kn = (N - k) & (N - 1);
+                        buf[kn] = make_float2(Pp[0].x + Pp[1].y, Pp[0].y - Pp[1].x);      // conj(Z[N-k]), Z[N-k] = conj(P1) + i conj(P2)
+                        buf[k] = make_float2(Pp[0].x - Pp[1].y, -(Pp[0].y + Pp[1].x));   // conj(Z[k]) (k = 0, N/2: the same value twice)
+                    }
+                }
+                WAVE_LDS_FENCE();
+                wave_fft<LOGN, 1, false>(v, b1, tw, lane);
+                for (int j = lane; j < n_mels; j += 64) {
+                    const float2 r = buf[(j - n_mels / 2) & (N - 1)];
+                    frame_out[j * C_OUT + 4 + 2 * g] = r.x * invn;
+                    frame_out[j * C_OUT + 5 + 2 * g] = -r.y * invn;
+                }
+                WAVE_LDS_FENCE();
+            }
+        }
+        WAVE_LDS_FENCE();
+    }
+    // ---- clip-wide max of the dB channels (top_db clamp needs it)
+    lmax = wave_max(lmax);
+    __syncthreads();                       // every wave is done with the tables: trips[] is reused for the waves' maxima
+    if (lane_id == 0) reinterpret_cast<float*>(trips)[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = -INFINITY;
+        for (int w = 0; w < FEAT_WAVES; ++w) m = fmaxf(m, reinterpret_cast<float*>(trips)[w]);
+        gmax[blockIdx.x] = m;
+    }
+}
+
+// top_db clamp: x_db = max(x_db, max over the clip - top_db) on the four dB channels.  Every workgroup first reduces the
+// per-workgroup maxima the extraction kernel left in gmax[0 .. nparts), then walks its share of the [T * n_mels] rows.
+__global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out, const float* __restrict__ gmax, int nparts,
+                                                         int64_t n_tm, int c_out, float top_db) {
+    __shared__ float red[256];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, gmax[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    const float floor_db = red[0] - top_db;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tm * 4; i += (int64_t)gridDim.x * 256) {
+        float* p = out + (i >> 2) * c_out + (int)(i & 3);
+        *p = fmaxf(*p, floor_db);
+    }
+}
 
 // features[T_in, FC] -> (x - mean)/max(std, eps), trimmed / zero-padded to T_out rows
 // (preprocess_features_labels :117-149 followed by apply_normalizer :226-234; the reference pads BEFORE
@@ -270,6 +638,21 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
         for (int b = 0; b < mcount[m]; ++b) mw.push_back(wts[mstart[m] + b]);
     }
     if (mw.empty()) mw.push_back(0.f);
+    std::vector<int> mstart4(n_mels), mcnt4(n_mels), moff4(n_mels);
+    std::vector<float> mw4;
+    int maxc4 = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        const int lead = mstart[m] & 3;
+        mstart4[m] = mstart[m] - lead;
+        mcnt4[m] = mcount[m] ? (lead + mcount[m] + 3) / 4 : 0;
+        moff4[m] = (int)mw4.size();
+        for (int b = 0; b < 4 * mcnt4[m]; ++b) mw4.push_back(b >= lead && b < lead + mcount[m] ? mw[moff[m] + b - lead] : 0.f);
+        if (mcnt4[m] > maxc4) maxc4 = mcnt4[m];
+    }
+    if (mw4.empty()) mw4.resize(4, 0.f);
+    std::vector<int> trips(16, 0);
+    for (int idx = 0; idx < 4 * n_mels && idx < 512; ++idx) trips[idx >> 6] = std::max(trips[idx >> 6], mcnt4[idx >> 2]);
+    for (int idx = 0; idx < 3 * n_mels && idx < 384; ++idx) trips[8 + (idx >> 6)] = std::max(trips[8 + (idx >> 6)], mcnt4[idx / 3]);
     bool ok = true;
     ok &= hipMalloc(&f->win, n_fft * sizeof(float)) == hipSuccess;
     ok &= hipMalloc(&f->tw, (n_fft / 2) * sizeof(float2)) == hipSuccess;
@@ -277,7 +660,12 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
     ok &= hipMalloc(&f->mel_count, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_off, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_w, mw.size() * sizeof(float)) == hipSuccess;
-    ok &= hipMalloc(&f->gmax, 16) == hipSuccess;
+    ok &= hipMalloc(&f->gmax, FEAT_MAX_PARTS * sizeof(float)) == hipSuccess;
+    ok &= hipMalloc(&f->mel_start4, n_mels * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->mel_cnt4, n_mels * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->mel_off4, n_mels * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->mel_w4, mw4.size() * sizeof(float)) == hipSuccess;
+    ok &= hipMalloc(&f->trips, 16 * sizeof(int)) == hipSuccess;
     if (!ok) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
     hipMemcpy(f->win, win.data(), n_fft * sizeof(float), hipMemcpyHostToDevice);
     hipMemcpy(f->tw, tw.data(), (n_fft / 2) * sizeof(float2), hipMemcpyHostToDevice);
@@ -285,6 +673,14 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
     hipMemcpy(f->mel_count, mcount.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_off, moff.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_w, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice);
+    f->n_melw = (int)mw.size();
+    hipMemcpy(f->mel_start4, mstart4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(f->mel_cnt4, mcnt4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(f->mel_off4, moff4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(f->mel_w4, mw4.data(), mw4.size() * sizeof(float), hipMemcpyHostToDevice);
+    f->n_melw4 = (int)mw4.size();
+    hipMemcpy(f->trips, trips.data(), 16 * sizeof(int), hipMemcpyHostToDevice);
+    f->maxc4 = maxc4;
     *out = f;
     return SELD_OK;
 }
@@ -295,7 +691,15 @@ void seld_feat_destroy(seld_feat* f) {
     hipDeviceSynchronize();
     hipFree(f->win); hipFree(f->tw); hipFree(f->mel_start); hipFree(f->mel_count); hipFree(f->mel_off); hipFree(f->mel_w);
     hipFree(f->gmax);
+    hipFree(f->mel_start4); hipFree(f->mel_cnt4); hipFree(f->mel_off4); hipFree(f->mel_w4); hipFree(f->trips);
     delete f;
+}
+
+int seld_feat_set_option(seld_feat* f, const char* key, int value) {
+    if (!f || !key) return SELD_ERR_INVALID;
+    if (!strcmp(key, "wave_kernel")) { f->use_wave_kernel = value != 0; return SELD_OK; }
+    if (!strcmp(key, "dbg")) { f->dbg = value; return SELD_OK; }
+    return ffail(f, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 
 int64_t seld_feat_frames(const seld_feat* f, int64_t n_samples) { return f ? 1 + n_samples / f->hop : -1; }
@@ -308,21 +712,48 @@ int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_sample
     hipStream_t st = (hipStream_t)stream;
     const int N = f->n_fft, NBP = N / 2 + 1 + 3;
     const int64_t T = 1 + n_samples / f->hop;
+    int nparts = 0;
+    bool launched = false;
+    // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
+    if (f->logn >= 8 && f->logn <= 10 && f->use_wave_kernel && f->n_mels <= 128 && f->n_mels <= N) {
+        const size_t tables = (size_t)(N / 2) * sizeof(float2) + (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) +
+                              (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
+        const size_t wb = feat_wave_bytes(N, f->n_mels, f->mode == 0 ? 7 : 10), smem = tables + FEAT_WAVES * wb;
+        int64_t blocks = (T + FEAT_WAVES - 1) / FEAT_WAVES;
+        if (blocks > 1024) blocks = 1024;
+#define FEAT_WAVE_CASE(MODE_, LOGN_)                                                                                            \
+        {                                                                                                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(feat_wave_kernel<MODE_, LOGN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL((feat_wave_kernel<MODE_, LOGN_>), dim3((unsigned)blocks), dim3(64 * FEAT_WAVES), smem, st, wav, n_samples, T, \
+                               f->hop, f->n_mels, f->n_melw4, f->maxc4, f->win, f->tw, f->mel_start4, f->mel_cnt4, f->mel_off4, f->mel_w4, \
+                               out, f->gmax, (int)wb, f->dbg, f->trips);                                                                      \
+            launched = true; nparts = (int)blocks;                                                                              \
+        }
+        if (f->mode == 0) {
+            if (f->logn == 8) FEAT_WAVE_CASE(0, 8) else if (f->logn == 9) FEAT_WAVE_CASE(0, 9) else FEAT_WAVE_CASE(0, 10)
+        } else {
+            if (f->logn == 8) FEAT_WAVE_CASE(1, 8) else if (f->logn == 9) FEAT_WAVE_CASE(1, 9) else FEAT_WAVE_CASE(1, 10)
+        }
+#undef FEAT_WAVE_CASE
+    }
+    if (!launched) {
+    nparts = (int)(T < FEAT_MAX_PARTS ? T : FEAT_MAX_PARTS);
     const size_t vals = f->mode == 0 ? (size_t)7 * NBP : (size_t)4 * NBP + (size_t)12 * NBP;
     const size_t smem = (size_t)(4 * N) * sizeof(float2) + (size_t)(N / 2) * sizeof(float2) + (vals + 256) * sizeof(float);
-    hipLaunchKernelGGL(feat_init_max_kernel, dim3(1), dim3(1), 0, st, f->gmax);
     if (f->mode == 0) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(feat_frame_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(feat_frame_kernel<0>, dim3((unsigned)T), dim3(256), smem, st, wav, n_samples, N, f->logn, f->hop, f->n_mels,
+        hipLaunchKernelGGL(feat_frame_kernel<0>, dim3((unsigned)nparts), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
                            f->win, f->tw, f->mel_start, f->mel_count, f->mel_off, f->mel_w, out, f->gmax);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(feat_frame_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(feat_frame_kernel<1>, dim3((unsigned)T), dim3(256), smem, st, wav, n_samples, N, f->logn, f->hop, f->n_mels,
+        hipLaunchKernelGGL(feat_frame_kernel<1>, dim3((unsigned)nparts), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
                            f->win, f->tw, f->mel_start, f->mel_count, f->mel_off, f->mel_w, out, f->gmax);
     }
+    }
     const int64_t n_tm = T * f->n_mels;
-    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)((n_tm * 4 + 255) / 256)), dim3(256), 0, st, out, f->gmax, n_tm,
-                       f->mode == 0 ? 7 : 10, 80.f);
+    int64_t tb = (n_tm * 4 + 255) / 256;
+    if (tb > 1024) tb = 1024;
+    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)tb), dim3(256), 0, st, out, f->gmax, nparts, n_tm, f->mode == 0 ? 7 : 10, 80.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ffail(f, SELD_ERR_HIP, std::string("feat_extract: ") + hipGetErrorString(e));
     return SELD_OK;

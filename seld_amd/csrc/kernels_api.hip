@@ -357,4 +357,14 @@ int seld_k_valu_clock_mhz(int blocks, double* mhz) {
     return SELD_OK;
 }
 
+int seld_device_clocks(int device, int* compute_units, int* clock_khz, int* mem_clock_khz, int* mem_bus_bits) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return SELD_ERR_HIP;
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (mem_clock_khz) *mem_clock_khz = p.memoryClockRate;
+    if (mem_bus_bits) *mem_bus_bits = p.memoryBusWidth;
+    return SELD_OK;
+}
+
 }  // extern "C"

@@ -41,6 +41,10 @@ class FeatureExtractor:
         self.channels = int(self.lib.seld_feat_channels(h))
         self._dev = torch.device("cuda", self.device)
 
+    def set_option(self, key: str, value: int) -> None:
+        """kernel selection (seld_feat_set_option): "wave_kernel" 1 (default) | 0"""
+        _lib.check(self.lib.seld_feat_set_option(self.h, key.encode(), int(value)))
+
     def __call__(self, wav) -> torch.Tensor:
         """wav [4, n] (torch / numpy) -> device tensor [1 + n//hop, n_mels, 7|10]"""
         w = torch.as_tensor(np.asarray(wav) if not isinstance(wav, torch.Tensor) else wav)

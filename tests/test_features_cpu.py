@@ -55,3 +55,11 @@ def test_stockham_model_matches_numpy_fft():
     for n in (64, 512, 1024):
         x = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
         np.testing.assert_allclose(FO.stockham_fft(x), np.fft.fft(x), atol=1e-10)
+
+
+def test_radix4_stockham_model_matches_numpy_fft():
+    """Index model of the wave-per-frame FFT (features.hip::wave_fft): in-place radix-4 passes + a final radix-2 pass for odd log2 n."""
+    rng = np.random.default_rng(3)
+    for n in (256, 512, 1024, 2048):
+        x = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+        np.testing.assert_allclose(FO.stockham_fft_radix4(x), np.fft.fft(x), atol=1e-10)

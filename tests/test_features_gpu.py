@@ -17,22 +17,31 @@ def _wav(n, seed=0, scale=0.1):
     return base.astype(np.float32)
 
 
+# the fp32 evaluation of the SAME oracle differs from its fp64 evaluation by (max|d| / max|ref|, measured in the build
+# container on these inputs): log-mel 2e-7 .. 4e-6, spatial channels 3e-6 .. 3.2e-5 (mic, n_fft 256), 6.2e-5 on the full
+# 60-s clip's intensity vectors — all below north_star's 1e-4, which is therefore the bar for every channel here.
+@pytest.mark.parametrize("wave_kernel", [1, 0])
 @pytest.mark.parametrize("mode,sr,kw", [
     ("foa", 24000, dict(win_length=960, hop_length=480, n_fft=1024)),     # feature_extractor.py:294-301
     ("mic", 24000, dict(win_length=960, hop_length=480, n_fft=1024)),
     ("foa", 16000, dict()),                                               # function defaults: n_fft 512, hop 256
     ("mic", 16000, dict(n_fft=256)),
+    ("foa", 16000, dict(n_fft=2048, win_length=1200, hop_length=400)),
+    ("mic", 16000, dict(n_fft=128)),                                      # below the wave kernel's range: the workgroup kernel
 ])
-def test_extract_features(seld_lib, mode, sr, kw):
+def test_extract_features(seld_lib, mode, sr, kw, wave_kernel):
+    """wave_kernel 1: one wave per frame, radix-4 FFT (the default for n_fft 256..2048); 0: the workgroup-per-frame radix-2
+    kernel that serves every other size — both against the fp64 oracle at 1e-4 on every channel."""
     from oracle import features_oracle as FO
     from seld_amd import feature_extractor as FE
     wav = _wav(sr * 2 + 123, seed=3)
     ref = FO.extract_features(wav, sr, mode=mode, dtype=torch.float64, **kw)
-    got = FE.extract_features(wav, sr, mode=mode, **kw)
+    fx = FE.FeatureExtractor(sr, mode, 64, **kw)
+    fx.set_option("wave_kernel", wave_kernel)
+    got = fx(wav).cpu().numpy()
     assert got.shape == ref.shape and got.dtype == np.float32
     check(f"{mode} log-mel [{sr}]", got[..., :4], ref[..., :4])
-    # IV / GCC channels are ratios of spectra: fp32 FFT rounding dominates where a bin is near-silent
-    check(f"{mode} spatial channels [{sr}]", got[..., 4:], ref[..., 4:], tol=5e-4)
+    check(f"{mode} spatial channels [{sr}]", got[..., 4:], ref[..., 4:])
 
 
 def test_zeros_like_reference_smoke(seld_lib):
@@ -57,11 +66,11 @@ def test_full_clip_and_normalize(seld_lib):
     fx = FE.FeatureExtractor(24000, "foa", 64, **kw)
     dev = fx(wav)
     assert tuple(dev.shape) == (3001, 64, 7)
-    ref = FO.extract_features(wav, 24000, "foa", dtype=torch.float32, **kw)   # fp32 oracle: seconds, not minutes
+    ref = FO.extract_features(wav, 24000, "foa", dtype=torch.float64, **kw)
     check("full clip log-mel", dev.cpu().numpy()[..., :4], ref[..., :4])
-    check("full clip IV", dev.cpu().numpy()[..., 4:], ref[..., 4:], tol=5e-4)
+    check("full clip IV", dev.cpu().numpy()[..., 4:], ref[..., 4:])      # the fp32 oracle itself: 6.2e-5
     mean, std = FO.calculate_statistics([ref[:3000]])
     out = fx.normalize(dev, mean, std, 3000)
-    check("normalised", out.cpu().numpy(), FO.apply_normalizer(ref[:3000], mean, std), tol=5e-4)
+    check("normalised", out.cpu().numpy(), FO.apply_normalizer(ref[:3000], mean, std))
     with pytest.raises(ValueError):
         FE.FeatureExtractor(24000, "stereo")
