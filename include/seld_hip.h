@@ -110,6 +110,22 @@ int seld_forward(seld_ctx* ctx, const float* x, float* sed, float* doa, int trai
  * while the conv backward is still running on the main stream; grads[0 : *offset) (conv/BN) are final when the main
  * stream has drained.  (No counterpart in the reference, which has no distributed path.) */
 int seld_grads_tail_ready(seld_ctx* ctx, void* stream, int64_t* offset);
+/* The same hand-off at the granularity the backward pass produces gradients in: bucket 0 = the last GRU layer + the heads
+ * (final when that layer's BPTT has run and its weight-gradient GEMMs have drained on the side stream, i.e. while the earlier
+ * layers' recurrences are still running), bucket k = GRU layer n_gru-1-k, the last bucket = the conv/BN variables (final when
+ * the main stream has drained).  seld_grads_bucket_ready makes `stream` wait for bucket `index` of the last ENQUEUED
+ * seld_train_fwd_bwd and returns its [offset, offset + count) range of the flat gradient buffer. */
+int seld_grads_bucket_count(const seld_ctx* ctx);
+int seld_grads_bucket_ready(seld_ctx* ctx, int index, void* stream, int64_t* offset, int64_t* count);
+/* ---- synchronised BatchNorm for data parallelism (a B/world-per-rank run then equals the reference's
+ * single-device batch, layers.py:33 with params.py:27's batch of 256).  The library calls `fn(user, buf, count, dtype, stream)`
+ * — dtype SELD_DTYPE_F64, count 128 = [sum z | sum z^2] resp. [sum dy | sum dy xhat] per channel — once per conv block in the
+ * training forward and once in the backward; fn must enqueue an in-place SUM over the `world` ranks of the device buffer `buf`
+ * on `stream` (e.g. ncclAllReduce / torch.distributed.all_reduce) and return 0.  fn == NULL switches back to per-replica
+ * statistics.  dgamma / dbeta stay per-rank partial sums like every other gradient (the gradient all-reduce completes them). */
+#define SELD_DTYPE_F64 1
+typedef int (*seld_allreduce_fn)(void* user, void* buf, int64_t count, int dtype, void* hip_stream);
+int seld_set_sync_bn(seld_ctx* ctx, seld_allreduce_fn fn, void* user, int world);
 /* ---- train.trainstep (train.py:22-36), split so that a data-parallel host can all-reduce
  * seld_grad_ptr() between the two halves:
  *   seld_train_fwd_bwd : forward(training=True) + losses + tape.gradient -> grad buffer
@@ -285,6 +301,10 @@ int seld_debug_pool_routing(seld_ctx* ctx, int block, unsigned char* pos, unsign
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */
 int seld_k_valu_clock_mhz(int blocks, double* mhz);
+/* Diagnostic builds only (make CXXFLAGS+=-DGRU_TIMING; tools/tune_gru.py): shader-cycle sums per phase of the recurrence kernels'
+ * last launch, wave 0 of every workgroup: cycles[blocks][4] = forward {h read + mat-vec, gate tail, barrier, chunk commit},
+ * BPTT {gate gradients, barrier, coefficients + mat-vec + fold, -}.  SELD_ERR_UNSUPPORTED in the normal build. */
+int seld_k_gru_timing(int which, unsigned long long* cycles, int blocks);
 /* hipGetDeviceProperties of `device`: compute units, engine clock (kHz), memory clock (kHz), memory bus width (bits) —
  * bench.py prints the peaks they imply next to the constants its roofline fractions use. */
 int seld_device_clocks(int device, int* compute_units, int* clock_khz, int* mem_clock_khz, int* mem_bus_bits);

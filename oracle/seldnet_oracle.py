@@ -66,14 +66,23 @@ class Spec:
     sed_units: List[int]
     doa_units: List[int]
     n_classes: int = 12
+    first: str = "simple_conv_block"   # or "xception_block" (spec/XCEPTION_BLOCK.md: absent from the reference snapshot)
+    xc_blocks: int = 0                 # xception_block: number of middle-flow modules (block_num)
 
     @staticmethod
     def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
-        if model_config["FIRST"] != "simple_conv_block":
-            raise ValueError("oracle restates simple_conv_block only")
+        if model_config["FIRST"] not in ("simple_conv_block", "xception_block"):
+            raise ValueError("oracle restates simple_conv_block and xception_block only")
         if model_config["SECOND"] != "bidirectional_GRU_block":
             raise ValueError("oracle restates bidirectional_GRU_block only")
         fa = model_config["FIRST_ARGS"]
+        if model_config["FIRST"] == "xception_block":
+            # spec/XCEPTION_BLOCK.md: entry conv2d_bn(2 filters) + MaxPool(5,4), block_num residual modules of three
+            # SeparableConv2D(2 filters) + BN, exit ReLU + MaxPool(1,8)
+            return Spec(in_ch=in_ch, n_freq=n_freq, filters=[2 * int(fa["filters"])], pools=[(5, 4)],
+                        gru_units=list(model_config["SECOND_ARGS"]["units"]), sed_units=list(model_config["SED_ARGS"]["units"]),
+                        doa_units=list(model_config["DOA_ARGS"]["units"]), n_classes=int(model_config.get("n_classes", 12)),
+                        first="xception_block", xc_blocks=int(fa["block_num"]))
         return Spec(
             in_ch=in_ch, n_freq=n_freq,
             filters=list(fa["filters"]),
@@ -99,6 +108,14 @@ def variable_specs(spec: Spec) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[
     fr = spec.n_freq
     for p in spec.pools:
         fr //= p[1]
+    if spec.first == "xception_block":
+        for b in range(spec.xc_blocks):
+            for u in range(3):
+                # Keras SeparableConv2D(use_bias=False): depthwise_kernel [kh,kw,in,depth_multiplier], pointwise_kernel [1,1,in,out]
+                tr += [(f"xc{b}.{u}.depthwise_kernel", (3, 3, cin, 1)), (f"xc{b}.{u}.pointwise_kernel", (1, 1, cin, cin)),
+                       (f"xc{b}.{u}.gamma", (cin,)), (f"xc{b}.{u}.beta", (cin,))]
+                nt += [(f"xc{b}.{u}.moving_mean", (cin,)), (f"xc{b}.{u}.moving_variance", (cin,))]
+        fr //= 8      # exit MaxPooling2D((1, 8))
     feat = fr * spec.filters[-1]
     for i, u in enumerate(spec.gru_units):
         for d in ("fwd", "bwd"):
@@ -145,6 +162,8 @@ def random_weights(spec: Spec, seed: int = 0, dtype=np.float32):
             v = rng.normal(0, 0.1, n)
         elif name.endswith("recurrent_kernel"):
             v = rng.normal(0, 1.0 / math.sqrt(shape[0]), n)
+        elif name.endswith("depthwise_kernel"):
+            v = rng.normal(0, 1.0 / 3.0, n)          # 9 taps per channel
         else:
             fan_in = int(np.prod(shape[:-1]))
             v = rng.normal(0, 1.0 / math.sqrt(fan_in), n)
@@ -166,8 +185,24 @@ def conv2d_same_nhwc(x, kernel_hwio, bias):
     return y.permute(0, 2, 3, 1)
 
 
-def batchnorm(z, gamma, beta, mov_mean, mov_var, training: bool):
-    """Keras BatchNormalization(axis=-1) (layers.py:33), fused semantics. Returns y, new stats."""
+def batchnorm(z, gamma, beta, mov_mean, mov_var, training: bool, sync=None):
+    """Keras BatchNormalization(axis=-1) (layers.py:33), fused semantics. Returns y, new stats.
+    `sync = (allreduce_sum, world)`: synchronised statistics for data parallelism (what seld_set_sync_bn computes): the
+    per-channel sums are summed over the ranks by the differentiable `allreduce_sum(tensor) -> tensor`, so that B/world
+    clips per rank reproduce a single-device batch of B."""
+    if training and sync is not None:
+        allreduce_sum, world = sync
+        n = (z.numel() // z.shape[-1]) * world
+        s1 = allreduce_sum(z.sum(dim=(0, 1, 2)))
+        s2 = allreduce_sum((z * z).sum(dim=(0, 1, 2)))
+        mean = s1 / n
+        var = s2 / n - mean * mean  # biased, from the global sums (the library's formula)
+        y = (z - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+        with torch.no_grad():
+            f = 1.0 - BN_MOMENTUM
+            new_mean = mov_mean * (1 - f) + mean * f
+            new_var = mov_var * (1 - f) + var * (n / max(n - 1, 1)) * f
+        return y, new_mean.detach(), new_var.detach()
     if training:
         n = z.numel() // z.shape[-1]
         mean = z.mean(dim=(0, 1, 2))
@@ -222,7 +257,7 @@ def bigru_mul(x, w, prefix):
 
 # --------------------------------------------------------------------------- model
 def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor], x, training: bool,
-            taps: dict | None = None, routing: dict | None = None, record_routing: dict | None = None):
+            taps: dict | None = None, routing: dict | None = None, record_routing: dict | None = None, bn_sync=None):
     """models.seldnet forward (models.py:18-32). x [B,T,F,C] -> sed [B,S,nc], doa [B,S,3nc].
     Returns (sed, doa, new_state). `taps` (optional dict) receives intermediate tensors.
 
@@ -236,7 +271,7 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
     for i in range(len(spec.filters)):
         z = conv2d_same_nhwc(h, w[f"conv{i}.kernel"], w[f"conv{i}.bias"])
         y, m, v = batchnorm(z, w[f"bn{i}.gamma"], w[f"bn{i}.beta"],
-                            st[f"bn{i}.moving_mean"], st[f"bn{i}.moving_variance"], training)
+                            st[f"bn{i}.moving_mean"], st[f"bn{i}.moving_variance"], training, sync=bn_sync)
         new_st[f"bn{i}.moving_mean"], new_st[f"bn{i}.moving_variance"] = m, v
         if routing is not None and i in routing:
             pos, gate = routing[i]
@@ -254,6 +289,25 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
         if taps is not None:
             taps[f"conv{i}.z"] = z
             taps[f"pool{i}"] = h
+    if spec.first == "xception_block":
+        # spec/XCEPTION_BLOCK.md: MIDDLE flow (residual modules of three ReLU -> SeparableConv2D -> BN) and EXIT (ReLU -> pool (1,8))
+        C = h.shape[-1]
+        for b in range(spec.xc_blocks):
+            y = h
+            for u in range(3):
+                pre = f"xc{b}.{u}"
+                y = torch.relu(y)
+                dw = w[f"{pre}.depthwise_kernel"].permute(2, 3, 0, 1)           # [kh,kw,in,1] -> [in,1,kh,kw]
+                y = F.conv2d(y.permute(0, 3, 1, 2), dw, None, stride=1, padding=1, groups=C)
+                pw = w[f"{pre}.pointwise_kernel"][0, 0]                        # [in,out]
+                y = y.permute(0, 2, 3, 1) @ pw
+                y, m, v = batchnorm(y, w[f"{pre}.gamma"], w[f"{pre}.beta"], st[f"{pre}.moving_mean"], st[f"{pre}.moving_variance"],
+                                    training, sync=bn_sync)
+                new_st[f"{pre}.moving_mean"], new_st[f"{pre}.moving_variance"] = m, v
+            h = h + y
+            if taps is not None:
+                taps[f"xc{b}"] = h
+        h = maxpool_nhwc(torch.relu(h), (1, 8))
     B, S = h.shape[0], h.shape[1]
     h = h.reshape(B, S, -1)  # layers.force_1d_inputs: feature index = f*C + c
     for i in range(len(spec.gru_units)):

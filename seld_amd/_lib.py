@@ -17,6 +17,8 @@ CSRC = os.path.join(_HERE, "csrc")
 SELD_OK = 0
 SELD_DOA_MSE, SELD_DOA_MMSE = 0, 1
 SELD_DTYPE_F32 = 0
+SELD_DTYPE_F64 = 1
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # seld_allreduce_fn
 MAX_LAYERS = 4
 ERR_NAMES = {-1: "SELD_ERR_INVALID", -2: "SELD_ERR_UNSUPPORTED", -3: "SELD_ERR_HIP", -4: "SELD_ERR_NOMEM"}
 
@@ -76,6 +78,9 @@ SIGNATURES = {
     "seld_forward": (_I, [_P, _P, _P, _P, _I]),
     "seld_train_fwd_bwd": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
     "seld_grads_tail_ready": (_I, [_P, _P, C.POINTER(_L)]),
+    "seld_grads_bucket_count": (_I, [_P]),
+    "seld_grads_bucket_ready": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_L)]),
+    "seld_set_sync_bn": (_I, [_P, _P, _P, _I]),
     "seld_adam_step": (_I, [_P, _F, _F, _F, _F, _I]),
     "seld_train_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _F, _I, _P, _P, _P, _P]),
     "seld_test_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),
@@ -119,6 +124,7 @@ SIGNATURES = {
     "seld_k_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
     "seld_debug_pool_routing": (_I, [_P, _I, _P, _P]),
+    "seld_k_gru_timing": (_I, [_I, _P, _I]),
     "seld_device_clocks": (_I, [_I] + [C.POINTER(C.c_int)] * 4),
     "seld_k_valu_clock_mhz": (_I, [_I, C.POINTER(C.c_double)]),
 }

@@ -73,6 +73,11 @@ struct seld_ctx {
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_bucket[SELD_MAX_LAYERS] = {};   // side stream: GRU layer n_gru-1-k's (and, k = 0, the heads') gradients are final
+    seld_allreduce_fn sync_fn = nullptr;          // synchronised BatchNorm (seld_set_sync_bn)
+    void* sync_user = nullptr;
+    int sync_world = 1;
+    double* sync_buf = nullptr;                   // [128] sums handed to sync_fn
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
@@ -296,11 +301,19 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     // bubble per fork); host reads go through hipStreamSynchronize, peers through RCCL kernels that run on this device
     if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        // ev_join and the bucket events cross to a caller's communication stream (RCCL reads the gradients there and writes
+        // them to peers): they keep the default system-scope release
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
     }
+    for (int i = 0; i < a->n_gru; ++i)
+        if (hipEventCreateWithFlags(&c->ev_bucket[i], hipEventDisableTiming) != hipSuccess) {
+            seld_destroy(c);
+            return fail(nullptr, SELD_ERR_HIP, "event creation failed");
+        }
+    ALLOC(c->sync_buf, 128);
     for (int hd = 0; hd < 2; ++hd)
         for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
     {
@@ -344,6 +357,7 @@ void seld_destroy(seld_ctx* c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_gram) hipEventDestroy(c->ev_gram);
+    for (auto e : c->ev_bucket) if (e) hipEventDestroy(e);
     if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -365,6 +379,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 int seld_sync(seld_ctx* c) {
@@ -578,7 +593,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
-        if (training)
+        if (training && c->sync_fn) {
+            // synchronised BatchNorm: this rank's [sum z | sum z^2] -> the host's all-reduce -> coefficients of the GLOBAL batch
+            launch_bn_partials_to_sums(st, c->stat_partial, npart, c->sync_buf);
+            if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+            launch_bn_finalize_sums(st, c->sync_buf, (double)B * L.H * L.W * c->sync_world, c->params + L.g_off, c->params + L.be_off,
+                                    c->state + L.mm_off, c->state + L.mv_off, L.mean, L.invstd, L.scale, L.shift);
+        } else if (training)
             launch_bn_finalize(st, c->stat_partial, npart, (double)B * L.H * L.W, c->params + L.g_off, c->params + L.be_off,
                                c->state + L.mm_off, c->state + L.mv_off, L.mean, L.invstd, L.scale, L.shift, 64, 1);
         else
@@ -815,6 +836,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             wgrad_dense(c, c->side, c->tn_slab_side, G.h[d], 128, c->dgh[i][d], 384, rows, 128, 384, G.u_off[d], G.b_off[d] + 384, S,
                         d == 0 ? -1 : 1);
         }
+        hipEventRecord(c->ev_bucket[(int)c->gru.size() - 1 - i], c->side);   // this layer's (and, for the last layer, the heads') gradients are final
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
@@ -841,7 +863,13 @@ static int backward_impl(seld_ctx* c, const float* x) {
                                           L.H, L.W, 64, L.pt, L.pf, gz ? 1 : 0))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
         }
-        launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
+        if (c->sync_fn) {
+            launch_bn_partials_to_sums(st, c->bn_partial, np, c->sync_buf);
+            launch_bn_bwd_local(st, c->sync_buf, c->grads + L.g_off, c->grads + L.be_off);
+            if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+            launch_bn_bwd_c1c2(st, c->sync_buf, (double)B * L.H * L.W * c->sync_world, L.c1c2);
+        } else
+            launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
         int ns = 0;
         const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
         if (!fused_first) {
@@ -913,6 +941,33 @@ int seld_grads_tail_ready(seld_ctx* c, void* stream, int64_t* offset) {
     // work, complete at ev_join (recorded by the last seld_train_fwd_bwd)
     *offset = c->gru[0].k_off[0];
     HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_join, 0));
+    return SELD_OK;
+}
+
+int seld_grads_bucket_count(const seld_ctx* c) { return c ? (int)c->gru.size() + 1 : -1; }
+
+int seld_grads_bucket_ready(seld_ctx* c, int index, void* stream, int64_t* offset, int64_t* count) {
+    if (!c || !offset || !count || index < 0 || index > (int)c->gru.size()) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = (int)c->gru.size();
+    if (index == n) {               // conv / BN: the main stream's own work (+ the side stream's join)
+        *offset = 0;
+        *count = c->gru[0].k_off[0];
+        HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_join, 0));
+        return SELD_OK;
+    }
+    const int layer = n - 1 - index;
+    *offset = c->gru[layer].k_off[0];
+    *count = (index == 0 ? c->nparam : c->gru[layer + 1].k_off[0]) - *offset;
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_bucket[index], 0));
+    return SELD_OK;
+}
+
+int seld_set_sync_bn(seld_ctx* c, seld_allreduce_fn fn, void* user, int world) {
+    if (!c || world < 1) return SELD_ERR_INVALID;
+    c->sync_fn = fn;
+    c->sync_user = user;
+    c->sync_world = fn ? world : 1;
     return SELD_OK;
 }
 

@@ -368,3 +368,64 @@ int launch_pool_routing(hipStream_t st, const float* z, const float* p, const un
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Synchronised BatchNorm (seld_set_sync_bn): the block partials are first reduced to 128 double sums, the host's
+// all-reduce callback sums those over the ranks, and the coefficients come from the global sums / global count.
+__global__ __launch_bounds__(1024) void bn_partials_to_sums_kernel(const float* __restrict__ partial, int npartial,
+                                                                   double* __restrict__ sums) {
+    __shared__ double red[1024];
+    const double t = reduce_partials_128(partial, npartial, red);
+    if (threadIdx.x < 128) sums[threadIdx.x] = t;
+}
+int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums) {
+    hipLaunchKernelGGL(bn_partials_to_sums_kernel, dim3(1), dim3(1024), 0, st, partial, npartial, sums);
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_sums_kernel(const double* __restrict__ sums, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                                              float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                              float* __restrict__ scale_o, float* __restrict__ shift_o) {
+    const int c = threadIdx.x;
+    const double mean = sums[c] / count;
+    double var = sums[64 + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)SELD_BN_EPS));
+    const float sc = gamma[c] * invstd;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = invstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)mean * sc;
+    const float f = 1.f - SELD_BN_MOMENTUM;
+    const double bessel = count > 1.0 ? count / (count - 1.0) : 1.0;
+    mov_mean[c] = mov_mean[c] * (1.f - f) + (float)mean * f;
+    mov_var[c] = mov_var[c] * (1.f - f) + (float)(var * bessel) * f;
+}
+int launch_bn_finalize_sums(hipStream_t st, const double* sums, double count, const float* gamma, const float* beta,
+                            float* mov_mean, float* mov_var, float* mean, float* invstd, float* scale, float* shift) {
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(1), dim3(64), 0, st, sums, count, gamma, beta, mov_mean, mov_var, mean,
+                       invstd, scale, shift);
+    return 0;
+}
+
+// local sums -> this rank's dgamma / dbeta (the gradient all-reduce sums them like every other gradient)
+__global__ __launch_bounds__(128) void bn_bwd_local_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    const int v = threadIdx.x;
+    if (v < 64) dbeta[v] = (float)sums[v];
+    else dgamma[v - 64] = (float)sums[v];
+}
+// global sums -> c1 = sum dy / N, c2 = sum dy xhat / N over the GLOBAL batch
+__global__ __launch_bounds__(128) void bn_bwd_c1c2_kernel(const double* __restrict__ sums, double count, float* __restrict__ c1c2) {
+    c1c2[threadIdx.x] = (float)(sums[threadIdx.x] / count);
+}
+int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float* dbeta) {
+    hipLaunchKernelGGL(bn_bwd_local_kernel, dim3(1), dim3(128), 0, st, sums, dgamma, dbeta);
+    return 0;
+}
+int launch_bn_bwd_c1c2(hipStream_t st, const double* sums, double count, float* c1c2) {
+    hipLaunchKernelGGL(bn_bwd_c1c2_kernel, dim3(1), dim3(128), 0, st, sums, count, c1c2);
+    return 0;
+}

@@ -85,6 +85,7 @@ int launch_flip_weights(hipStream_t st, const float* w, float* wt);
 int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp);
 // up to 8 tensors in one launch; flip[i] != 0: the planes of the flipped (input-gradient) weights, from the unflipped tensor
 int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, unsigned short* const* dst, const int* flip);
+extern int g_conv64_dbuf;   // conv_sb.hip: 1 = double-buffered-weights kernel (default)
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights
@@ -103,6 +104,11 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, co
                               int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme = 0);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C);
+int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums);
+int launch_bn_finalize_sums(hipStream_t st, const double* sums, double count, const float* gamma, const float* beta,
+                            float* mov_mean, float* mov_var, float* mean, float* invstd, float* scale, float* shift);
+int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float* dbeta);
+int launch_bn_bwd_c1c2(hipStream_t st, const double* sums, double count, float* c1c2);
 int launch_pool_routing(hipStream_t st, const float* z, const float* p, const unsigned char* amax, const float* scale,
                         const float* shift, unsigned char* pos, unsigned char* gate, int B, int H, int W, int pt, int pf);
 int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,
@@ -154,6 +160,7 @@ int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const f
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S);
+int gru_timing_read(int which, unsigned long long* out, int blocks);
 int launch_mul(hipStream_t st, const float* a, const float* b, float* out, int64_t n);
 
 struct seld_loss_cfg;

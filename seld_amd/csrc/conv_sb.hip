@@ -450,8 +450,227 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Double-buffered-weights variant (the default for W = 16 and W = 4).  Two changes against conv64_fwd_sbr_kernel, both aimed at
+// the 18 barriers + 9 serialised weight commits per tile that held its matrix pipe at ~54 % busy:
+//  * the image is exactly W columns wide, so the region's two halo COLUMNS are always zero padding: they are not stored — a lane
+//    whose shifted column falls outside reads ONE shared all-zero row instead — and the LDS they occupied pays for
+//  * a SECOND weight buffer: tap t + 1's pre-split weights are committed while tap t's MFMAs run (they were loaded to registers a
+//    tap earlier), so a tap needs one barrier instead of commit-between-two-barriers.
+// Region = (R + 2) rows x W columns, three bf16 planes, rows XOR-swizzled; weights [2][3][64][64].
+template <int WLOG2, int R, bool STATS>
+__global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
+    float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
+    constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
+    constexpr int RR = R + 2, NPIX = RR * W, ZROW = NPIX;               // region pixels; index of the all-zero row
+    constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
+    constexpr int NW4 = 3 * 64 * 8, NWF = (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
+    constexpr int LD = 64, PLANE = (NPIX + 1) * LD, WBUF = 3 * 64 * LD;
+    static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
+    static_assert(NWF == 4 || NWF == 3, "weight staging is three or four named registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
+    unsigned short* Rp = sb_smem;                          // [3][NPIX + 1][LD]
+    unsigned short* Wp = sb_smem + 3 * PLANE;              // [2][3][64][LD]
+    float* red = reinterpret_cast<float*>(sb_smem);        // [NW][128], aliases the region after the last tile
+#define SBD_CH(p_, c_) ((c_) ^ (((p_) >> 1) & 7))          /* where 16-byte chunk c_ of row p_ lives */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, li = lane & 31;
+    const int tiles_per_img = (H + R - 1) / R;
+    const int ntiles = B * tiles_per_img;
+    int roff[NPF], rrow[NPF];    // float offset relative to the tile's first pixel (negative in the top halo row); region row or -1
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = tid + NT * u;
+        const int pix = idx >> 4, g = idx & 15;
+        const int rr = pix >> WLOG2, cc = pix & (W - 1);
+        rrow[u] = idx < NREG4 ? rr : -1;
+        roff[u] = ((rr - 1) * W + cc) * 64 + g * 4;
+    }
+    for (int i = tid; i < 3 * LD / 2; i += NT) {           // the zero row of every plane (never written again)
+        const int pl = i / (LD / 2), e = i - pl * (LD / 2);
+        reinterpret_cast<unsigned*>(Rp + pl * PLANE + ZROW * LD)[e] = 0u;
+    }
+    float4 rreg[NPF];
+    u32x4 wreg0, wreg1, wreg2, wreg3;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#define SBD_ISSUE_REGION(tile_)                                                                         \
+    {                                                                                                   \
+        const int tb_ = (tile_) / tiles_per_img, tt0_ = ((tile_) - tb_ * tiles_per_img) * R;            \
+        const float* org_ = x + (size_t)(tb_ * H + tt0_) * W * 64;                                      \
+        _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                               \
+            const int t_ = tt0_ - 1 + rrow[u];                                                          \
+            const bool ok_ = rrow[u] >= 0 && t_ >= 0 && t_ < H;                                         \
+            const float4 v_ = *reinterpret_cast<const float4*>(ok_ ? org_ + roff[u] : x);               \
+            rreg[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+        }                                                                                               \
+    }
+#define SBD_COMMIT_REGION()                                                                             \
+    _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                   \
+        const int idx = tid + NT * u;                                                                   \
+        if (idx < NREG4) {                                                                              \
+            unsigned h0, m0, l0, h1, m1, l1;                                                            \
+            split3_pair(rreg[u].x, rreg[u].y, h0, m0, l0);                                              \
+            split3_pair(rreg[u].z, rreg[u].w, h1, m1, l1);                                              \
+            unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
+            *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                         \
+            *reinterpret_cast<uint2*>(d_ + PLANE) = make_uint2(m0, m1);                                 \
+            *reinterpret_cast<uint2*>(d_ + 2 * PLANE) = make_uint2(l0, l1);                             \
+        }                                                                                               \
+    }
+#define SBD_W_SRC(tap_, u_) \
+    reinterpret_cast<const u32x4*>(wsp + (size_t)(tap_) * 3 * 4096)[(tid + NT * (u_)) < NW4 ? (tid + NT * (u_)) : 0]
+#define SBD_ISSUE_W(tap_)                                                                               \
+    {                                                                                                   \
+        wreg0 = SBD_W_SRC(tap_, 0);                                                                     \
+        wreg1 = SBD_W_SRC(tap_, 1);                                                                     \
+        wreg2 = SBD_W_SRC(tap_, 2);                                                                     \
+        if (NWF > 3) wreg3 = SBD_W_SRC(tap_, 3);                                                        \
+    }
+#define SBD_W_DST(buf_, u_, v_)                                                                         \
+    {                                                                                                   \
+        const int idx = tid + NT * (u_);                                                                \
+        if (idx < NW4) {                                                                                \
+            const int pl = idx >> 9, rem = idx & 511;      /* 512 uint4 per plane: row = rem>>3 */      \
+            *reinterpret_cast<u32x4*>(Wp + (buf_) * WBUF + pl * 64 * LD + (rem >> 3) * LD + SBD_CH(rem >> 3, rem & 7) * 8) = v_; \
+        }                                                                                               \
+    }
+#define SBD_COMMIT_W(buf_)                                                                              \
+    {                                                                                                   \
+        SBD_W_DST(buf_, 0, wreg0)                                                                       \
+        SBD_W_DST(buf_, 1, wreg1)                                                                       \
+        SBD_W_DST(buf_, 2, wreg2)                                                                       \
+        if (NWF > 3) SBD_W_DST(buf_, 3, wreg3)                                                          \
+    }
+    int tile = blockIdx.x;
+    const int pl_ = wave * 32 + li;                       // this lane's pixel of the tile
+    const int pr = pl_ >> WLOG2, pc = pl_ & (W - 1);
+    // region row of this lane's A fragment per column shift dx = 0, 1, 2 at tap row 0 (ZROW: outside the image)
+    const int prow0 = pc >= 1 ? pr * W + pc - 1 : -1, prow1 = pr * W + pc, prow2 = pc + 1 < W ? pr * W + pc + 1 : -1;
+    if (tile < ntiles) {
+        SBD_ISSUE_REGION(tile)
+        SBD_ISSUE_W(0)
+        SBD_COMMIT_REGION()
+        SBD_COMMIT_W(0)
+        SBD_ISSUE_W(1)                                    // tap 1 rides in the registers until tap 0's loop body commits it
+    }
+    lds_barrier();
+    int wb = 0;                                           // weight buffer that holds the tap being computed
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * R;
+        const int nxt = tile + gridDim.x;
+        SBD_ISSUE_REGION(nxt < ntiles ? nxt : tile)     // unconditional: no phi on the staged registers
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2] = {zero16(), zero16()}, accs[2] = {zero16(), zero16()};
+        const int wsw = (li >> 1) & 7;        // swizzle key of weight rows li and li + 32 (the same)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // the registers hold tap + 1 (tap 8: tap 0 of the next tile): into the buffer nobody reads in this tap, then fetch tap + 2
+            SBD_COMMIT_W(wb ^ 1)
+            SBD_ISSUE_W(tap < 7 ? tap + 2 : tap - 7)
+            __builtin_amdgcn_sched_barrier(0);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int pbase_ = dx == 0 ? prow0 : (dx == 1 ? prow1 : prow2);
+            const int prow = pbase_ >= 0 ? pbase_ + dy * W : ZROW;
+            const unsigned short* arow = Rp + prow * LD;
+            const unsigned short* wrow0 = Wp + wb * WBUF + li * LD;
+            const int asw = (prow >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[3], bb[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const int ca = (2 * s + hi) ^ asw, cw = (2 * s + hi) ^ wsw;
+                    a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * PLANE + 8 * ca);
+                    bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 8 * cw);
+                    bb[pl][1] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 32 * LD + 8 * cw);
+                }
+#define SBD_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+                SBD_MFMA(a[0], bb[0][0], acc[0]);  SBD_MFMA(a[0], bb[0][1], acc[1]);     // hi*hi
+                SBD_MFMA(a[0], bb[1][0], accs[0]); SBD_MFMA(a[0], bb[1][1], accs[1]);    // hi*mid
+                SBD_MFMA(a[1], bb[0][0], acc[0]);  SBD_MFMA(a[1], bb[0][1], acc[1]);     // mid*hi
+                SBD_MFMA(a[0], bb[2][0], accs[0]); SBD_MFMA(a[0], bb[2][1], accs[1]);    // hi*lo
+                SBD_MFMA(a[2], bb[0][0], acc[0]);  SBD_MFMA(a[2], bb[0][1], acc[1]);     // lo*hi
+                SBD_MFMA(a[1], bb[1][0], accs[0]); SBD_MFMA(a[1], bb[1][1], accs[1]);    // mid*mid
+#undef SBD_MFMA
+            }
+            lds_barrier();      // tap + 1's weights are visible; everyone is done with this tap's buffer
+            wb ^= 1;
+        }
+        SBD_COMMIT_REGION()     // next tile's region (every wave passed the barrier after tap 8's reads)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float bv = bias ? bias[c * 32 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 32 + mfma_row(r, hi);          // pixel of the tile
+                const int t = t0 + (p >> WLOG2);
+                if (t < H) {
+                    const float v = (acc[c][r] + accs[c][r]) + bv;
+                    z[((size_t)(b * H + t) * W + (p & (W - 1))) * 64 + c * 32 + li] = v;
+                    s1[c] += v;
+                    s2[c] = fmaf(v, v, s2[c]);
+                }
+            }
+        }
+        lds_barrier();          // the committed region is visible to every wave
+    }
+#undef SBD_ISSUE_REGION
+#undef SBD_COMMIT_REGION
+#undef SBD_ISSUE_W
+#undef SBD_COMMIT_W
+#undef SBD_CH
+#undef SBD_W_SRC
+#undef SBD_W_DST
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        __syncthreads();
+        if (hi == 0) {
+            red[wave * 128 + li] = s1[0];
+            red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0];
+            red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * 128 + tid];
+            stat_partial[(size_t)blockIdx.x * 128 + tid] = t;
+        }
+    }
+}
+
+int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights) for W = 16 / 4; 0: conv64_fwd_sbr_kernel
+
+template <int WLOG2, int R>
+static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
+                      float* stat_partial, int* n_partial, int B, int H) {
+    constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * W;
+    const int ntiles = B * ((H + R - 1) / R);
+    const int grid = ntiles < 256 ? ntiles : 256;      // one block per CU (LDS-limited), persistent
+    const size_t smem = (size_t)(3 * (NPIX + 1) * 64 + 2 * 3 * 64 * 64) * sizeof(unsigned short);
+    static_assert((size_t)(3 * ((R + 2) * (1 << WLOG2) + 1) * 64 + 2 * 3 * 64 * 64) * 2 <= 163840, "LDS");
+    static_assert((size_t)NW * 128 * 4 <= (size_t)3 * (NPIX + 1) * 64 * 2, "the statistics buffer aliases the region");
+    if (stat_partial) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+    }
+    if (n_partial) *n_partial = grid;
+    return 0;
+}
+
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W) {
+    if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 8 waves, 156 KB
+    if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 6 waves
     if (W == 16) return launch_sbr<4, 16, true>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves, 153 KB
     if (W == 4) return launch_sbr<2, 48, false>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 6 waves (halo columns: no room for 8)
     const int npix = B * H * W;

@@ -24,6 +24,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // on gfx950, so the mat-vec of the recurrence (the step's longest phase) runs twice as fast packed.
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// -DGRU_TIMING (diagnostic build only, tools/tune_gru.py): per-phase shader-cycle sums of wave 0 of every workgroup, read back
+// with seld_k_gru_timing.  Stamps follow cdna_hip_programming.md section 7 (s_memtime + lgkmcnt(0) in ONE asm statement between
+// sched_barriers); they perturb the schedule (their waits drain the LDS queue), so read the SHARES, not the total.
+#ifdef GRU_TIMING
+__device__ unsigned long long g_gru_timing[2][512][4];    // [fwd | bwd][workgroup][phase]
+#define GRU_STAMP(t_)                                                                      \
+    {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+#else
+#define GRU_STAMP(t_)
+#endif
+
 #define GRU_U 128
 #define GRU_G 384
 #define GRUF_CH 16   // forward: steps per staged chunk
@@ -99,6 +114,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     GRUF_ISSUE(0)
     GRUF_COMMIT(0)
     __syncthreads();
+#ifdef GRU_TIMING
+    unsigned long long tm_mv = 0, tm_tail = 0, tm_bar = 0, tm_commit = 0, tm_last = 0;
+#endif
     int step = 0;
     for (int c = 0; c < nchunks; ++c) {
         int n, tlo;
@@ -108,6 +126,10 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         GRUF_ISSUE(min(c + 1, nchunks - 1))
         const float* gb = gxl[c & 1];
         auto do_step = [&](int i) {
+#ifdef GRU_TIMING
+            unsigned long long ts0, ts1, ts2;
+            GRU_STAMP(ts0)
+#endif
             const int row = dir ? n - 1 - i : i;
             const int t = tlo + row;
             // lanes q = 0, 2 of a quad finish the update gate, lanes 1, 3 the reset gate: each reads only its own input term
@@ -121,6 +143,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 az2 = pk_fma(h01, u[0][2 * k4], az2); ar2 = pk_fma(h01, u[1][2 * k4], ar2); ah2 = pk_fma(h01, u[2][2 * k4], ah2);
                 az2 = pk_fma(h23, u[0][2 * k4 + 1], az2); ar2 = pk_fma(h23, u[1][2 * k4 + 1], ar2); ah2 = pk_fma(h23, u[2][2 * k4 + 1], ah2);
             }
+#ifdef GRU_TIMING
+            GRU_STAMP(ts1)
+#endif
             const float az = az2.x + az2.y, ar = ar2.x + ar2.y;
             float ah = ah2.x + ah2.y;
             // fold the z and r sums instead of two quad sums: with its xor-1 neighbour a lane trades the sum it does not
@@ -148,16 +173,32 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                                     (__float_as_uint(ghh) & sel3);
                 sv[((size_t)t * 4 + q) * GRU_U + j] = __uint_as_float(vb);
             }
+#ifdef GRU_TIMING
+            GRU_STAMP(ts2)
+            tm_mv += ts1 - ts0; tm_tail += ts2 - ts1; tm_last = ts2;
+#endif
             ++step;
         };
         for (int i = 0; i < n - 1; ++i) {
             do_step(i);
             lds_barrier();   // LDS-only: __syncthreads() would also drain vmcnt, i.e. wait for this step's global stores
+#ifdef GRU_TIMING
+            { unsigned long long tb; GRU_STAMP(tb) tm_bar += tb - tm_last; }
+#endif
         }
         do_step(n - 1);
         GRUF_COMMIT((c + 1) & 1)  // the only wait on the staged loads: one chunk after their issue
         lds_barrier();
+#ifdef GRU_TIMING
+        { unsigned long long tb; GRU_STAMP(tb) tm_commit += tb - tm_last; }
+#endif
     }
+#ifdef GRU_TIMING
+    if (tid == 0 && blockIdx.x < 512) {
+        g_gru_timing[0][blockIdx.x][0] = tm_mv; g_gru_timing[0][blockIdx.x][1] = tm_tail;
+        g_gru_timing[0][blockIdx.x][2] = tm_bar; g_gru_timing[0][blockIdx.x][3] = tm_commit;
+    }
+#endif
 }
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
@@ -270,6 +311,9 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     commit(0);
     __syncthreads();
     float carry = 0.f;    // carry of unit jm
+#ifdef GRU_TIMING
+    unsigned long long tm_p1 = 0, tm_bar = 0, tm_p2 = 0;
+#endif
     int step = 0;
     // Everything in a step's gate gradients except the factor dh = dout*h_other + carry is known before the step's carry
     // is: a_z = dh*kz, a_r = dh*kr, a_h = dh*kh, a_h*r = dh*khr with kh = (1-z)(1-hh^2), kz = (h_prev-hh) z (1-z),
@@ -343,10 +387,24 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             ++step;
         };
         for (int i = 0; i < n - 1; ++i) {
+#ifdef GRU_TIMING
+            unsigned long long tb0, tb1, tb2, tb3;
+            GRU_STAMP(tb0)
+#endif
             part1(i);
+#ifdef GRU_TIMING
+            GRU_STAMP(tb1)
+#endif
             lds_barrier();   // LDS-only barrier: never wait for the dgx/dgh stores
+#ifdef GRU_TIMING
+            GRU_STAMP(tb2)
+#endif
             pre(sb, dir ? i + 1 : n - 2 - i);
             part2();
+#ifdef GRU_TIMING
+            GRU_STAMP(tb3)
+            tm_p1 += tb1 - tb0; tm_bar += tb2 - tb1; tm_p2 += tb3 - tb2;
+#endif
         }
         part1(n - 1);
         commit((c + 1) & 1);  // the only wait on the staged loads
@@ -359,6 +417,12 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         }
         part2();
     }
+#ifdef GRU_TIMING
+    if (tid == 0 && blockIdx.x < 512) {
+        g_gru_timing[1][blockIdx.x][0] = tm_p1; g_gru_timing[1][blockIdx.x][1] = tm_bar;
+        g_gru_timing[1][blockIdx.x][2] = tm_p2; g_gru_timing[1][blockIdx.x][3] = 0;
+    }
+#endif
 }
 
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
@@ -369,4 +433,16 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);
     return 0;
+}
+
+// per-phase cycle sums of the last gru_fwd (which = 0) / gru_bwd (1) launch: out[blocks][4]; -2 unless built with -DGRU_TIMING
+int gru_timing_read(int which, unsigned long long* out, int blocks) {
+#ifdef GRU_TIMING
+    if (which < 0 || which > 1 || blocks < 1 || blocks > 512) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gru_timing), (size_t)blocks * 4 * sizeof(unsigned long long),
+                               (size_t)which * 512 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+#else
+    return -2;
+#endif
 }

@@ -35,6 +35,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_split_bf16")) { g_conv1_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
     return SELD_ERR_INVALID;
@@ -355,6 +356,12 @@ int seld_k_valu_clock_mhz(int blocks, double* mhz) {
     std::sort(r.begin(), r.end());
     *mhz = r[r.size() / 2];
     return SELD_OK;
+}
+
+int seld_k_gru_timing(int which, unsigned long long* cycles, int blocks) {
+    if (!cycles) return SELD_ERR_INVALID;
+    const int rc = gru_timing_read(which, cycles, blocks);
+    return rc == 0 ? SELD_OK : (rc == -2 ? SELD_ERR_UNSUPPORTED : SELD_ERR_INVALID);
 }
 
 int seld_device_clocks(int device, int* compute_units, int* clock_khz, int* mem_clock_khz, int* mem_bus_bits) {

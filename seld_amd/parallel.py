@@ -3,8 +3,9 @@
 The reference has no distributed path; this is the MI355X-native addition.  The
 SELDnet step shards by clips: every rank holds a full 2 MB weight replica and B/world clips; the
 only exchange is the all-reduce(SUM) of the flat fp32 gradient buffer (513 840 floats = 2.06 MB,
-latency-bound on xGMI) between backward and Adam — in two buckets, the large one overlapped with the conv backward —, plus one scalar all-reduce for the MMSE mask
-count.  BatchNorm statistics stay per replica.
+latency-bound on xGMI) between backward and Adam — in the buckets the backward pass finishes them in, all but the small conv/BN
+one overlapped with the rest of the backward —, plus one scalar all-reduce for the MMSE mask count.  BatchNorm statistics are per
+replica by default; `enable_sync_batchnorm` makes them global (six 1-KB all-reduces per step).
 
 Loss-reduction rules that make the summed gradient equal the single-device gradient of the
 global batch (derivation in DESIGN.md §5):
@@ -36,11 +37,11 @@ def loss_scaling(is_mmse: bool, local_den: torch.Tensor | None, group=None):
 def allreduce_gradients(flat_grad: torch.Tensor, group=None, model=None, force: bool = False) -> None:
     """Sum the flat gradient buffer in place over ranks.
 
-    With `model` (a SeldNet on a GPU) the buffer goes in two buckets: the GRU + head gradients (86 % of the bytes)
-    are final early in the backward pass — the library produces them on its side stream — so their all-reduce is
-    issued on a communication stream that waits for exactly that (seld_grads_tail_ready) and runs UNDER the conv
-    backward still executing on the main stream; the conv/BN bucket follows on the main stream.  Both are complete
-    (for the main stream) on return.  Without `model` (CPU tensors, gloo tests): one bucket."""
+    With `model` (a SeldNet on a GPU) the buffer goes in the buckets the backward pass produces it in
+    (seld_grads_bucket_ready): the last GRU layer + the heads first — final while the earlier layers' recurrences are
+    still running —, then each earlier GRU layer, each on a communication stream that waits for exactly that bucket's
+    event; the conv/BN bucket follows on the main stream when the step's kernels are enqueued.  All are complete (for the
+    main stream) on return.  Without `model` (CPU tensors, gloo tests): one bucket."""
     if world_size(group) <= 1 and not force:        # force: exercise the collective path on a one-rank group (tests)
         return
     d = torch.distributed
@@ -52,10 +53,52 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None, model=None, force: 
     comm = getattr(model, "_comm_stream", None)
     if comm is None:
         comm = model._comm_stream = torch.cuda.Stream(device=flat_grad.device)
-    off = C.c_int64()
-    _lib.check(model.lib.seld_grads_tail_ready(model.ctx, C.c_void_p(comm.cuda_stream), C.byref(off)), model.ctx)
-    with torch.cuda.stream(comm):
-        tail = d.all_reduce(flat_grad[off.value:], group=group, async_op=True)
-    head = d.all_reduce(flat_grad[:off.value], group=group, async_op=True)
-    head.wait()
-    tail.wait()          # the current (main) stream waits for both before Adam
+    nb = int(model.lib.seld_grads_bucket_count(model.ctx))
+    works = []
+    off, cnt = C.c_int64(), C.c_int64()
+    for k in range(nb - 1):
+        _lib.check(model.lib.seld_grads_bucket_ready(model.ctx, k, C.c_void_p(comm.cuda_stream), C.byref(off), C.byref(cnt)), model.ctx)
+        with torch.cuda.stream(comm):
+            works.append(d.all_reduce(flat_grad[off.value:off.value + cnt.value], group=group, async_op=True))
+    # conv / BN variables: produced by the main stream itself
+    cur = torch.cuda.current_stream(flat_grad.device)
+    _lib.check(model.lib.seld_grads_bucket_ready(model.ctx, nb - 1, C.c_void_p(cur.cuda_stream), C.byref(off), C.byref(cnt)), model.ctx)
+    works.append(d.all_reduce(flat_grad[off.value:off.value + cnt.value], group=group, async_op=True))
+    for wk in works:
+        wk.wait()          # the current (main) stream waits for every bucket before Adam
+
+
+def enable_sync_batchnorm(model, group=None, force: bool = False) -> None:
+    """Synchronised BatchNorm over the ranks of `group` (seld_set_sync_bn): the per-channel sums of every conv block's
+    BatchNormalization are all-reduced in the training forward and in the backward pass, so that B/world clips per rank
+    reproduce the reference's single-device batch of B (layers.py:33).  Six 1-KB collectives per step."""
+    import ctypes as C
+    from . import _lib
+    world = world_size(group)
+    if world <= 1 and not force:
+        model.lib.seld_set_sync_bn(model.ctx, None, None, 1)
+        model._sync_bn_cb = None
+        return
+    dev = model._dev
+
+    def _cb(_user, buf, count, dtype, _stream):
+        try:
+            t = torch.as_tensor(_F64Ptr(int(buf), int(count)), device=dev) if dtype == _lib.SELD_DTYPE_F64 else None
+            if t is None:
+                return 1
+            torch.distributed.all_reduce(t, group=group)       # enqueued behind the library's stream (= torch's current stream)
+            return 0
+        except Exception:                                       # never let an exception cross the C ABI
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    model._sync_bn_cb = _lib.ALLREDUCE_FN(_cb)                  # keep the trampoline alive as long as the ctx may call it
+    _lib.check(model.lib.seld_set_sync_bn(model.ctx, C.cast(model._sync_bn_cb, C.c_void_p), None, world), model.ctx)
+
+
+class _F64Ptr:
+    """A raw device pointer to `n` doubles owned by the HIP library, exposed to torch without a copy."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}

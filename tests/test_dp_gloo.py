@@ -84,3 +84,70 @@ def test_two_rank_gradient_equals_global_objective(mode):
     assert err < 1e-9
     if mode == "MMSE":
         assert sed_scale == 0.5 and den > 0
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """differentiable all-reduce(SUM): the backward of a sum over ranks is the sum over ranks of the incoming gradients"""
+
+    @staticmethod
+    def forward(ctx, t):
+        t = t.clone()
+        dist.all_reduce(t)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import seldnet_oracle as O
+    from seld_amd import parallel
+    from __graft_entry__ import SELDNET_CONFIG
+    spec = O.Spec.from_config(SELDNET_CONFIG)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(2 * world, 50, seed=99)
+    sl = slice(2 * rank, 2 * rank + 2)
+    tr, nt = O.variable_specs(spec)
+    fw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    sed, doa, new_st = O.forward(spec, O.unflatten(fw, tr), O.unflatten(torch.tensor(st, dtype=torch.float64), nt),
+                                 torch.tensor(x[sl], dtype=torch.float64), True, bn_sync=(_AllReduceSum.apply, world))
+    obj, _, _ = O.losses_and_objective(sed, doa, torch.tensor(ys[sl], dtype=torch.float64), torch.tensor(yd[sl], dtype=torch.float64),
+                                       "MSE", (1.0, 1000.0))
+    (g,) = torch.autograd.grad(obj, fw)
+    parallel.allreduce_gradients(g)
+    if rank == 0:
+        q.put((g.numpy(), sed.detach().numpy(), torch.cat([new_st[n].reshape(-1) for n, _ in nt]).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_single_process_batch():
+    """The SyncBN rule the library implements (seld_set_sync_bn: global sums -> mean/var and c1/c2, per-rank dgamma/dbeta):
+    2 ranks x 2 clips with synchronised statistics == ONE process on the 4-clip batch — gradient, outputs, moving statistics."""
+    from oracle import seldnet_oracle as O
+    from __graft_entry__ import SELDNET_CONFIG
+    world, port = 2, 30600 + (os.getpid() % 500)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    g_dp, sed0, state = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spec = O.Spec.from_config(SELDNET_CONFIG)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(2 * world, 50, seed=99)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64)
+    err = np.abs(g_dp - ref["grad"]).max() / np.abs(ref["grad"]).max()
+    print(f"[dp] SyncBN: rel_err={err:.2e}")
+    assert err < 1e-9
+    assert np.abs(sed0 - ref["sed"][:2]).max() < 1e-12
+    assert np.abs(state - ref["new_state"]).max() < 1e-9

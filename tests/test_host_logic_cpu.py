@@ -106,3 +106,43 @@ def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
             bad[head][key] = val
             with pytest.raises(ValueError):
                 models._arch_from_config(bad, 7, 64)
+
+
+def test_keras_h5_name_mapping_on_a_hand_built_name_list():
+    """tools/keras_h5_to_npz.py (reference seams train.py:372-380 / :322-331 / evaluator.py:57): the Keras-variable -> seld_amd
+    mapping is a pure function of names and shapes, tested here on the names Keras gives model_config/seldnet.json's layers
+    (h5py, which the converter's file IO needs, is absent from this image)."""
+    import importlib.util
+    from conftest import ROOT
+    spec_ = importlib.util.spec_from_file_location("keras_h5_to_npz", os.path.join(ROOT, "tools", "keras_h5_to_npz.py"))
+    K = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(K)
+    kv = []
+    # a checkpoint taken in a session where earlier models had been built: suffixes do not start at 0 and the file order is alphabetical
+    for i, cin in zip((4, 5, 6), (7, 64, 64)):
+        kv += [(f"conv2d_{i}/kernel:0", (3, 3, cin, 64)), (f"conv2d_{i}/bias:0", (64,))]
+        kv += [(f"batch_normalization_{i}/{leaf}:0", (64,)) for leaf in ("gamma", "beta", "moving_mean", "moving_variance")]
+    for b, (fw, bw) in (("bidirectional_2", ("gru_cell_7", "gru_cell_8")), ("bidirectional_3", ("gru_cell_10", "gru_cell_11"))):
+        for tag, cell in (("forward_gru_" + b[-1], fw), ("backward_gru_" + b[-1], bw)):
+            kv += [(f"{b}/{tag}/{cell}/kernel:0", (128, 384)), (f"{b}/{tag}/{cell}/recurrent_kernel:0", (128, 384)),
+                   (f"{b}/{tag}/{cell}/bias:0", (2, 384))]
+    kv += [("conv1d_2/kernel:0", (1, 128, 128)), ("conv1d_2/bias:0", (128,)), ("conv1d_3/kernel:0", (1, 128, 128)), ("conv1d_3/bias:0", (128,))]
+    kv += [("sed_out/kernel:0", (128, 12)), ("sed_out/bias:0", (12,)), ("doa_out/kernel:0", (128, 36)), ("doa_out/bias:0", (36,))]
+    kv = sorted(kv)
+    m = K.map_keras_variables(kv)
+    ours = K.our_variable_shapes()
+    K.check_shapes(m, kv, ours)
+    # the converter's variable list is the oracle's (and so the C library's) variable list
+    from oracle import seldnet_oracle as O
+    from __graft_entry__ import SELDNET_CONFIG
+    tr, nt = O.variable_specs(O.Spec.from_config(SELDNET_CONFIG))
+    assert {n: tuple(s) for n, s in tr + nt} == ours and sum(int(np.prod(s)) for _, s in tr) == 513840
+    assert m["conv0.kernel"] == "conv2d_4/kernel:0" and m["bn2.moving_variance"] == "batch_normalization_6/moving_variance:0"
+    assert m["gru1.bwd.recurrent_kernel"] == "bidirectional_3/backward_gru_3/gru_cell_11/recurrent_kernel:0"
+    assert m["sed.dense0.kernel"] == "conv1d_2/kernel:0" and m["doa.dense0.bias"] == "conv1d_3/bias:0"
+    assert m["doa.out.kernel"] == "doa_out/kernel:0" and len(m) == len(ours)
+    with pytest.raises(ValueError):                       # a layer missing
+        K.map_keras_variables([v for v in kv if not v[0].startswith("conv2d_6")])
+    bad = [(n, (3, 3, 10, 64) if n == "conv2d_4/kernel:0" else s) for n, s in kv]
+    with pytest.raises(ValueError):                       # a mic-feature checkpoint into a foa model
+        K.check_shapes(K.map_keras_variables(bad), bad, ours)

@@ -242,6 +242,25 @@ def test_sliding_window_inference(seldnet_config):
     assert got[0][0].shape[0] == (1 + (120 - 50) // 5) - 1 + 10
 
 
+def test_sliding_window_inference_reference_geometry(seldnet_config):
+    """The reference's own inference geometry (evaluator.py:16-50): a 3000-frame file, 300-frame windows every 5 frames -> 541
+    windows -> model(windows, training=False) in batches of 256 -> overlap-add average -> [600, 12], [600, 36]."""
+    from oracle import infer_oracle as IO
+    from oracle import seldnet_oracle as O
+    from seld_amd import evaluator, models
+    spec = O.Spec.from_config(seldnet_config)
+    w, st = O.random_weights(spec, 0)
+    x = np.random.default_rng(8).standard_normal((3000, 64, 7)).astype(np.float32)
+    model = models.seldnet((256, 300, 64, 7), seldnet_config)
+    model.set_weights(w, st)
+    (gs, gd), = evaluator.ensemble_outputs(model, [x], win_size=300, step_size=5, batch_size=256)
+    assert tuple(gs.shape) == (600, 12) and tuple(gd.shape) == (600, 36)       # 541 - 1 + 60 label frames
+    (rs, rd), = IO.ensemble_outputs(spec, w, st, [x], win_size=300, step_size=5, dtype=torch.float32)   # 541 windows: fp32 oracle, seconds
+    assert rs.shape == (600, 12)
+    check("ensemble 541x300 sed", gs.cpu().numpy(), rs)
+    check("ensemble 541x300 doa", gd.cpu().numpy(), rd)
+
+
 def test_train_step_mic_features(seldnet_config):
     """'mic' mode of the reference (feature_extractor.py:78-80): 10-channel input [4 log-mel + 6 GCC]."""
     from oracle import seldnet_oracle as O
@@ -425,8 +444,12 @@ def test_full_batch_vs_golden(seldnet_config, mode):
     at 20 M pooling windows a handful of windows have their two largest elements (or their maximum and 0) within one fp32
     rounding of each other (`near_ties` in the fixture: 49 first-block windows with an fp64 margin below 1e-6), and every such
     routing flip moves one whole gradient element.  WHICH of them flip is chance (7 here, profiles/r02_routing_flips_b32.log),
-    so an fp32 evaluation lands within a small factor of another one's error, not below it: the factor 3.  That the flips
-    are all there is to it is test_parity_given_identical_routing's job."""
+    so an fp32 evaluation lands within a small factor of another one's error, not below it: the factor 3 — and a conv-stack
+    variable the fp32 oracle happened to get through without a flip (bn2.beta in MMSE mode: 3e-6) can still catch one here (one
+    ReLU-gate flip in the third block: 1.6e-4), so conv / bn variables get a floor of 5e-4, the size of the fp32 oracle's own
+    flip-caused errors on such variables at this size (bn0.gamma 4.3e-4, bn1.* 1.2e-4, conv2.kernel 1.1e-4).  Everything after the
+    conv stack stays at 1e-4 (measured: <= 1e-6).  That the flips are all there is to it is
+    test_parity_given_identical_routing's job (and tools/diag_routing_flips.py at this size: profiles/r02_routed_parity_b32.log)."""
     import importlib.util
     import os
     from conftest import ROOT
@@ -456,7 +479,7 @@ def test_full_batch_vs_golden(seldnet_config, mode):
             # exactly 0 in exact arithmetic (a bias in front of training-mode BatchNorm): rounding noise on both sides
             assert np.abs(gv).max() <= 1e-3 * z["grad_max"].max(), n
             continue
-        bar = max(1e-4, 3.0 * float(z["bar_fp32"][i]))
+        bar = max(5e-4 if n.startswith(("conv", "bn")) else 1e-4, 3.0 * float(z["bar_fp32"][i]))
         e = np.abs(gv[mg.sample_index(n, k)] - z["g." + n]).max() / z["grad_max"][i]
         en = abs(np.linalg.norm(gv) - z["grad_norms"][i]) / z["grad_norms"][i]
         print(f"[parity] full grad {n:28s} rel_err={e:.3e} norm_err={en:.3e} bar={bar:.3e} (fp32 oracle: {z['bar_fp32'][i]:.3e})")
@@ -518,3 +541,95 @@ def test_parity_given_identical_routing(seldnet_config):
     ref = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
     print(f"[routing] {n_flip} decisions differ from the free-running fp64 oracle; gradients against the fp64 oracle WITH the library's routing:")
     _per_var(model, "routed grad", g, ref["grad"])
+
+
+def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
+    """seld_set_sync_bn: two replicas (two ctxs on the one test GPU, driven by two host threads, their all-reduce callback a
+    rendezvous that sums the two 128-double buffers on the host) each train on half of a batch; with synchronised BatchNorm the
+    SUM of their gradient buffers, their outputs and their BN moving statistics must equal the oracle's single-process step on
+    the whole batch — the reference's single-device semantics (layers.py:33), which per-replica statistics only approximate.
+    Also checks the gradient buckets of the DP path (seld_grads_bucket_ready): contiguous, disjoint, covering the buffer."""
+    import ctypes as C
+    import threading
+    from oracle import seldnet_oracle as O
+    from seld_amd import _lib, losses, models, train
+    spec = O.Spec.from_config(seldnet_config)
+    w, st = O.random_weights(spec, 0)
+    B, T = 4, 100
+    x, ys, yd = O.synthetic_batch(B, T, seed=31)
+    reps = [models.seldnet((B // 2, T, 64, 7), seldnet_config) for _ in range(2)]
+    host = [None, None]
+    bar = threading.Barrier(2)
+    calls = [0, 0]
+    errors = []
+
+    def make_cb(r):
+        def cb(_user, buf, count, dtype, _stream):
+            try:
+                assert dtype == _lib.SELD_DTYPE_F64 and count == 128
+                from seld_amd.parallel import _F64Ptr
+                t = torch.as_tensor(_F64Ptr(int(buf), int(count)), device="cuda")
+                torch.cuda.current_stream().synchronize()        # the library enqueued the sums on this thread's current stream
+                host[r] = t.cpu().numpy().copy()
+                bar.wait(timeout=60)
+                tot = host[0] + host[1]
+                bar.wait(timeout=60)
+                t.copy_(torch.as_tensor(tot).cuda())
+                calls[r] += 1
+                return 0
+            except Exception as e:       # noqa: BLE001
+                errors.append(e)
+                bar.abort()
+                return 1
+        return _lib.ALLREDUCE_FN(cb)
+
+    cbs = [make_cb(r) for r in range(2)]
+    out = [None, None]
+
+    def run(r):
+        try:
+            m = reps[r]
+            m.set_weights(w, st)
+            _lib.check(m.lib.seld_set_sync_bn(m.ctx, C.cast(cbs[r], C.c_void_p), None, 2), m.ctx)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                sl = slice(r * B // 2, (r + 1) * B // 2)
+                xd = m._prep(x[sl])
+                ysd, ydd = train._labels(m, (ys[sl], yd[sl]), B // 2)
+                sed, doa = m._outputs(B // 2)
+                cfg = train._cfg(losses.MSE, (1.0, 1000.0))
+                _lib.check(m.lib.seld_train_fwd_bwd(m.ctx, xd.data_ptr(), ysd.data_ptr(), ydd.data_ptr(), C.byref(cfg), sed.data_ptr(),
+                                                    doa.data_ptr(), None, None), m.ctx)
+                torch.cuda.current_stream().synchronize()
+                out[r] = (sed.cpu().numpy(), doa.cpu().numpy(), m.get_grads().astype(np.float64), m.get_weights()[1])
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+            bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=120)
+    assert not errors, errors
+    assert calls == [6, 6]                                           # 3 conv blocks x (forward + backward)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64)
+    check("syncbn sed", np.concatenate([out[0][0], out[1][0]]), ref["sed"])
+    check("syncbn doa", np.concatenate([out[0][1], out[1][1]]), ref["doa"])
+    _per_var(reps[0], "syncbn grad", out[0][2] + out[1][2], ref["grad"])
+    check("syncbn moving stats rank0", out[0][3], ref["new_state"])
+    check("syncbn moving stats rank1", out[1][3], ref["new_state"])
+    # gradient buckets: last GRU layer + heads | earlier GRU layers ... | conv/BN
+    m = reps[0]
+    nb = m.lib.seld_grads_bucket_count(m.ctx)
+    assert nb == 3
+    spans = []
+    for k in range(nb):
+        off, cnt = C.c_int64(), C.c_int64()
+        _lib.check(m.lib.seld_grads_bucket_ready(m.ctx, k, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(off), C.byref(cnt)), m.ctx)
+        spans.append((off.value, cnt.value))
+    first = {p: min(o for n, o, _ in m.variables if n.startswith(p)) for p in ("conv", "gru0", "gru1")}
+    assert spans[0] == (first["gru1"], m.n_params - first["gru1"])
+    assert spans[1] == (first["gru0"], first["gru1"] - first["gru0"])
+    assert spans[2] == (0, first["gru0"])
+    for m in reps:
+        m.lib.seld_set_sync_bn(m.ctx, None, None, 1)

@@ -32,3 +32,17 @@ for _ in range(5):
                             B, S, 128)
     assert rc == 0, rc
 print("bwd ok")
+
+# -DGRU_TIMING build (SELD_HIP_LIB=... python tools/tune_gru.py): per-phase cycle shares of the last launches
+import numpy as np
+for which, names in ((0, ("h read + mat-vec", "gate tail", "barrier wait", "chunk commit + barrier")),
+                     (1, ("gate gradients -> LDS/global", "barrier wait", "coefficients + mat-vec + fold", "-"))):
+    buf = np.zeros((2 * B, 4), np.uint64)
+    rc = lib.seld_k_gru_timing(which, C.c_void_p(buf.ctypes.data), 2 * B)
+    if rc != 0:
+        print("(normal build: no phase counters)")
+        break
+    per_step = buf.astype(np.float64).mean(0) / S
+    tot = per_step.sum()
+    print(("gru_fwd" if which == 0 else "gru_bwd") + f": {tot:.0f} stamped cycles per recurrence step (wave 0, mean over {2 * B} workgroups): " +
+          ", ".join(f"{n} {v:.0f} ({100 * v / tot:.0f} %)" for n, v in zip(names, per_step) if n != "-"))
