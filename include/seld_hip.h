@@ -54,7 +54,16 @@ typedef struct seld_arch {
     int32_t n_doa_dense;
     int32_t doa_units[SELD_MAX_LAYERS];
     int32_t n_classes;                  /* 12 (train.py:306-307) */
+    /* FIRST block kind (models.py:24 getattr(modules, model_config['FIRST'])): 0 = simple_conv_block (filters / pool_* above),
+     * 1 = xception_block (model_config/xception_gru.json; spec/XCEPTION_BLOCK.md): n_conv = 1 entry conv2d_bn(filters[0] = 2 x
+     * FIRST_ARGS.filters) with pool (5,4), then xc_blocks = FIRST_ARGS.block_num residual modules of three
+     * SeparableConv2D + BatchNormalization, then ReLU + MaxPooling2D((1,8)). */
+    int32_t first_kind;
+    int32_t xc_blocks;
 } seld_arch;
+#define SELD_FIRST_SIMPLE_CONV 0
+#define SELD_FIRST_XCEPTION 1
+#define SELD_MAX_XC_BLOCKS 16
 
 /* Loss configuration = train.py:311-320 + the `loss_weight` flag (params.py:30). */
 typedef struct seld_loss_cfg {

@@ -38,7 +38,8 @@ class Arch(C.Structure):
                 ("filters", C.c_int32 * MAX_LAYERS), ("pool_t", C.c_int32 * MAX_LAYERS),
                 ("pool_f", C.c_int32 * MAX_LAYERS), ("n_gru", C.c_int32), ("gru_units", C.c_int32 * MAX_LAYERS),
                 ("n_sed_dense", C.c_int32), ("sed_units", C.c_int32 * MAX_LAYERS),
-                ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32)]
+                ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32),
+                ("first_kind", C.c_int32), ("xc_blocks", C.c_int32)]
 
 
 class LossCfg(C.Structure):

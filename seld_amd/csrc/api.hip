@@ -33,6 +33,14 @@ struct GruL {
 
 struct DenseL { int in, out; int64_t w_off, b_off; float* y; float* dy; };
 
+// one  ReLU -> SeparableConv2D(64, 3, use_bias=False) -> BatchNormalization  unit of xception_block's middle flow (spec/XCEPTION_BLOCK.md)
+struct XcUnit {
+    int64_t dw_off, pw_off, g_off, be_off;   // trainable offsets: depthwise_kernel [3,3,64,1], pointwise_kernel [1,1,64,64], gamma, beta
+    int64_t mm_off, mv_off;                  // state offsets
+    float *dwo = nullptr, *z = nullptr, *a = nullptr;   // depthwise output, pointwise output (pre-BN), unit output (units 0, 1)
+    float *mean, *invstd, *scale, *shift, *c1c2;
+};
+
 struct Head {
     std::vector<DenseL> layers;   // dense chain, last = output layer with activation
     int act;
@@ -51,6 +59,11 @@ struct seld_ctx {
     std::vector<ConvL> conv;
     std::vector<GruL> gru;
     Head heads[2];
+    // xception_block (arch.first_kind == SELD_FIRST_XCEPTION): conv[0] is the entry block, then 3 * xc_blocks units on [B,S,16,64]
+    std::vector<XcUnit> xc;
+    std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
+    float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
+    float *xc_g[3] = {};                     // gradient ping-pong buffers [B,S,16,64]
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
@@ -170,6 +183,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernels are built for in_ch = 7 (foa) and 10 (mic)");
     if (a->n_freq != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for n_freq = 64");
     if (a->n_classes <= 0) return fail(nullptr, SELD_ERR_INVALID, "n_classes must be positive");
+    const bool xcep = a->first_kind == SELD_FIRST_XCEPTION;
+    if (a->first_kind != SELD_FIRST_SIMPLE_CONV && !xcep) return fail(nullptr, SELD_ERR_UNSUPPORTED, "unknown FIRST block kind");
+    if (xcep && (a->n_conv != 1 || a->pool_t[0] != 5 || a->pool_f[0] != 4 || a->xc_blocks < 1 || a->xc_blocks > SELD_MAX_XC_BLOCKS))
+        return fail(nullptr, SELD_ERR_UNSUPPORTED, "xception_block: one entry conv2d_bn(64) with pool (5,4) and 1..16 middle modules (spec/XCEPTION_BLOCK.md)");
     int H = T, W = a->n_freq;
     for (int i = 0; i < a->n_conv; ++i) {
         if (a->filters[i] != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "conv kernels are built for 64 filters");
@@ -179,6 +196,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             return fail(nullptr, SELD_ERR_UNSUPPORTED, "inner conv width must be a power of two <= 32");
         H /= a->pool_t[i];
         W /= a->pool_f[i];
+    }
+    if (xcep) {
+        if (W != 16) return fail(nullptr, SELD_ERR_UNSUPPORTED, "xception_block: 16 frequency bins after the entry pool (n_freq 64)");
+        W /= 8;       // exit MaxPooling2D((1, 8))
     }
     const int S = H, feat = W * 64;
     for (int i = 0; i < a->n_gru; ++i)
@@ -210,6 +231,19 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         c->conv.push_back(L);
         cin = 64; H /= L.pt; W /= L.pf;
     }
+    if (xcep)
+        for (int b = 0; b < a->xc_blocks; ++b)
+            for (int u = 0; u < 3; ++u) {
+                XcUnit U;
+                char nm[64];
+                snprintf(nm, sizeof nm, "xc%d.%d.depthwise_kernel", b, u); U.dw_off = off; add_var(c->tr, off, nm, {3, 3, 64, 1});
+                snprintf(nm, sizeof nm, "xc%d.%d.pointwise_kernel", b, u); U.pw_off = off; add_var(c->tr, off, nm, {1, 1, 64, 64});
+                snprintf(nm, sizeof nm, "xc%d.%d.gamma", b, u); U.g_off = off; add_var(c->tr, off, nm, {64});
+                snprintf(nm, sizeof nm, "xc%d.%d.beta", b, u); U.be_off = off; add_var(c->tr, off, nm, {64});
+                snprintf(nm, sizeof nm, "xc%d.%d.moving_mean", b, u); U.mm_off = soff; add_var(c->nt, soff, nm, {64});
+                snprintf(nm, sizeof nm, "xc%d.%d.moving_variance", b, u); U.mv_off = soff; add_var(c->nt, soff, nm, {64});
+                c->xc.push_back(U);
+            }
     int fin = feat;
     for (int i = 0; i < a->n_gru; ++i) {
         GruL G;
@@ -271,6 +305,26 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(c->gram_slab, (size_t)conv_gram_slab_capacity() * kp * kp);
         ALLOC(c->gram, kp * kp);
         ALLOC(c->mmat, kp * 64);
+    }
+    if (xcep) {
+        const size_t npx = (size_t)B * S * 16 * 64;     // elements of one [B,S,16,64] tensor
+        ALLOC(c->xc_small, c->xc.size() * 64 * 6);
+        ALLOC(c->xc_ident, 64 * 6);
+        launch_xc_ident(0, c->xc_ident);
+        for (size_t i = 0; i < c->xc.size(); ++i) {
+            XcUnit& U = c->xc[i];
+            ALLOC(U.dwo, npx); ALLOC(U.z, npx);
+            if (i % 3 != 2) ALLOC(U.a, npx);
+            float* sm = c->xc_small + i * 64 * 6;
+            U.mean = sm; U.invstd = sm + 64; U.scale = sm + 128; U.shift = sm + 192; U.c1c2 = sm + 256;
+        }
+        c->xc_x.resize(a->xc_blocks + 1);
+        c->xc_x[0] = c->conv[0].p;
+        for (int b = 1; b <= a->xc_blocks; ++b) ALLOC(c->xc_x[b], npx);
+        for (int k = 0; k < 3; ++k) ALLOC(c->xc_g[k], npx);
+        ALLOC(c->xc_feat, (size_t)B * S * 128);
+        ALLOC(c->xc_part, (size_t)xc_partial_capacity() * 128);
+        ALLOC(c->xc_slab, (size_t)xc_partial_capacity() * 576);
     }
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
@@ -615,6 +669,40 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         }
         in = L.p;
     }
+    if (c->arch.first_kind == SELD_FIRST_XCEPTION) {
+        // ---- xception_block middle flow + exit (spec/XCEPTION_BLOCK.md) on [B,S,16,64]
+        const int64_t npix = (int64_t)B * S * 16;
+        if (training && c->sync_fn) return fail(c, SELD_ERR_UNSUPPORTED, "synchronised BatchNorm is not wired into xception_block");
+        for (size_t i = 0; i < c->xc.size(); ++i) {
+            XcUnit& U = c->xc[i];
+            const size_t b = i / 3, u = i % 3;
+            const float* uin = u == 0 ? c->xc_x[b] : c->xc[i - 1].a;
+            {
+                PROF2(c, "xc_depthwise_fwd");
+                launch_dw3x3_fwd(st, uin, c->params + U.dw_off, U.dwo, B, S, 16);       // ReLU on load, no bias
+            }
+            {
+                PROF2(c, "xc_pointwise_fwd");
+                launch_gemm(st, U.dwo, 64, c->params + U.pw_off, 64, nullptr, U.z, 64, (int)npix, 64, 64, 0, 0, 0);
+            }
+            PROF2(c, "xc_bn_fwd");
+            if (training) {
+                int np = 0;
+                launch_xc_bn_stats(st, U.z, c->xc_part, &np, npix);
+                launch_bn_finalize(st, c->xc_part, np, (double)npix, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off,
+                                   c->state + U.mv_off, U.mean, U.invstd, U.scale, U.shift, 64, 1);
+            } else {
+                launch_bn_eval_coeffs(st, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off, c->state + U.mv_off, U.scale,
+                                      U.shift, 64);
+            }
+            launch_xc_bn_apply(st, U.z, U.scale, U.shift, u == 2 ? c->xc_x[b] : nullptr, u == 2 ? c->xc_x[b + 1] : U.a, npix);
+        }
+        // exit: ReLU -> MaxPooling2D((1, 8)) = the BN+ReLU+pool kernel with identity coefficients
+        PROF2(c, "xc_exit_pool");
+        if (launch_bn_relu_pool_fwd(st, c->xc_x.back(), c->xc_ident + 128, c->xc_ident + 192, c->xc_feat, B, S, 16, 64, 1, 8))
+            return fail(c, SELD_ERR_UNSUPPORTED, "xception exit pool");
+        in = c->xc_feat;
+    }
     const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
     for (size_t i = 0; i < c->gru.size(); ++i) {
         GruL& G = c->gru[i];
@@ -820,7 +908,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
     const float* dout = c->feat_grad;
     for (int i = (int)c->gru.size() - 1; i >= 0; --i) {
         GruL& G = c->gru[i];
-        const float* lin = i == 0 ? c->conv.back().p : c->gru[i - 1].out;
+        const float* lin = i == 0 ? (c->arch.first_kind == SELD_FIRST_XCEPTION ? c->xc_feat : c->conv.back().p) : c->gru[i - 1].out;
         {
             PROF(c, "gru_bwd");
             launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
@@ -851,6 +939,49 @@ static int backward_impl(seld_ctx* c, const float* x) {
     }
     // ---- conv blocks, last to first.  dout = gradient w.r.t. the last pooled output
     const float* dp = dout;
+    if (c->arch.first_kind == SELD_FIRST_XCEPTION) {
+        // ---- xception_block backward: exit pool, then the modules last to first.  gX = gradient w.r.t. the module's output
+        // (= the next module's input); within a module gY walks back through the three units and the residual adds gX to it.
+        const int64_t npix = (int64_t)B * S * 16;
+        // three [B,S,16,64] gradient buffers: X = gradient w.r.t. the current module's output (kept until its residual add),
+        // F1 = gradient w.r.t. a unit's depthwise output, F2 = gradient w.r.t. a unit's input (= the previous unit's output)
+        float *X = c->xc_g[0], *F1 = c->xc_g[1], *F2 = c->xc_g[2];
+        {
+            PROF2(c, "xc_exit_pool_bwd");
+            const float* id = c->xc_ident;       // mean 0 | invstd 1 | scale 1 | shift 0 | c1 0 | c2 0
+            launch_bn_pool_bwd_dz(st, c->xc_x.back(), dout, id, id + 64, id + 128, id + 192, id + 256, X, B, S, 16, 64, 1, 8);
+        }
+        for (int b = (int)c->arch.xc_blocks - 1; b >= 0; --b) {
+            const float* gY = X;
+            for (int u = 2; u >= 0; --u) {
+                XcUnit& U = c->xc[(size_t)b * 3 + u];
+                const float* uin = u == 0 ? c->xc_x[b] : c->xc[(size_t)b * 3 + u - 1].a;
+                int np = 0, ns = 0;
+                {
+                    PROF2(c, "xc_bn_bwd");
+                    launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
+                    launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
+                    launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, c->dzbuf, npix);
+                }
+                {
+                    PROF2(c, "xc_pointwise_bwd");
+                    // dW = dwo^T dz (TN product over the pixels, many short splits: the slab is only 64 x 64), d(dwo) = dz W^T
+                    launch_gemm_tn(st, U.dwo, 64, c->dzbuf, 64, c->tn_slab, &ns, (int)npix, 64, 64, 0, 0, 0, 2048);
+                    launch_reduce_slabs2(st, c->tn_slab, ns, 64 * 64 + 64, c->grads + U.pw_off, 64 * 64, nullptr, 0);
+                    launch_gemm(st, c->dzbuf, 64, c->params + U.pw_off, 64, nullptr, F1, 64, (int)npix, 64, 64, 1, 0, 0);
+                }
+                PROF2(c, "xc_depthwise_bwd");
+                launch_dw3x3_bwd_w(st, uin, F1, c->xc_slab, &ns, B, S, 16);
+                launch_reduce_slabs(st, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
+                // gradient w.r.t. the unit's input, through its ReLU; the module's first unit adds the residual branch's X
+                float* gin = (u == 0 && b == 0) ? c->conv[0].dp : F2;
+                launch_dw3x3_bwd_data(st, F1, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16);
+                gY = gin;
+            }
+            if (b > 0) { float* t_ = X; X = F2; F2 = t_; }      // the module's input gradient is the next module's output gradient
+        }
+        dp = c->conv[0].dp;
+    }
     for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
         ConvL& L = c->conv[i];
         int np = 0;

@@ -104,6 +104,18 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, co
                               int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme = 0);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C);
+// xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
+int xc_partial_capacity();
+int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W);
+int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H, int W);
+int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W);
+int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npartial, int64_t npix);
+int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
+                            int* npartial, int64_t npix);
+int launch_xc_bn_apply(hipStream_t st, const float* z, const float* scale, const float* shift, const float* res, float* out, int64_t npix);
+int launch_xc_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, const float* scale,
+                        const float* c1c2, float* dz, int64_t npix);
+int launch_xc_ident(hipStream_t st, float* ident);
 int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums);
 int launch_bn_finalize_sums(hipStream_t st, const double* sums, double count, const float* gamma, const float* beta,
                             float* mov_mean, float* mov_var, float* mean, float* invstd, float* scale, float* shift);
@@ -144,7 +156,7 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift, int want_bias);
+                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits = 0);
 // split-bf16 form with transposed LDS reads (gemm_tn_sb.hip): K1 = 128, N % 128 == 0; same slabs as launch_gemm_tn
 int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N);
 int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,

@@ -395,12 +395,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift, int want_bias) {
+                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits) {
     if (M <= 0 || K1 <= 0 || N <= 0) return -1;
+    if (max_splits <= 0) max_splits = TN_MAX_SPLITS;       // callers with small K1 x N slabs may ask for more (the slab buffer permitting)
     // Rows per split: the loop prefetches one 32-row chunk ahead, i.e. every chunk costs a load round trip (~2 us) unless other
     // blocks of the CU cover it: short splits = many co-resident blocks (16 KB of LDS each) and few dependent chunks per block
     int splits = (M + 159) / 160;
-    if (splits > TN_MAX_SPLITS) splits = TN_MAX_SPLITS;
+    if (splits > max_splits) splits = max_splits;
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;

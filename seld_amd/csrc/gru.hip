@@ -84,7 +84,6 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const float bzr = brec[zr_off], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f;
-    const unsigned sel0 = q == 0 ? ~0u : 0u, sel1 = q == 1 ? ~0u : 0u, sel2 = q == 2 ? ~0u : 0u, sel3 = q == 3 ? ~0u : 0u;
     const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
     // staged chunk: three float4 per thread held in NAMED registers (an array captured by a lambda was
     // demoted to scratch memory by the compiler, which put a vmcnt wait right behind the loads)
@@ -160,18 +159,17 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, true));
             const float ghh = ah + bh;
             const float hh = tanh_(gxh + r * ghh);
-            const float hn = z * h_own + (1.f - z) * hh;
+            const float hn = fmaf(z, h_own - hh, hh);      // z h + (1 - z) hh
             h_own = hn;
             if (q == 0) {
                 hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
                 H[(size_t)t * GRU_U + j] = hn;
             }
             if (sv) {
-                // lane q of a quad saves gate q (z | r | hh | gh): AND/OR with per-lane one-hot masks — the nested
-                // ternary became three exec-mask branches per step
-                const unsigned vb = (__float_as_uint(z) & sel0) | (__float_as_uint(r) & sel1) | (__float_as_uint(hh) & sel2) |
-                                    (__float_as_uint(ghh) & sel3);
-                sv[((size_t)t * 4 + q) * GRU_U + j] = __uint_as_float(vb);
+                // lane q of a quad saves gate q (z | r | hh | gh).  Even lanes finished z and odd lanes r in `sg` itself, so lanes 0 / 1
+                // store sg as it is; lanes 2 / 3 pick hh / gh: two selects (seven AND/OR ops with one-hot masks before)
+                const float hi2 = q == 2 ? hh : ghh;
+                sv[((size_t)t * 4 + q) * GRU_U + j] = q < 2 ? sg : hi2;
             }
 #ifdef GRU_TIMING
             GRU_STAMP(ts2)

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-SUPPORTED_FIRST = ("simple_conv_block",)
+SUPPORTED_FIRST = ("simple_conv_block", "xception_block")
 SUPPORTED_SECOND = ("bidirectional_GRU_block",)
 SUPPORTED_HEAD = ("simple_dense_block",)
 
@@ -27,7 +27,15 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         if model_config.get(key) not in ok:
             raise ValueError(f"model_config[{key!r}]={model_config.get(key)!r}: only {ok} has MI355X kernels")
     fa = model_config["FIRST_ARGS"]
-    filters, pools = list(fa["filters"]), [tuple(p) for p in fa["pool_size"]]
+    xception = model_config["FIRST"] == "xception_block"
+    if xception:
+        # model_config/xception_gru.json:2-11; the block is absent from the reference snapshot: spec/XCEPTION_BLOCK.md is ours
+        # (entry conv2d_bn(2 filters) + MaxPool (5,4), block_num residual modules of 3 x [ReLU, SeparableConv2D, BN], ReLU + MaxPool (1,8))
+        if int(fa["filters"]) != 32:
+            raise ValueError("xception_block kernels are built for filters = 32 (width 64)")
+        filters, pools = [2 * int(fa["filters"])], [(5, 4)]
+    else:
+        filters, pools = list(fa["filters"]), [tuple(p) for p in fa["pool_size"]]
     if len(filters) != len(pools):
         raise ValueError("filters and pool_size must have the same length")
     if fa.get("dropout_rate", 0.0) or model_config["SECOND_ARGS"].get("dropout_rate", 0.0):
@@ -64,6 +72,8 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         a.doa_units[i] = u
     # models.py:19 default 14; train.py:306-307 overrides to 12 before building
     a.n_classes = int(model_config.get("n_classes", 14))
+    a.first_kind = 1 if xception else 0
+    a.xc_blocks = int(fa["block_num"]) if xception else 0
     return a
 
 

@@ -36,3 +36,13 @@ def seldnet_config():
         "DOA_ARGS": {"units": [128], "n_classes": 42, "activation": "tanh", "name": "doa_out"},
         "n_classes": 12,
     }
+
+
+@pytest.fixture(scope="session")
+def xception_config(seldnet_config):
+    """model_config/xception_gru.json of the reference, restated as data (n_classes = 12 as train.py:306-307 forces)."""
+    import copy
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST"] = "xception_block"
+    cfg["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    return cfg

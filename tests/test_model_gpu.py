@@ -633,3 +633,37 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
     assert spans[2] == (0, first["gru0"])
     for m in reps:
         m.lib.seld_set_sync_bn(m.ctx, None, None, 1)
+
+
+
+@pytest.mark.parametrize("B,T,blocks,doa_loss", [(2, 50, 8, "MSE"), (3, 100, 2, "MMSE"), (1, 35, 1, "MSE")])
+def test_xception_gru_train_step(xception_config, B, T, blocks, doa_loss):
+    """BASELINE config 4 (model_config/xception_gru.json): FIRST = xception_block as published in spec/XCEPTION_BLOCK.md (the
+    reference snapshot does not define the block: parity is against OUR spec, restated by the oracle) — one train step and one
+    test step against the fp64 oracle, variable by variable; block_num 8 (the JSON's), 2 and 1; a ragged time extent."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(xception_config)
+    cfg["FIRST_ARGS"]["block_num"] = blocks
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 5)
+    x, ys, yd = O.synthetic_batch(B, T, seed=17)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    tr, nt = O.variable_specs(spec)
+    assert [(n, s) for n, _, s in model.variables] == tr and [(n, s) for n, _, s in model.state_variables] == nt
+    if blocks == 8:
+        assert model.n_params == 554928          # spec/XCEPTION_BLOCK.md
+    model.set_weights(w, st)
+    ref_t = O.test_step(spec, w, st, x, ys, yd, doa_loss, dtype=torch.float64)
+    y_t, sl_t, dl_t = train.teststep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.get_doa_loss(doa_loss))
+    check("xception teststep sed", y_t[0].cpu().numpy(), ref_t["sed"])
+    check("xception teststep doa", y_t[1].cpu().numpy(), ref_t["doa"])
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss=doa_loss, loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.get_doa_loss(doa_loss), (1.0, 1000.0), train.Adam(1e-3))
+    check("xception trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("xception trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("xception trainstep dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "xception grad", model.get_grads(), ref["grad"])
+    _, st1 = model.get_weights()
+    check("xception BN moving stats", st1, ref["new_state"])
