@@ -71,6 +71,11 @@ def kernel_work(name, B, T, F=64, C=7):
         # reference op count (two Dense layers per head); the default build computes them as one 48-column product (heads_fused)
         "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
         "adam": ("hbm", 4 * 7 * 513840),
+        # xception_block middle flow (spec/XCEPTION_BLOCK.md), per launch group on [B,S,16,64]: depthwise 3x3 = read + write the
+        # tensor; pointwise 64 x 64 product; BatchNorm passes
+        "xc_depthwise_fwd": ("hbm", 4 * 2 * px2 * 64), "xc_pointwise_fwd": ("mfma", 2 * px2 * 64 * 64),
+        "xc_bn_fwd": ("hbm", 4 * 3 * px2 * 64), "xc_bn_bwd": ("hbm", 4 * 5 * px2 * 64),
+        "xc_pointwise_bwd": ("mfma", 2 * 2 * px2 * 64 * 64), "xc_depthwise_bwd": ("hbm", 4 * 5 * px2 * 64),
     }
     return table.get(name)
 
@@ -87,13 +92,13 @@ def host_cores():
     return n
 
 
-def cpu_baseline(B_gpu, T, steps, warmup, budget_s):
+def cpu_baseline(B_gpu, T, steps, warmup, budget_s, model_config=None):
     """the oracle's train step (PyTorch-CPU fp32 restatement of the reference semantics, NOT the
     reference's TensorFlow) on the host cores: `warmup` warm-ups, median of `steps` steps, at B=2 (BASELINE configs[0],
     the reference's own CPU-runnable case) and at the GPU batch.  The GPU-batch leg times fewer steps (>= 3) when `steps`
     of them would exceed `budget_s`, so that the default bench still finishes in minutes; what was run is in `sample`."""
     from oracle import seldnet_oracle as O
-    spec = O.Spec.from_config(SELDNET_CONFIG)
+    spec = O.Spec.from_config(model_config or SELDNET_CONFIG)
     w, st = O.random_weights(spec, 0)
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -191,6 +196,9 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="cpu_baseline at the GPU batch: fewer than --cpu-steps steps are timed (never fewer than 3) if they would exceed this")
     ap.add_argument("--no-features", action="store_true", help="skip the feature-stage leg")
+    ap.add_argument("--model", default="seldnet", choices=["seldnet", "xception_gru"],
+                    help="model_config of the reference: seldnet.json (the headline, BASELINE configs[1]) or xception_gru.json "
+                         "(configs[3]; its FIRST block is defined by spec/XCEPTION_BLOCK.md: absent from the reference snapshot)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,7 +216,12 @@ def main():
     from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only
 
     B, T = args.batch, args.frames
-    model = models.seldnet((B, T, 64, 7), SELDNET_CONFIG, device=local)
+    import copy
+    model_config = copy.deepcopy(SELDNET_CONFIG)
+    if args.model == "xception_gru":        # model_config/xception_gru.json:2-11
+        model_config["FIRST"] = "xception_block"
+        model_config["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    model = models.seldnet((B, T, 64, 7), model_config, device=local)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         model.set_option(key, int(val))
@@ -321,7 +334,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"model_config/seldnet.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12",
+            "config": {"workload": f"model_config/{args.model}.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12"
+                                   + (" (FIRST block per spec/XCEPTION_BLOCK.md: absent from the reference snapshot)" if args.model != "seldnet" else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
             "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
         }
@@ -333,7 +347,7 @@ def main():
             ft = traffic_tab.get("feat_frame", {}).get("hbm_bytes_per_launch")
             out["features"]["roofline"]["traffic"] = ft
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

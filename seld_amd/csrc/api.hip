@@ -966,7 +966,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 {
                     PROF2(c, "xc_pointwise_bwd");
                     // dW = dwo^T dz (TN product over the pixels, many short splits: the slab is only 64 x 64), d(dwo) = dz W^T
-                    launch_gemm_tn(st, U.dwo, 64, c->dzbuf, 64, c->tn_slab, &ns, (int)npix, 64, 64, 0, 0, 0, 2048);
+                    launch_gemm_tn(st, U.dwo, 64, c->dzbuf, 64, c->tn_slab, &ns, (int)npix, 64, 64, 0, 0, 0, 512);
                     launch_reduce_slabs2(st, c->tn_slab, ns, 64 * 64 + 64, c->grads + U.pw_off, 64 * 64, nullptr, 0);
                     launch_gemm(st, c->dzbuf, 64, c->params + U.pw_off, 64, nullptr, F1, 64, (int)npix, 64, 64, 1, 0, 0);
                 }

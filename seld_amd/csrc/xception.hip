@@ -15,7 +15,8 @@
 //   bn_bwd_dz_plain  dz = scale (dy - c1 - xhat c2)
 #include "common.h"
 
-#define XC_MAX_PARTIAL 512
+#define XC_MAX_PARTIAL 2048     // depthwise kernel-gradient slabs (one per workgroup of image rows)
+#define XC_BN_PARTIAL 512       // BatchNorm partial sums: the single-workgroup finalisation reads all of them
 int xc_partial_capacity() { return XC_MAX_PARTIAL; }
 
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
@@ -67,25 +68,33 @@ int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const
     return 0;
 }
 
-// dk[tap][c] = sum_p relu(x[p + tap][c]) dy[p][c]: thread (slot = tid >> 4, g = tid & 15) walks pixels slot, slot + 16 gridDim, ...;
-// 9 x 4 sums in registers, the 16 slots combined through LDS in a fixed order -> slab[blockIdx][9][64]
+// dk[tap][c] = sum_p relu(x[p + tap][c]) dy[p][c].  A workgroup takes whole image rows (W pixels x 64 channels = one contiguous
+// 4 W floats x 16 line): thread (slot = tid >> 4, g = tid & 15) owns pixel column `slot` (W = 16) of the rows blockIdx, + gridDim, ...
+// and keeps the 3 x 3 x 4 sums in registers; the three input rows it needs are read once each per output row through L1 (the
+// neighbouring columns belong to the neighbouring threads of the same workgroup).  Slots combined through LDS in a fixed order
+// -> slab[blockIdx][9][64]
 __global__ __launch_bounds__(256) void dw3x3_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab,
-                                                          int64_t npix, int H, int W) {
+                                                          int64_t nrows, int H, int W) {
     __shared__ float red[16][9 * 64 + 4];
     const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
     float4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t p = (int64_t)blockIdx.x * 16 + slot; p < npix; p += (int64_t)gridDim.x * 16) {
-        const int f = (int)(p % W), t = (int)((p / W) % H);
-        const float4 d = *reinterpret_cast<const float4*>(dy + p * 64 + 4 * g);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int t = (int)(r % H);
+        for (int f = slot; f < W; f += 16) {
+            const int64_t p = r * W + f;
+            const float4 d = *reinterpret_cast<const float4*>(dy + p * 64 + 4 * g);
+            float4 v[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dt = tap / 3 - 1, df = tap % 3 - 1;
-            if (t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W) {
-                const float4 v = relu4(*reinterpret_cast<const float4*>(x + (p + dt * W + df) * 64 + 4 * g));
-                acc[tap] = fma4v(v, d, acc[tap]);
+            for (int tap = 0; tap < 9; ++tap) {          // all nine loads in flight before the first FMA
+                const int dt = tap / 3 - 1, df = tap % 3 - 1;
+                const bool ok = t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W;
+                v[tap] = ok ? *reinterpret_cast<const float4*>(x + (p + dt * W + df) * 64 + 4 * g) : zero4;
             }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] = fma4v(relu4(v[tap]), d, acc[tap]);
         }
     }
 #pragma unroll
@@ -100,10 +109,9 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_w_kernel(const float* __restric
 }
 
 int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W) {
-    const int64_t npix = (int64_t)B * H * W;
-    int64_t blocks = (npix + 15) / 16;
-    if (blocks > XC_MAX_PARTIAL) blocks = XC_MAX_PARTIAL;
-    hipLaunchKernelGGL(dw3x3_bwd_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, slab, npix, H, W);
+    const int64_t nrows = (int64_t)B * H;
+    int64_t blocks = nrows < XC_MAX_PARTIAL ? nrows : XC_MAX_PARTIAL;
+    hipLaunchKernelGGL(dw3x3_bwd_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, slab, nrows, H, W);
     *nslab = (int)blocks;
     return 0;
 }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void xc_reduce_kernel(const float* __restrict_
 
 int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npartial, int64_t npix) {
     int64_t blocks = (npix + 15) / 16;
-    if (blocks > XC_MAX_PARTIAL) blocks = XC_MAX_PARTIAL;
+    if (blocks > XC_BN_PARTIAL) blocks = XC_BN_PARTIAL;
     hipLaunchKernelGGL(xc_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix);
     *npartial = (int)blocks;
     return 0;
@@ -151,7 +159,7 @@ int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npar
 int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
                             int* npartial, int64_t npix) {
     int64_t blocks = (npix + 15) / 16;
-    if (blocks > XC_MAX_PARTIAL) blocks = XC_MAX_PARTIAL;
+    if (blocks > XC_BN_PARTIAL) blocks = XC_BN_PARTIAL;
     hipLaunchKernelGGL(xc_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, z, dy, mean, invstd, partial, npix);
     *npartial = (int)blocks;
     return 0;
