@@ -99,6 +99,7 @@ struct seld_ctx {
     std::string err;
     int prof = 0;   // 0 off, 1 major kernel groups, 2 every group
     std::vector<Timer> timers;
+    std::vector<hipEvent_t> ev_pool;   // timing events are created once and recycled: no hipEventCreate inside a timed step
 };
 
 namespace {
@@ -146,12 +147,16 @@ struct ProfScope {
         if (c->prof < level) return;
         for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) { Timer t; t.name = name; c->timers.push_back(t); idx = (int)c->timers.size() - 1; }
-        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
+        hipEvent_t e = take(c); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
     }
     ~ProfScope() {
         if (idx < 0) return;
-        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
+        hipEvent_t e = take(c); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
         c->timers[idx].launches++;
+    }
+    static hipEvent_t take(seld_ctx* c) {
+        if (c->ev_pool.empty()) { hipEvent_t e; hipEventCreate(&e); return e; }
+        hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e;
     }
 };
 #define PROF_CAT2(a, b) a##b
@@ -408,6 +413,7 @@ void seld_destroy(seld_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto& t : c->timers) for (auto e : t.ev) hipEventDestroy(e);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_gram) hipEventDestroy(c->ev_gram);
@@ -1149,7 +1155,15 @@ int seld_debug_pool_routing(seld_ctx* c, int block, unsigned char* pos, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------- profiling
-int seld_profile_enable(seld_ctx* c, int on) { if (!c) return SELD_ERR_INVALID; c->prof = on < 0 ? 0 : (on > 2 ? 2 : on); return SELD_OK; }
+int seld_profile_enable(seld_ctx* c, int on) {
+    if (!c) return SELD_ERR_INVALID;
+    c->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
+    if (c->prof) {      // events for a default bench run of scopes up front; prof_resolve (seld_profile_get / _reset) recycles them
+        hipSetDevice(c->device);
+        while (c->ev_pool.size() < (c->prof == 1 ? 1024u : 8192u)) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; c->ev_pool.push_back(e); }
+    }
+    return SELD_OK;
+}
 int seld_profile_count(const seld_ctx* c) { return c ? (int)c->timers.size() : -1; }
 static void prof_resolve(seld_ctx* c) {
     hipStreamSynchronize(c->stream);
@@ -1158,7 +1172,7 @@ static void prof_resolve(seld_ctx* c) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) t.ms += ms;
         }
-        for (auto e : t.ev) hipEventDestroy(e);
+        for (auto e : t.ev) c->ev_pool.push_back(e);     // recycled by the next timed scopes
         t.ev.clear();
     }
 }

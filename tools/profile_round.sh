@@ -10,17 +10,36 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd "$root"
 timeout -k 10 300 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --timing-level 2 > "$out/bench_l2.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-features --timing-level 2 > "$out/bench_l2.json" 2>> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- \
-    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.log"
+    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o pmc -- \
-        python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> "$out/rocprof_$c.log"
+        python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-features --no-kernel-timing > /dev/null 2> "$out/rocprof_$c.log"
 done
 f=$(find "$out/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 w=$(find "$out/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$root/tools/pmc_traffic.py" "$f" "$w" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, build $tag" > "$out/traffic.json"
+# feature stage (feature_extractor.extract_features on 60-s FOA clips): kernel stats + its own PMC passes, merged into traffic.json
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/feat_stats" -o feat -- \
+    python3 "$root/tools/bench_features.py" > "$out/bench_features_under_rocprof.json" 2> "$out/rocprof_feat.log"
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/featpmc_$c" -o pmc -- \
+        python3 "$root/tools/bench_features.py" > /dev/null 2> "$out/rocprof_feat_$c.log"
+done
+ff=$(find "$out/featpmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
+fw=$(find "$out/featpmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
+python3 "$root/tools/pmc_traffic.py" "$ff" "$fw" "feature stage: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, build $tag" > "$out/traffic_features.json"
+rm -rf "$out/featpmc_FETCH_SIZE" "$out/featpmc_WRITE_SIZE"
+find "$out/feat_stats" -name '*kernel_trace.csv' -delete
+# BASELINE config 4 (xception_gru.json; FIRST block per spec/XCEPTION_BLOCK.md): bench line + kernel stats
+cd "$root"
+timeout -k 10 200 python3 bench.py --model xception_gru --steps 10 --warmup 3 --no-cpu-baseline --no-features --timing-level 2 > "$out/bench_xception_gru.json" 2>> "$out/bench.err"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/xc_stats" -o xc -- \
+    python3 "$root/bench.py" --model xception_gru --steps 5 --warmup 2 --no-cpu-baseline --no-features --no-kernel-timing > /dev/null 2> "$out/rocprof_xc.log"
+find "$out/xc_stats" -name '*kernel_trace.csv' -delete
 rm -rf "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"   # raw per-dispatch counters are large; the per-kernel summary stays
 find "$out/stats" -name '*kernel_trace.csv' -delete
 cat "$out/bench.json"
