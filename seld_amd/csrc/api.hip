@@ -678,7 +678,6 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     if (c->arch.first_kind == SELD_FIRST_XCEPTION) {
         // ---- xception_block middle flow + exit (spec/XCEPTION_BLOCK.md) on [B,S,16,64]
         const int64_t npix = (int64_t)B * S * 16;
-        if (training && c->sync_fn) return fail(c, SELD_ERR_UNSUPPORTED, "synchronised BatchNorm is not wired into xception_block");
         for (size_t i = 0; i < c->xc.size(); ++i) {
             XcUnit& U = c->xc[i];
             const size_t b = i / 3, u = i % 3;
@@ -695,8 +694,14 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             if (training) {
                 int np = 0;
                 launch_xc_bn_stats(st, U.z, c->xc_part, &np, npix);
-                launch_bn_finalize(st, c->xc_part, np, (double)npix, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off,
-                                   c->state + U.mv_off, U.mean, U.invstd, U.scale, U.shift, 64, 1);
+                if (c->sync_fn) {      // synchronised BatchNorm: global sums through the host's all-reduce (see the conv blocks above)
+                    launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf);
+                    if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+                    launch_bn_finalize_sums(st, c->sync_buf, (double)npix * c->sync_world, c->params + U.g_off, c->params + U.be_off,
+                                            c->state + U.mm_off, c->state + U.mv_off, U.mean, U.invstd, U.scale, U.shift);
+                } else
+                    launch_bn_finalize(st, c->xc_part, np, (double)npix, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off,
+                                       c->state + U.mv_off, U.mean, U.invstd, U.scale, U.shift, 64, 1);
             } else {
                 launch_bn_eval_coeffs(st, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off, c->state + U.mv_off, U.scale,
                                       U.shift, 64);
@@ -966,7 +971,13 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 {
                     PROF2(c, "xc_bn_bwd");
                     launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
-                    launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
+                    if (c->sync_fn) {
+                        launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf);
+                        launch_bn_bwd_local(st, c->sync_buf, c->grads + U.g_off, c->grads + U.be_off);
+                        if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+                        launch_bn_bwd_c1c2(st, c->sync_buf, (double)npix * c->sync_world, U.c1c2);
+                    } else
+                        launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
                     launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, c->dzbuf, npix);
                 }
                 {

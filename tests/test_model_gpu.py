@@ -543,7 +543,8 @@ def test_parity_given_identical_routing(seldnet_config):
     _per_var(model, "routed grad", g, ref["grad"])
 
 
-def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
+@pytest.mark.parametrize("which", ["seldnet", "xception_gru"])
+def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xception_config, which):
     """seld_set_sync_bn: two replicas (two ctxs on the one test GPU, driven by two host threads, their all-reduce callback a
     rendezvous that sums the two 128-double buffers on the host) each train on half of a batch; with synchronised BatchNorm the
     SUM of their gradient buffers, their outputs and their BN moving statistics must equal the oracle's single-process step on
@@ -553,6 +554,11 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
     import threading
     from oracle import seldnet_oracle as O
     from seld_amd import _lib, losses, models, train
+    import copy
+    seldnet_config = copy.deepcopy(seldnet_config if which == "seldnet" else xception_config)
+    if which != "seldnet":
+        seldnet_config["FIRST_ARGS"]["block_num"] = 2
+    n_bn = 3 if which == "seldnet" else 1 + 3 * 2
     spec = O.Spec.from_config(seldnet_config)
     w, st = O.random_weights(spec, 0)
     B, T = 4, 100
@@ -611,7 +617,7 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
     for th in ths:
         th.join(timeout=120)
     assert not errors, errors
-    assert calls == [6, 6]                                           # 3 conv blocks x (forward + backward)
+    assert calls == [2 * n_bn, 2 * n_bn]                             # every BatchNormalization x (forward + backward)
     ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64)
     check("syncbn sed", np.concatenate([out[0][0], out[1][0]]), ref["sed"])
     check("syncbn doa", np.concatenate([out[0][1], out[1][1]]), ref["doa"])
@@ -628,6 +634,7 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config):
         _lib.check(m.lib.seld_grads_bucket_ready(m.ctx, k, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(off), C.byref(cnt)), m.ctx)
         spans.append((off.value, cnt.value))
     first = {p: min(o for n, o, _ in m.variables if n.startswith(p)) for p in ("conv", "gru0", "gru1")}
+    assert all(o < first["gru0"] for n, o, _ in m.variables if n.startswith(("conv", "bn", "xc")))
     assert spans[0] == (first["gru1"], m.n_params - first["gru1"])
     assert spans[1] == (first["gru0"], first["gru1"] - first["gru0"])
     assert spans[2] == (0, first["gru0"])
