@@ -70,14 +70,31 @@ def kernel_work(name, B, T, F=64, C=7):
         "gru_bwd_gemms": ("mfma", 2 * 2 * rows * 128 * 384),   # main stream: the two input-gradient GEMMs of a layer
         # reference op count (two Dense layers per head); the default build computes them as one 48-column product (heads_fused)
         "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
-        "adam": ("hbm", 4 * 7 * 513840),
+        "adam": ("hbm", 4 * 7 * N_PARAMS),
         # xception_block middle flow (spec/XCEPTION_BLOCK.md), per launch group on [B,S,16,64]: depthwise 3x3 = read + write the
         # tensor; pointwise 64 x 64 product; BatchNorm passes
         "xc_depthwise_fwd": ("hbm", 4 * 2 * px2 * 64), "xc_pointwise_fwd": ("mfma", 2 * px2 * 64 * 64),
         "xc_bn_fwd": ("hbm", 4 * 3 * px2 * 64), "xc_bn_bwd": ("hbm", 4 * 5 * px2 * 64),
         "xc_pointwise_bwd": ("mfma", 2 * 2 * px2 * 64 * 64), "xc_depthwise_bwd": ("hbm", 4 * 5 * px2 * 64),
     }
+    if name in ("rn_stages_fwd", "rn_stages_bwd"):
+        # resnet50_block (spec/RESNET50_BLOCK.md): the products of every bottleneck (1x1 reduce, 3x3, 1x1 expand, projection shortcut)
+        # on the f32-input MFMA GEMM; the backward pass runs each twice (kernel gradient + input gradient)
+        mac, cin, wbins = 0, 64, 16
+        for s_, nb in enumerate(RESNET_BLOCKS):
+            w = 32 * 2 ** s_
+            for b in range(nb):
+                if b == 0 and s_ > 0:
+                    wbins //= 2
+                px = B * S * wbins
+                mac += px * (cin * w + 9 * w * w + w * 4 * w + (cin * 4 * w if b == 0 else 0))
+                cin = 4 * w
+        return ("mfma", (2 if name == "rn_stages_fwd" else 4) * mac)
     return table.get(name)
+
+
+RESNET_BLOCKS = [3, 4, 6, 3]      # model_config/resnet50_gru.json:5
+N_PARAMS = 513840                 # seldnet.json; main() sets the timed model's count
 
 
 def host_cores():
@@ -184,7 +201,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed steps (default 40: a >= 100 ms timed region)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE.json configs[1])")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clips per GPU; default 32 (BASELINE.json configs[1]), 16 for --model resnet50_gru (configs[4]: 128 over 8 GPUs)")
     ap.add_argument("--frames", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -196,10 +214,16 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="cpu_baseline at the GPU batch: fewer than --cpu-steps steps are timed (never fewer than 3) if they would exceed this")
     ap.add_argument("--no-features", action="store_true", help="skip the feature-stage leg")
-    ap.add_argument("--model", default="seldnet", choices=["seldnet", "xception_gru"],
-                    help="model_config of the reference: seldnet.json (the headline, BASELINE configs[1]) or xception_gru.json "
-                         "(configs[3]; its FIRST block is defined by spec/XCEPTION_BLOCK.md: absent from the reference snapshot)")
+    ap.add_argument("--model", default="seldnet", choices=["seldnet", "xception_gru", "resnet50_gru"],
+                    help="model_config of the reference: seldnet.json (the headline, BASELINE configs[1]), xception_gru.json "
+                         "(configs[3]) or resnet50_gru.json (configs[4]); the FIRST blocks of the latter two are defined by "
+                         "spec/XCEPTION_BLOCK.md / spec/RESNET50_BLOCK.md: absent from the reference snapshot")
+    ap.add_argument("--with-features", action="store_true",
+                    help="configs[4]'s 'on-device STFT feature_extractor': every timed step first extracts and normalises the features of "
+                         "its clips from 60-s FOA waveforms resident in HBM (feature_extractor.py:53-88, data_loader.py:117-149,226-234)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16 if args.model == "resnet50_gru" else 32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,7 +245,12 @@ def main():
     if args.model == "xception_gru":        # model_config/xception_gru.json:2-11
         model_config["FIRST"] = "xception_block"
         model_config["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    if args.model == "resnet50_gru":        # model_config/resnet50_gru.json:2-11
+        model_config["FIRST"] = "resnet50_block"
+        model_config["FIRST_ARGS"] = {"filters": 32, "block_num": list(RESNET_BLOCKS), "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
     model = models.seldnet((B, T, 64, 7), model_config, device=local)
+    global N_PARAMS
+    N_PARAMS = model.n_params
     for kv in args.opt:
         key, _, val = kv.partition("=")
         model.set_option(key, int(val))
@@ -230,6 +259,24 @@ def main():
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
     opt = train.Adam(1e-3)
     sed_loss, doa_loss, lw = losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0)
+    featurize = None
+    if args.with_features:
+        import ctypes as C
+        from seld_amd import _lib, feature_extractor as FE
+        if T != 3000:
+            raise SystemExit("--with-features extracts 60-s clips: --frames must be 3000")
+        rng = np.random.default_rng(77 + rank)
+        wavs = [torch.as_tensor((rng.standard_normal((4, 1440000)) * 0.1).astype(np.float32)).to(dev) for _ in range(B)]
+        fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=local)
+        f_mean = torch.full((64 * 7,), -3.0, device=dev)     # a fitted normalizer's statistics (data_loader.py:226-234), synthetic here
+        f_std = torch.full((64 * 7,), 2.0, device=dev)
+
+        def featurize():
+            st_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for b in range(B):
+                f = fx(wavs[b])                                  # [3001, 64, 7]
+                _lib.check(fx.lib.seld_feat_normalize(f.data_ptr(), f_mean.data_ptr(), f_std.data_ptr(), x[b].data_ptr(), 3001, 3000,
+                                                      64 * 7, 1e-8, st_))
 
     def barrier():
         torch.cuda.synchronize()
@@ -243,6 +290,8 @@ def main():
     run_stream.wait_stream(torch.cuda.current_stream(dev))
     torch.cuda.set_stream(run_stream)
     for _ in range(args.warmup):
+        if featurize:
+            featurize()
         train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
     timing = not args.no_kernel_timing
     model.lib.seld_profile_reset(model.ctx)
@@ -250,6 +299,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if featurize:
+            featurize()
         y_p, sl, dl = train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -268,6 +319,8 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
+            if featurize:
+                featurize()
             train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt, allreduce=False)
         torch.cuda.synchronize()
         local_no_comm = time.perf_counter() - t1
@@ -335,7 +388,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"model_config/{args.model}.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12"
-                                   + (" (FIRST block per spec/XCEPTION_BLOCK.md: absent from the reference snapshot)" if args.model != "seldnet" else ""),
+                                   + (" (FIRST block per spec/XCEPTION_BLOCK.md: absent from the reference snapshot)" if args.model == "xception_gru" else "")
+                                   + (" (FIRST block per spec/RESNET50_BLOCK.md: absent from the reference snapshot)" if args.model == "resnet50_gru" else "")
+                                   + (", features extracted on the device from 60-s FOA waveforms inside every step" if featurize else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
             "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
         }

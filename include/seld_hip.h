@@ -60,9 +60,14 @@ typedef struct seld_arch {
      * SeparableConv2D + BatchNormalization, then ReLU + MaxPooling2D((1,8)). */
     int32_t first_kind;
     int32_t xc_blocks;
+    /* 2 = resnet50_block (model_config/resnet50_gru.json; spec/RESNET50_BLOCK.md): the same entry, then four stages of rn_blocks[s]
+     * bottleneck blocks of width rn_filters * 2^s, frequency stride 2 at the first block of stages 1..3 -> [B, T/5, 2, 32 rn_filters] */
+    int32_t rn_filters;
+    int32_t rn_blocks[4];
 } seld_arch;
 #define SELD_FIRST_SIMPLE_CONV 0
 #define SELD_FIRST_XCEPTION 1
+#define SELD_FIRST_RESNET50 2
 #define SELD_MAX_XC_BLOCKS 16
 
 /* Loss configuration = train.py:311-320 + the `loss_weight` flag (params.py:30). */
@@ -306,10 +311,28 @@ int seld_k_adam(float* theta, const float* g, float* m, float* v, int64_t n, flo
  * (layers.py:33-37 + simple_conv_block) take the same decisions from their own fp32 values; windows whose two largest elements
  * are within one rounding of each other may decide differently.  Synchronises the ctx stream. */
 int seld_debug_pool_routing(seld_ctx* ctx, int block, unsigned char* pos, unsigned char* gate);
+/* Test aid for resnet50_block (tests/test_model_gpu.py::test_resnet50_gru_train_step): after seld_train_fwd_bwd, the output of one
+ * of bottleneck block `block`'s three ReLUs (which = 0: after the 1x1 reduce, 1: after the 3x3, 2: the block output), copied to the
+ * device buffer `dst` (capacity floats); *count = its size, [B, T/5, W_block, w or 4w].  output > 0 is the gate the backward pass
+ * used.  Synchronises the ctx stream. */
+int seld_debug_relu_output(seld_ctx* ctx, int block, int which, float* dst, int64_t capacity, int64_t* count);
 /* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */
 int seld_k_valu_clock_mhz(int blocks, double* mhz);
+/* resnet50_block pieces (spec/RESNET50_BLOCK.md; model_config/resnet50_gru.json:2-11), as the train / predict entry points compose them.
+ *   seld_k_rn_conv      z [B,H,W/stride_f,Cout] = Conv2D(Cout, ksize in {1,3}, 'same', strides (1,stride_f), use_bias=False)(x [B,H,W,Cin]);
+ *                       w HWIO.  ksize 3: im2col + fp32 MFMA GEMM; ksize 1: the GEMM on rows of stride Cin*stride_f.
+ *   seld_k_rn_conv_bwd  dw (HWIO) and dx from dz
+ *   seld_k_rn_bn        out = [relu](BatchNormalization(training)(z) [+ res]) over npix x C (C % 32 == 0); mean / invstd optional outputs
+ *   seld_k_rn_bn_bwd    dz, dgamma, dbeta from dy gated by (mask > 0) (mask may be NULL) */
+int seld_k_rn_conv(const float* x, const float* w, float* z, int B, int H, int W, int Cin, int Cout, int ksize, int stride_f);
+int seld_k_rn_conv_bwd(const float* x, const float* w, const float* dz, float* dw, float* dx, int B, int H, int W, int Cin, int Cout,
+                       int ksize, int stride_f);
+int seld_k_rn_bn(const float* z, const float* gamma, const float* beta, const float* res, float* out, float* mean, float* invstd,
+                 int64_t npix, int C, int relu);
+int seld_k_rn_bn_bwd(const float* z, const float* dy, const float* mask, const float* gamma, float* dz, float* dgamma, float* dbeta,
+                     int64_t npix, int C);
 /* Diagnostic builds only (make CXXFLAGS+=-DGRU_TIMING; tools/tune_gru.py): shader-cycle sums per phase of the recurrence kernels'
  * last launch, wave 0 of every workgroup: cycles[blocks][4] = forward {h read + mat-vec, gate tail, barrier, chunk commit},
  * BPTT {gate gradients, barrier, coefficients + mat-vec + fold, -}.  SELD_ERR_UNSUPPORTED in the normal build. */

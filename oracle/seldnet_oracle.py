@@ -66,13 +66,15 @@ class Spec:
     sed_units: List[int]
     doa_units: List[int]
     n_classes: int = 12
-    first: str = "simple_conv_block"   # or "xception_block" (spec/XCEPTION_BLOCK.md: absent from the reference snapshot)
+    first: str = "simple_conv_block"   # or "xception_block" / "resnet50_block" (spec/*.md: absent from the reference snapshot)
     xc_blocks: int = 0                 # xception_block: number of middle-flow modules (block_num)
+    rn_filters: int = 0                # resnet50_block: base width (FIRST_ARGS.filters)
+    rn_blocks: Tuple[int, ...] = ()    # resnet50_block: bottleneck blocks per stage (FIRST_ARGS.block_num)
 
     @staticmethod
     def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
-        if model_config["FIRST"] not in ("simple_conv_block", "xception_block"):
-            raise ValueError("oracle restates simple_conv_block and xception_block only")
+        if model_config["FIRST"] not in ("simple_conv_block", "xception_block", "resnet50_block"):
+            raise ValueError("oracle restates simple_conv_block, xception_block and resnet50_block only")
         if model_config["SECOND"] != "bidirectional_GRU_block":
             raise ValueError("oracle restates bidirectional_GRU_block only")
         fa = model_config["FIRST_ARGS"]
@@ -83,6 +85,12 @@ class Spec:
                         gru_units=list(model_config["SECOND_ARGS"]["units"]), sed_units=list(model_config["SED_ARGS"]["units"]),
                         doa_units=list(model_config["DOA_ARGS"]["units"]), n_classes=int(model_config.get("n_classes", 12)),
                         first="xception_block", xc_blocks=int(fa["block_num"]))
+        if model_config["FIRST"] == "resnet50_block":
+            # spec/RESNET50_BLOCK.md: entry conv2d_bn(2 filters) + MaxPool(5,4), four stages of bottleneck blocks
+            return Spec(in_ch=in_ch, n_freq=n_freq, filters=[2 * int(fa["filters"])], pools=[(5, 4)],
+                        gru_units=list(model_config["SECOND_ARGS"]["units"]), sed_units=list(model_config["SED_ARGS"]["units"]),
+                        doa_units=list(model_config["DOA_ARGS"]["units"]), n_classes=int(model_config.get("n_classes", 12)),
+                        first="resnet50_block", rn_filters=int(fa["filters"]), rn_blocks=tuple(int(v) for v in fa["block_num"]))
         return Spec(
             in_ch=in_ch, n_freq=n_freq,
             filters=list(fa["filters"]),
@@ -93,6 +101,18 @@ class Spec:
             # train.py:306-307 forces n_classes = 12 regardless of the JSON
             n_classes=int(model_config.get("n_classes", 12)),
         )
+
+
+def resnet_plan(spec: Spec):
+    """spec/RESNET50_BLOCK.md as data: [(stage, block, cin, width, stride_f, projection)] in forward order, cin = the block's input channels"""
+    plan, cin = [], spec.filters[-1]
+    for s, nb in enumerate(spec.rn_blocks):
+        w = spec.rn_filters * (2 ** s)
+        for b in range(nb):
+            st = 2 if (b == 0 and s > 0) else 1
+            plan.append((s, b, cin, w, st, b == 0))
+            cin = 4 * w
+    return plan
 
 
 def variable_specs(spec: Spec) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tuple[str, Tuple[int, ...]]]]:
@@ -116,7 +136,19 @@ def variable_specs(spec: Spec) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[
                        (f"xc{b}.{u}.gamma", (cin,)), (f"xc{b}.{u}.beta", (cin,))]
                 nt += [(f"xc{b}.{u}.moving_mean", (cin,)), (f"xc{b}.{u}.moving_variance", (cin,))]
         fr //= 8      # exit MaxPooling2D((1, 8))
-    feat = fr * spec.filters[-1]
+    cout = spec.filters[-1]
+    if spec.first == "resnet50_block":
+        for s_, b, ci, wd, stf, proj in resnet_plan(spec):
+            pre = f"rn{s_}.{b}"
+            for i, shape in enumerate(((1, 1, ci, wd), (3, 3, wd, wd), (1, 1, wd, 4 * wd))):
+                tr += [(f"{pre}.c{i}.kernel", shape), (f"{pre}.c{i}.gamma", (shape[-1],)), (f"{pre}.c{i}.beta", (shape[-1],))]
+                nt += [(f"{pre}.c{i}.moving_mean", (shape[-1],)), (f"{pre}.c{i}.moving_variance", (shape[-1],))]
+            if proj:
+                tr += [(f"{pre}.sc.kernel", (1, 1, ci, 4 * wd)), (f"{pre}.sc.gamma", (4 * wd,)), (f"{pre}.sc.beta", (4 * wd,))]
+                nt += [(f"{pre}.sc.moving_mean", (4 * wd,)), (f"{pre}.sc.moving_variance", (4 * wd,))]
+            fr //= stf
+            cout = 4 * wd
+    feat = fr * cout
     for i, u in enumerate(spec.gru_units):
         for d in ("fwd", "bwd"):
             tr += [(f"gru{i}.{d}.kernel", (feat, 3 * u)),
@@ -265,7 +297,8 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
     is a ROUTING decision per pooled element — which window position passes (argmax) and whether it passes at all (> 0).
     `routing[i] = (pos int64 [B,H/pt,W/pf,C], gate bool same shape)` replaces the block's own decision by a given one (the
     function stays differentiable: the gradient then flows exactly where the given routing says); `record_routing[i]`
-    receives the free decision (pos, gate) and the fp64 margin behind it (top1 - top2 of the window, |top1|)."""
+    receives the free decision (pos, gate) and the fp64 margin behind it (top1 - top2 of the window, |top1|).
+    resnet50_block's ReLUs take the same aids under the keys "rn{s}.{b}.y0" / ".y1" / ".out" (gate only)."""
     new_st = {}
     h = x
     for i in range(len(spec.filters)):
@@ -308,6 +341,33 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             if taps is not None:
                 taps[f"xc{b}"] = h
         h = maxpool_nhwc(torch.relu(h), (1, 8))
+    if spec.first == "resnet50_block":
+        # spec/RESNET50_BLOCK.md: bottleneck blocks, strides on the frequency axis
+        def conv_bn(t, pre, stride_f, k):
+            kern = w[f"{pre}.kernel"].permute(3, 2, 0, 1)
+            t = F.conv2d(t.permute(0, 3, 1, 2), kern, None, stride=(1, stride_f), padding=k // 2).permute(0, 2, 3, 1)
+            t, m, v = batchnorm(t, w[f"{pre}.gamma"], w[f"{pre}.beta"], st[f"{pre}.moving_mean"], st[f"{pre}.moving_variance"],
+                                training, sync=bn_sync)
+            new_st[f"{pre}.moving_mean"], new_st[f"{pre}.moving_variance"] = m, v
+            return t
+        def relu_gate(t, key):
+            # routing[key] (bool, t's shape): the ReLU's gate given from outside (the decision an fp32 evaluation took); the
+            # function stays differentiable and the gradient passes exactly where the given gate says.  record_routing[key]
+            # receives the free decision and the pre-activation behind it.
+            if record_routing is not None:
+                record_routing[key] = {"gate": t.detach() > 0, "pre": t.detach()}
+            if routing is not None and key in routing:
+                return torch.where(routing[key], t, torch.zeros((), dtype=t.dtype))
+            return torch.relu(t)
+        for s_, b, ci, wd, stf, proj in resnet_plan(spec):
+            pre = f"rn{s_}.{b}"
+            y = relu_gate(conv_bn(h, f"{pre}.c0", stf, 1), f"{pre}.y0")
+            y = relu_gate(conv_bn(y, f"{pre}.c1", 1, 3), f"{pre}.y1")
+            y = conv_bn(y, f"{pre}.c2", 1, 1)
+            r = conv_bn(h, f"{pre}.sc", stf, 1) if proj else h
+            h = relu_gate(y + r, f"{pre}.out")
+            if taps is not None:
+                taps[pre] = h
     B, S = h.shape[0], h.shape[1]
     h = h.reshape(B, S, -1)  # layers.force_1d_inputs: feature index = f*C + c
     for i in range(len(spec.gru_units)):

@@ -39,7 +39,7 @@ class Arch(C.Structure):
                 ("pool_f", C.c_int32 * MAX_LAYERS), ("n_gru", C.c_int32), ("gru_units", C.c_int32 * MAX_LAYERS),
                 ("n_sed_dense", C.c_int32), ("sed_units", C.c_int32 * MAX_LAYERS),
                 ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32),
-                ("first_kind", C.c_int32), ("xc_blocks", C.c_int32)]
+                ("first_kind", C.c_int32), ("xc_blocks", C.c_int32), ("rn_filters", C.c_int32), ("rn_blocks", C.c_int32 * 4)]
 
 
 class LossCfg(C.Structure):
@@ -125,7 +125,12 @@ SIGNATURES = {
     "seld_k_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
     "seld_debug_pool_routing": (_I, [_P, _I, _P, _P]),
+    "seld_debug_relu_output": (_I, [_P, _I, _I, _P, _L, C.POINTER(C.c_int64)]),
     "seld_k_gru_timing": (_I, [_I, _P, _I]),
+    "seld_k_rn_conv": (_I, [_P, _P, _P] + [_I] * 7),
+    "seld_k_rn_conv_bwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 7),
+    "seld_k_rn_bn": (_I, [_P] * 7 + [_L, _I, _I]),
+    "seld_k_rn_bn_bwd": (_I, [_P] * 7 + [_L, _I]),
     "seld_device_clocks": (_I, [_I] + [C.POINTER(C.c_int)] * 4),
     "seld_k_valu_clock_mhz": (_I, [_I, C.POINTER(C.c_double)]),
 }

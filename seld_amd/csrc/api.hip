@@ -3,6 +3,7 @@
 #include "common.h"
 #include "../../include/seld_hip.h"
 
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -32,6 +33,19 @@ struct GruL {
 };
 
 struct DenseL { int in, out; int64_t w_off, b_off; float* y; float* dy; };
+
+// Conv2D(k in {1, 3}, strides (1, stride_f), use_bias=False) + BatchNormalization of resnet50_block (spec/RESNET50_BLOCK.md)
+struct RnConv {
+    int k = 1, Cin = 0, Cout = 0;
+    int64_t w_off = 0, g_off = 0, be_off = 0, mm_off = 0, mv_off = 0;
+    float *col = nullptr, *z = nullptr, *coef = nullptr;     // im2col of the input (k = 3), pre-BN output, [mean|invstd|scale|shift|c1|c2] x Cout
+};
+struct RnBlock {
+    int Cin, w, stride_f, Win, Wout;
+    bool proj;
+    RnConv c[3], sc;
+    float *y0 = nullptr, *y1 = nullptr, *out = nullptr;      // ReLU(BN(c0)), ReLU(BN(c1)) [M, w]; block output [M, 4w]
+};
 
 // one  ReLU -> SeparableConv2D(64, 3, use_bias=False) -> BatchNormalization  unit of xception_block's middle flow (spec/XCEPTION_BLOCK.md)
 struct XcUnit {
@@ -64,6 +78,10 @@ struct seld_ctx {
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
     float *xc_g[3] = {};                     // gradient ping-pong buffers [B,S,16,64]
+    // resnet50_block (arch.first_kind == SELD_FIRST_RESNET50): conv[0] is the entry block, then the bottleneck blocks
+    std::vector<RnBlock> rn;
+    float *rn_part = nullptr, *rn_gx[2] = {}, *rn_bz = nullptr, *rn_ba = nullptr, *rn_bb = nullptr, *rn_bcol = nullptr;
+    int rn_feat = 0;                         // features per label frame into the first GRU layer (2 x 32 rn_filters)
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
@@ -188,8 +206,14 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernels are built for in_ch = 7 (foa) and 10 (mic)");
     if (a->n_freq != 64) return fail(nullptr, SELD_ERR_UNSUPPORTED, "first conv kernel is built for n_freq = 64");
     if (a->n_classes <= 0) return fail(nullptr, SELD_ERR_INVALID, "n_classes must be positive");
-    const bool xcep = a->first_kind == SELD_FIRST_XCEPTION;
-    if (a->first_kind != SELD_FIRST_SIMPLE_CONV && !xcep) return fail(nullptr, SELD_ERR_UNSUPPORTED, "unknown FIRST block kind");
+    const bool xcep = a->first_kind == SELD_FIRST_XCEPTION, resn = a->first_kind == SELD_FIRST_RESNET50;
+    if (a->first_kind != SELD_FIRST_SIMPLE_CONV && !xcep && !resn) return fail(nullptr, SELD_ERR_UNSUPPORTED, "unknown FIRST block kind");
+    if (resn) {
+        if (a->n_conv != 1 || a->pool_t[0] != 5 || a->pool_f[0] != 4 || a->rn_filters != 32)
+            return fail(nullptr, SELD_ERR_UNSUPPORTED, "resnet50_block: one entry conv2d_bn(64) with pool (5,4), filters 32 (spec/RESNET50_BLOCK.md)");
+        for (int s_ = 0; s_ < 4; ++s_)
+            if (a->rn_blocks[s_] < 1 || a->rn_blocks[s_] > 8) return fail(nullptr, SELD_ERR_UNSUPPORTED, "resnet50_block: 1..8 blocks per stage");
+    }
     if (xcep && (a->n_conv != 1 || a->pool_t[0] != 5 || a->pool_f[0] != 4 || a->xc_blocks < 1 || a->xc_blocks > SELD_MAX_XC_BLOCKS))
         return fail(nullptr, SELD_ERR_UNSUPPORTED, "xception_block: one entry conv2d_bn(64) with pool (5,4) and 1..16 middle modules (spec/XCEPTION_BLOCK.md)");
     int H = T, W = a->n_freq;
@@ -206,10 +230,11 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         if (W != 16) return fail(nullptr, SELD_ERR_UNSUPPORTED, "xception_block: 16 frequency bins after the entry pool (n_freq 64)");
         W /= 8;       // exit MaxPooling2D((1, 8))
     }
-    const int S = H, feat = W * 64;
+    if (resn && W != 16) return fail(nullptr, SELD_ERR_UNSUPPORTED, "resnet50_block: 16 frequency bins after the entry pool (n_freq 64)");
+    const int S = H, feat = resn ? (W / 8) * 32 * a->rn_filters : W * 64;
     for (int i = 0; i < a->n_gru; ++i)
         if (a->gru_units[i] != 128) return fail(nullptr, SELD_ERR_UNSUPPORTED, "GRU kernels are built for 128 units");
-    if (feat != 128) return fail(nullptr, SELD_ERR_UNSUPPORTED, "GRU input projection expects 128 features (F'*C' = 2*64)");
+    if (feat <= 0 || feat % 128) return fail(nullptr, SELD_ERR_UNSUPPORTED, "GRU input projection expects a multiple of 128 features (seldnet.json: F'*C' = 2*64)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SELD_ERR_HIP, "no HIP device");
@@ -249,6 +274,30 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
                 snprintf(nm, sizeof nm, "xc%d.%d.moving_variance", b, u); U.mv_off = soff; add_var(c->nt, soff, nm, {64});
                 c->xc.push_back(U);
             }
+    if (resn) {
+        int cin_b = 64, wcur = 16;
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int wd = a->rn_filters << s_;
+            for (int b = 0; b < a->rn_blocks[s_]; ++b) {
+                RnBlock R;
+                R.Cin = cin_b; R.w = wd; R.stride_f = (b == 0 && s_ > 0) ? 2 : 1; R.Win = wcur; R.Wout = wcur / R.stride_f; R.proj = b == 0;
+                auto mk = [&](RnConv& cv, const char* tag, int k, int ci, int co) {
+                    char nm[96];
+                    cv.k = k; cv.Cin = ci; cv.Cout = co;
+                    snprintf(nm, sizeof nm, "rn%d.%d.%s.kernel", s_, b, tag); cv.w_off = off; add_var(c->tr, off, nm, {k, k, ci, co});
+                    snprintf(nm, sizeof nm, "rn%d.%d.%s.gamma", s_, b, tag); cv.g_off = off; add_var(c->tr, off, nm, {co});
+                    snprintf(nm, sizeof nm, "rn%d.%d.%s.beta", s_, b, tag); cv.be_off = off; add_var(c->tr, off, nm, {co});
+                    snprintf(nm, sizeof nm, "rn%d.%d.%s.moving_mean", s_, b, tag); cv.mm_off = soff; add_var(c->nt, soff, nm, {co});
+                    snprintf(nm, sizeof nm, "rn%d.%d.%s.moving_variance", s_, b, tag); cv.mv_off = soff; add_var(c->nt, soff, nm, {co});
+                };
+                mk(R.c[0], "c0", 1, cin_b, wd); mk(R.c[1], "c1", 3, wd, wd); mk(R.c[2], "c2", 1, wd, 4 * wd);
+                if (R.proj) mk(R.sc, "sc", 1, cin_b, 4 * wd);
+                c->rn.push_back(R);
+                cin_b = 4 * wd; wcur = R.Wout;
+            }
+        }
+        c->rn_feat = feat;
+    }
     int fin = feat;
     for (int i = 0; i < a->n_gru; ++i) {
         GruL G;
@@ -330,6 +379,21 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(c->xc_feat, (size_t)B * S * 128);
         ALLOC(c->xc_part, (size_t)xc_partial_capacity() * 128);
         ALLOC(c->xc_slab, (size_t)xc_partial_capacity() * 576);
+    }
+    if (resn) {
+        size_t mx_out = 0, mx_w = 0, mx_col = 0, mx_in = (size_t)B * S * 16 * 64;
+        for (auto& R : c->rn) {
+            const size_t M = (size_t)B * S * R.Wout;
+            for (int i = 0; i < 3; ++i) { ALLOC(R.c[i].z, M * R.c[i].Cout); ALLOC(R.c[i].coef, (size_t)6 * R.c[i].Cout); }
+            ALLOC(R.c[1].col, M * 9 * R.w);
+            if (R.proj) { ALLOC(R.sc.z, M * 4 * R.w); ALLOC(R.sc.coef, (size_t)6 * 4 * R.w); }
+            ALLOC(R.y0, M * R.w); ALLOC(R.y1, M * R.w); ALLOC(R.out, M * 4 * R.w);
+            mx_out = std::max(mx_out, M * 4 * R.w); mx_w = std::max(mx_w, M * R.w); mx_col = std::max(mx_col, M * 9 * R.w);
+            mx_in = std::max(mx_in, (size_t)B * S * R.Win * R.Cin);
+        }
+        ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
+        ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
+        ALLOC(c->rn_bz, mx_out); ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bb, mx_w); ALLOC(c->rn_bcol, mx_col);
     }
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
@@ -561,6 +625,8 @@ static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orien
     return flush();
 }
 
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training);
+
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
@@ -714,6 +780,38 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             return fail(c, SELD_ERR_UNSUPPORTED, "xception exit pool");
         in = c->xc_feat;
     }
+    if (c->arch.first_kind == SELD_FIRST_RESNET50) {
+        // ---- resnet50_block stages (spec/RESNET50_BLOCK.md): every convolution a product on the fp32 MFMA GEMM
+        if (training && c->sync_fn) return fail(c, SELD_ERR_UNSUPPORTED, "synchronised BatchNorm is not wired into resnet50_block");
+        PROF(c, "rn_stages_fwd");
+        const float* X = in;      // [B,S,Win,Cin]
+        for (auto& R : c->rn) {
+            const int64_t M = (int64_t)B * S * R.Wout;
+            const int w = R.w;
+            // 1x1 (frequency stride = doubled row stride of the operand), BN, ReLU
+            launch_gemm(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, w, nullptr, R.c[0].z, w, (int)M, w, R.Cin, 0, 0, 0);
+            rn_bn(c, st, R.c[0], M, training);
+            launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1);
+            // 3x3 through im2col, BN, ReLU
+            launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
+            launch_gemm(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, w, nullptr, R.c[1].z, w, (int)M, w, 9 * w, 0, 0, 0);
+            rn_bn(c, st, R.c[1], M, training);
+            launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1);
+            // 1x1 expand, BN; shortcut; out = ReLU(y + r)
+            launch_gemm(st, R.y1, w, c->params + R.c[2].w_off, 4 * w, nullptr, R.c[2].z, 4 * w, (int)M, 4 * w, w, 0, 0, 0);
+            rn_bn(c, st, R.c[2], M, training);
+            if (R.proj) {
+                launch_gemm(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, 4 * w, nullptr, R.sc.z, 4 * w, (int)M, 4 * w, R.Cin, 0, 0, 0);
+                rn_bn(c, st, R.sc, M, training);
+                launch_rn_bn_apply(st, R.sc.z, R.sc.coef, nullptr, R.out, M, 4 * w, 0);
+                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, R.out, R.out, M, 4 * w, 1);
+            } else {
+                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1);
+            }
+            X = R.out;
+        }
+        in = X;       // [B,S,2,1024] = [B,S,2048]
+    }
     const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
     for (size_t i = 0; i < c->gru.size(); ++i) {
         GruL& G = c->gru[i];
@@ -842,9 +940,35 @@ int seld_test_step(seld_ctx* c, const float* x, const float* y_sed, const float*
 static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A, int lda, const float* Bm, int ldb, int M,
                         int K1, int N, int64_t w_off, int64_t b_off, int S, int shift) {
     int ns = 0;
+    // both slab buffers hold gemm_tn_max_splits() slabs of 384 x 384 + 384 floats: larger products (a 2048-feature GRU input) take fewer splits
+    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384) / ((int64_t)K1 * N + N);
     if (c->gemm_split_bf16 && gemm_tn_sb_usable(A, lda, Bm, ldb, K1, N)) launch_gemm_tn_sb(st, A, lda, Bm, ldb, slab, &ns, M, N, S, shift, 1);
-    else launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1);
+    else launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1, (int)std::min<int64_t>(cap, gemm_tn_max_splits()));
     launch_reduce_slabs2(st, slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
+}
+
+// dW[K1,N] = A^T B for a bias-free convolution of a FIRST block (xception / resnet50), as many short splits as the slab buffer holds
+static void wgrad_conv(seld_ctx* c, hipStream_t st, const float* A, int lda, const float* Bm, int M, int K1, int N, int64_t w_off) {
+    int ns = 0;
+    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384) / ((int64_t)K1 * N + N);
+    launch_gemm_tn(st, A, lda, Bm, N, c->tn_slab, &ns, M, K1, N, 0, 0, 0, (int)std::max<int64_t>(1, std::min<int64_t>(cap, 512)));
+    launch_reduce_slabs2(st, c->tn_slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, nullptr, 0);
+}
+
+
+// BatchNormalization of a resnet50_block convolution: statistics (training) or moving statistics -> cv.coef
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training) {
+    int nbx = 0;
+    if (training) launch_rn_bn_stats(st, cv.z, c->rn_part, &nbx, M, cv.Cout);
+    launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, c->params + cv.g_off, c->params + cv.be_off, c->state + cv.mm_off,
+                          c->state + cv.mv_off, cv.coef, cv.Cout, training);
+}
+// backward of the same: dz = BN'(dy [mask > 0]) into `dz`, dgamma / dbeta into the gradient buffer
+static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, const float* mask, float* dz, int64_t M) {
+    int nbx = 0;
+    launch_rn_bn_bwd_reduce(st, cv.z, dy, mask, cv.coef, c->rn_part, &nbx, M, cv.Cout);
+    launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout);
+    launch_rn_bn_bwd_dz(st, cv.z, dy, mask, cv.coef, dz, M, cv.Cout);
 }
 
 // weight gradients of the fused linear heads, on the side stream (the caller has forked): F = feat^T dy and colsum(dy) in one TN
@@ -919,7 +1043,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
     const float* dout = c->feat_grad;
     for (int i = (int)c->gru.size() - 1; i >= 0; --i) {
         GruL& G = c->gru[i];
-        const float* lin = i == 0 ? (c->arch.first_kind == SELD_FIRST_XCEPTION ? c->xc_feat : c->conv.back().p) : c->gru[i - 1].out;
+        const float* lin = i == 0 ? (c->arch.first_kind == SELD_FIRST_XCEPTION ? c->xc_feat : (c->arch.first_kind == SELD_FIRST_RESNET50 ? c->rn.back().out : c->conv.back().p)) : c->gru[i - 1].out;
         {
             PROF(c, "gru_bwd");
             launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
@@ -950,6 +1074,45 @@ static int backward_impl(seld_ctx* c, const float* x) {
     }
     // ---- conv blocks, last to first.  dout = gradient w.r.t. the last pooled output
     const float* dp = dout;
+    if (c->arch.first_kind == SELD_FIRST_RESNET50) {
+        // ---- resnet50_block backward, blocks last to first; g = gradient w.r.t. the block's output
+        PROF(c, "rn_stages_bwd");
+        const float* g = dout;
+        int flip = 0;
+        for (int bi = (int)c->rn.size() - 1; bi >= 0; --bi) {
+            RnBlock& R = c->rn[bi];
+            const int64_t M = (int64_t)B * S * R.Wout;
+            const int w = R.w;
+            const float* X = bi == 0 ? c->conv[0].p : c->rn[bi - 1].out;
+            float* dX = bi == 0 ? c->conv[0].dp : c->rn_gx[flip];
+            const int ldx = R.Cin * R.stride_f;
+            // main branch: BN2 (behind the block's ReLU: mask = out), 1x1 expand
+            rn_bn_bwd(c, st, R.c[2], g, R.out, c->rn_bz, M);
+            wgrad_conv(c, st, R.y1, w, c->rn_bz, (int)M, w, 4 * w, R.c[2].w_off);
+            launch_gemm(st, c->rn_bz, 4 * w, c->params + R.c[2].w_off, 4 * w, nullptr, c->rn_ba, w, (int)M, w, 4 * w, 1, 0, 0);
+            // BN1 (mask = y1), 3x3 through im2col / col2im
+            rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, c->rn_bb, M);
+            wgrad_conv(c, st, R.c[1].col, 9 * w, c->rn_bb, (int)M, 9 * w, w, R.c[1].w_off);
+            launch_gemm(st, c->rn_bb, w, c->params + R.c[1].w_off, w, nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 1, 0, 0);
+            launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
+            // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
+            rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, c->rn_bb, M);
+            wgrad_conv(c, st, X, ldx, c->rn_bb, (int)M, R.Cin, w, R.c[0].w_off);
+            if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
+            launch_gemm(st, c->rn_bb, w, c->params + R.c[0].w_off, w, nullptr, dX, ldx, (int)M, R.Cin, w, 1, 0, 0);
+            // shortcut
+            if (R.proj) {
+                rn_bn_bwd(c, st, R.sc, g, R.out, c->rn_bz, M);
+                wgrad_conv(c, st, X, ldx, c->rn_bz, (int)M, R.Cin, 4 * w, R.sc.w_off);
+                launch_gemm(st, c->rn_bz, 4 * w, c->params + R.sc.w_off, 4 * w, nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1, 0, 1);
+            } else {
+                launch_rn_add_masked(st, dX, g, R.out, M * 4 * w);
+            }
+            g = dX;
+            flip ^= 1;
+        }
+        dp = c->conv[0].dp;
+    }
     if (c->arch.first_kind == SELD_FIRST_XCEPTION) {
         // ---- xception_block backward: exit pool, then the modules last to first.  gX = gradient w.r.t. the module's output
         // (= the next module's input); within a module gY walks back through the three units and the residual adds gX to it.
@@ -1163,6 +1326,20 @@ int seld_debug_pool_routing(seld_ctx* c, int block, unsigned char* pos, unsigned
         return fail(c, SELD_ERR_UNSUPPORTED, "pool_routing");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "pool_routing");
+}
+
+int seld_debug_relu_output(seld_ctx* c, int block, int which, float* dst, int64_t capacity, int64_t* count) {
+    if (!c || !dst || !count || which < 0 || which > 2) return SELD_ERR_INVALID;
+    if (c->arch.first_kind != SELD_FIRST_RESNET50 || block < 0 || block >= (int)c->rn.size()) return SELD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const RnBlock& R = c->rn[block];
+    const int64_t M = (int64_t)c->B * c->S * R.Wout, n = M * (which == 2 ? 4 * R.w : R.w);
+    *count = n;
+    if (capacity < n) return fail(c, SELD_ERR_INVALID, "seld_debug_relu_output: destination too small");
+    const float* src = which == 0 ? R.y0 : (which == 1 ? R.y1 : R.out);
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SELD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- profiling

@@ -104,6 +104,19 @@ int launch_bn_pool_bwd_reduce(hipStream_t st, const float* z, const float* p, co
                               int* npartial, int B, int H, int W, int C, int pt, int pf, int z_is_pooled_extreme = 0);
 int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, double count, float* dgamma,
                            float* dbeta, float* c1c2, int C);
+// resnet.hip: channel-count-generic layers of resnet50_block (spec/RESNET50_BLOCK.md)
+int rn_partial_capacity();
+int launch_im2col3x3(hipStream_t st, const float* y, float* col, int B, int H, int W, int C);
+int launch_col2im3x3(hipStream_t st, const float* dcol, float* dy, int B, int H, int W, int C);
+int launch_rn_bn_stats(hipStream_t st, const float* z, float* partial, int* nbx, int64_t npix, int C);
+int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* partial, int* nbx,
+                            int64_t npix, int C);
+int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double count, const float* gamma, const float* beta, float* mov_mean,
+                          float* mov_var, float* coef, int C, int training);
+int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C);
+int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu);
+int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C);
+int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n);
 // xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
 int xc_partial_capacity();
 int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W);

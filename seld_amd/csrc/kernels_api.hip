@@ -358,6 +358,91 @@ int seld_k_valu_clock_mhz(int blocks, double* mhz) {
     return SELD_OK;
 }
 
+// ---- resnet50_block pieces (resnet.hip + the fp32 GEMMs), as api.hip composes them
+int seld_k_rn_conv(const float* x, const float* w, float* z, int B, int H, int W, int Cin, int Cout, int ksize, int stride_f) {
+    if (!x || !w || !z) return SELD_ERR_INVALID;
+    if ((ksize != 1 && ksize != 3) || (ksize == 3 && stride_f != 1) || stride_f < 1 || W % stride_f || Cin % 4) return SELD_ERR_UNSUPPORTED;
+    const int Wo = W / stride_f;
+    const int M = B * H * Wo;
+    if (ksize == 1) {
+        if (launch_gemm(0, x, Cin * stride_f, w, Cout, nullptr, z, Cout, M, Cout, Cin, 0, 0, 0)) return SELD_ERR_INVALID;
+        return done();
+    }
+    Scratch s;
+    float* col = s.get((size_t)M * 9 * Cin);
+    if (!col) return SELD_ERR_NOMEM;
+    launch_im2col3x3(0, x, col, B, H, W, Cin);
+    if (launch_gemm(0, col, 9 * Cin, w, Cout, nullptr, z, Cout, M, Cout, 9 * Cin, 0, 0, 0)) return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_rn_conv_bwd(const float* x, const float* w, const float* dz, float* dw, float* dx, int B, int H, int W, int Cin, int Cout,
+                       int ksize, int stride_f) {
+    if (!x || !w || !dz || !dw || !dx) return SELD_ERR_INVALID;
+    if ((ksize != 1 && ksize != 3) || (ksize == 3 && stride_f != 1) || stride_f < 1 || W % stride_f || Cin % 4) return SELD_ERR_UNSUPPORTED;
+    const int Wo = W / stride_f, M = B * H * Wo, K1 = ksize * ksize * Cin;
+    Scratch s;
+    const int64_t per = (int64_t)K1 * Cout + Cout;
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)gemm_tn_max_splits() * (384 * 384 + 384)) / per));
+    float* slab = s.get((size_t)splits * per);
+    float* col = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
+    float* dcol = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
+    if (!slab || (ksize == 3 && (!col || !dcol))) return SELD_ERR_NOMEM;
+    int ns = 0;
+    if (ksize == 3) {
+        launch_im2col3x3(0, x, col, B, H, W, Cin);
+        launch_gemm_tn(0, col, K1, dz, Cout, slab, &ns, M, K1, Cout, 0, 0, 0, splits);
+        launch_reduce_slabs2(0, slab, ns, per, dw, (int64_t)K1 * Cout, nullptr, 0);
+        launch_gemm(0, dz, Cout, w, Cout, nullptr, dcol, K1, M, K1, Cout, 1, 0, 0);
+        launch_col2im3x3(0, dcol, dx, B, H, W, Cin);
+    } else {
+        const int ldx = Cin * stride_f;
+        launch_gemm_tn(0, x, ldx, dz, Cout, slab, &ns, M, K1, Cout, 0, 0, 0, splits);
+        launch_reduce_slabs2(0, slab, ns, per, dw, (int64_t)K1 * Cout, nullptr, 0);
+        if (stride_f > 1 && hipMemsetAsync(dx, 0, (size_t)B * H * W * Cin * sizeof(float), 0) != hipSuccess) return SELD_ERR_HIP;
+        launch_gemm(0, dz, Cout, w, Cout, nullptr, dx, ldx, M, Cin, Cout, 1, 0, 0);
+    }
+    return done();
+}
+
+int seld_k_rn_bn(const float* z, const float* gamma, const float* beta, const float* res, float* out, float* mean, float* invstd,
+                 int64_t npix, int C, int relu) {
+    if (!z || !gamma || !beta || !out) return SELD_ERR_INVALID;
+    if (C % 32 || npix <= 0) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* part = s.get((size_t)rn_partial_capacity() * ((C + 63) / 64) * 128);
+    float* coef = s.get((size_t)6 * C);
+    float* mov = s.get((size_t)2 * C);
+    if (!part || !coef || !mov) return SELD_ERR_NOMEM;
+    if (hipMemsetAsync(mov, 0, (size_t)2 * C * sizeof(float), 0) != hipSuccess) return SELD_ERR_HIP;
+    int nbx = 0;
+    if (launch_rn_bn_stats(0, z, part, &nbx, npix, C)) return SELD_ERR_UNSUPPORTED;
+    launch_rn_bn_finalize(0, part, nbx, (double)npix, gamma, beta, mov, mov + C, coef, C, 1);
+    launch_rn_bn_apply(0, z, coef, res, out, npix, C, relu);
+    if (mean && hipMemcpyAsync(mean, coef, C * sizeof(float), hipMemcpyDeviceToDevice, 0) != hipSuccess) return SELD_ERR_HIP;
+    if (invstd && hipMemcpyAsync(invstd, coef + C, C * sizeof(float), hipMemcpyDeviceToDevice, 0) != hipSuccess) return SELD_ERR_HIP;
+    return done();
+}
+
+int seld_k_rn_bn_bwd(const float* z, const float* dy, const float* mask, const float* gamma, float* dz, float* dgamma, float* dbeta,
+                     int64_t npix, int C) {
+    if (!z || !dy || !gamma || !dz || !dgamma || !dbeta) return SELD_ERR_INVALID;
+    if (C % 32 || npix <= 0) return SELD_ERR_UNSUPPORTED;
+    Scratch s;
+    float* part = s.get((size_t)rn_partial_capacity() * ((C + 63) / 64) * 128);
+    float* coef = s.get((size_t)6 * C);
+    float* mov = s.get((size_t)3 * C);
+    if (!part || !coef || !mov) return SELD_ERR_NOMEM;
+    if (hipMemsetAsync(mov, 0, (size_t)3 * C * sizeof(float), 0) != hipSuccess) return SELD_ERR_HIP;
+    int nbx = 0;
+    launch_rn_bn_stats(0, z, part, &nbx, npix, C);
+    launch_rn_bn_finalize(0, part, nbx, (double)npix, gamma, mov + 2 * C, mov, mov + C, coef, C, 1);     // beta plays no part in the backward
+    launch_rn_bn_bwd_reduce(0, z, dy, mask, coef, part, &nbx, npix, C);
+    launch_rn_bn_bwd_finalize(0, part, nbx, (double)npix, dgamma, dbeta, coef, C);
+    launch_rn_bn_bwd_dz(0, z, dy, mask, coef, dz, npix, C);
+    return done();
+}
+
 int seld_k_gru_timing(int which, unsigned long long* cycles, int blocks) {
     if (!cycles) return SELD_ERR_INVALID;
     const int rc = gru_timing_read(which, cycles, blocks);

@@ -1,0 +1,242 @@
+// resnet.hip — channel-count-generic layer kernels for `resnet50_block` (spec/RESNET50_BLOCK.md; model_config/resnet50_gru.json:2-11
+// names the block, the reference snapshot does not define it).  Correctness-first: every convolution is a product on the fp32 MFMA
+// GEMM of gemm.hip — a 1x1 convolution directly (a frequency stride of 2 is a doubled row stride of the operand), a 3x3 convolution
+// through an explicit im2col —, kernel gradients are the TN product of gemm.hip, and BatchNormalization / ReLU / residual adds are
+// streaming kernels over [pixels][C] with float4 over the channels, C any multiple of 32.
+//
+//   im2col3x3 / col2im3x3     col[p][tap C + c] = y[p + tap][c] ('same' padding)  /  dy[p][c] = sum_taps dcol[p - tap][tap C + c]
+//   rn_reduce<BWD>            per-workgroup, per 64-channel chunk [sum z | sum z^2]  resp.  [sum dy' | sum dy' xhat], dy' = dy [mask > 0]
+//   rn_bn_finalize / rn_bn_bwd_finalize   the per-channel finalisation of bn_pool.hip for any C (one workgroup per 64 channels)
+//   rn_bn_apply               out = [relu](z scale + shift [+ res])
+//   rn_bn_bwd_dz              dz = scale (dy' - c1 - xhat c2)
+//   rn_add_masked             dst += dy [mask > 0]
+#include "common.h"
+
+#define RN_MAX_PARTIAL 256
+int rn_partial_capacity() { return RN_MAX_PARTIAL; }
+
+__device__ __forceinline__ float4 rn_fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// thread per (output pixel, tap, group of 4 channels): G = C / 4 groups
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ y, float* __restrict__ col, int64_t npix, int H, int W, int G) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * 9 * G) return;
+    const int g = (int)(gid % G);
+    const int64_t pt = gid / G;
+    const int tap = (int)(pt % 9);
+    const int64_t p = pt / 9;
+    const int f = (int)(p % W), t = (int)((p / W) % H);
+    const int dt = tap / 3 - 1, df = tap % 3 - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W) v = reinterpret_cast<const float4*>(y)[(p + dt * W + df) * G + g];
+    reinterpret_cast<float4*>(col)[(p * 9 + tap) * G + g] = v;
+}
+int launch_im2col3x3(hipStream_t st, const float* y, float* col, int B, int H, int W, int C) {
+    const int64_t npix = (int64_t)B * H * W, n = npix * 9 * (C / 4);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, col, npix, H, W, C / 4);
+    return 0;
+}
+
+// dy[p][c] = sum_taps dcol[p - tap][tap C + c]: thread per (pixel, group)
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, float* __restrict__ dy, int64_t npix, int H, int W, int G) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npix * G) return;
+    const int g = (int)(gid % G);
+    const int64_t p = gid / G;
+    const int f = (int)(p % W), t = (int)((p / W) % H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dt = tap / 3 - 1, df = tap % 3 - 1;
+        if (t - dt >= 0 && t - dt < H && f - df >= 0 && f - df < W) {
+            const float4 v = reinterpret_cast<const float4*>(dcol)[((p - dt * W - df) * 9 + tap) * G + g];
+            acc = make_float4(acc.x + v.x, acc.y + v.y, acc.z + v.z, acc.w + v.w);
+        }
+    }
+    reinterpret_cast<float4*>(dy)[p * G + g] = acc;
+}
+int launch_col2im3x3(hipStream_t st, const float* dcol, float* dy, int B, int H, int W, int C) {
+    const int64_t npix = (int64_t)B * H * W, n = npix * (C / 4);
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dcol, dy, npix, H, W, C / 4);
+    return 0;
+}
+
+// grid (blocks_x, C / 64): workgroup (x, y) reduces the pixels x, x + gridDim.x, ... of channels [64 y, 64 y + 64).
+// partial[(y * gridDim.x + x)][128]
+template <bool BWD>
+__global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
+                                                        const float* __restrict__ coef, float* __restrict__ partial, int64_t npix, int C) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
+    const int c0 = blockIdx.y * 64 + 4 * g;
+    const bool gok = c0 < C;                 // C = 32: half of the chunk's groups have no channels
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
+    if (BWD && gok) { mu = *reinterpret_cast<const float4*>(coef + c0); is = *reinterpret_cast<const float4*>(coef + C + c0); }
+    for (int64_t p = (int64_t)blockIdx.x * 16 + slot; gok && p < npix; p += (int64_t)gridDim.x * 16) {
+        const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c0);
+        if (BWD) {
+            float4 d = *reinterpret_cast<const float4*>(dy + p * C + c0);
+            if (mask) {
+                const float4 m = *reinterpret_cast<const float4*>(mask + p * C + c0);
+                d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+            }
+            s1 = make_float4(s1.x + d.x, s1.y + d.y, s1.z + d.z, s1.w + d.w);
+            s2 = make_float4(s2.x + d.x * (zv.x - mu.x) * is.x, s2.y + d.y * (zv.y - mu.y) * is.y, s2.z + d.z * (zv.z - mu.z) * is.z,
+                             s2.w + d.w * (zv.w - mu.w) * is.w);
+        } else {
+            s1 = make_float4(s1.x + zv.x, s1.y + zv.y, s1.z + zv.z, s1.w + zv.w);
+            s2 = rn_fma4(zv, zv, s2);
+        }
+    }
+    *reinterpret_cast<float4*>(&red[tid * 8]) = s1;
+    *reinterpret_cast<float4*>(&red[tid * 8 + 4]) = s2;
+    __syncthreads();
+    if (tid < 128) {
+        const int kind = tid >> 6, ch = tid & 63, gg = ch >> 2, cc = ch & 3;
+        float s = 0.f;
+        for (int sl = 0; sl < 16; ++sl) s += red[(sl * 16 + gg) * 8 + kind * 4 + cc];
+        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + tid] = s;
+    }
+}
+static int rn_blocks_x(int64_t npix) {
+    int64_t b = (npix + 15) / 16;
+    return (int)(b > RN_MAX_PARTIAL ? RN_MAX_PARTIAL : b);
+}
+int launch_rn_bn_stats(hipStream_t st, const float* z, float* partial, int* nbx, int64_t npix, int C) {
+    if (C % 32) return -2;
+    *nbx = rn_blocks_x(npix);
+    hipLaunchKernelGGL(rn_reduce_kernel<false>, dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix, C);
+    return 0;
+}
+int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* partial, int* nbx,
+                            int64_t npix, int C) {
+    if (C % 32) return -2;
+    *nbx = rn_blocks_x(npix);
+    hipLaunchKernelGGL(rn_reduce_kernel<true>, dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
+    return 0;
+}
+
+// one workgroup per 64-channel chunk: the chunk's partials [nbx][128] -> coef = [mean | invstd | scale | shift | c1 | c2] x C
+__global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const float* __restrict__ partial, int nbx, double count, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ mov_mean,
+                                                             float* __restrict__ mov_var, float* __restrict__ coef, int C, int training) {
+    __shared__ double red[256];
+    __shared__ double tot[128];
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+    if (training) {
+        const int v = tid & 127, part = tid >> 7;
+        double s = 0.0;
+        for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < 128) tot[tid] = red[tid] + red[128 + tid];
+        __syncthreads();
+    }
+    if (tid >= 64) return;
+    const int c = c0 + tid;
+    if (c >= C) return;
+    if (training) {
+        const double mean = tot[tid] / count;
+        double var = tot[64 + tid] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)SELD_BN_EPS));
+        const float sc = gamma[c] * invstd;
+        coef[c] = (float)mean; coef[C + c] = invstd; coef[2 * C + c] = sc; coef[3 * C + c] = beta[c] - (float)mean * sc;
+        const float f = 1.f - SELD_BN_MOMENTUM;
+        const double bessel = count > 1.0 ? count / (count - 1.0) : 1.0;
+        mov_mean[c] = mov_mean[c] * (1.f - f) + (float)mean * f;
+        mov_var[c] = mov_var[c] * (1.f - f) + (float)(var * bessel) * f;
+    } else {
+        const float sc = gamma[c] * rsqrtf(mov_var[c] + SELD_BN_EPS);
+        coef[2 * C + c] = sc; coef[3 * C + c] = beta[c] - mov_mean[c] * sc;
+    }
+}
+int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double count, const float* gamma, const float* beta, float* mov_mean,
+                          float* mov_var, float* coef, int C, int training) {
+    hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, gamma, beta, mov_mean, mov_var, coef, C,
+                       training);
+    return 0;
+}
+__global__ __launch_bounds__(256) void rn_bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbx, double count, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ coef, int C) {
+    __shared__ double red[256];
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x, v = tid & 127, part = tid >> 7;
+    double s = 0.0;
+    for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
+    red[tid] = s;
+    __syncthreads();
+    if (tid >= 128) return;
+    const double t = red[tid] + red[128 + tid];
+    if (c0 + (tid & 63) >= C) return;
+    if (tid < 64) { dbeta[c0 + tid] = (float)t; coef[4 * C + c0 + tid] = (float)(t / count); }
+    else { dgamma[c0 + tid - 64] = (float)t; coef[5 * C + c0 + tid - 64] = (float)(t / count); }
+}
+int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C) {
+    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, dgamma, dbeta, coef, C);
+    return 0;
+}
+
+// out = [relu](z scale + shift [+ res]); G = C / 4
+__global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ res,
+                                                          float* __restrict__ out, int64_t n4, int G, int relu) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n4) return;
+    const int g = (int)(gid % G), C = 4 * G;
+    float4 o = rn_fma4(reinterpret_cast<const float4*>(z)[gid], reinterpret_cast<const float4*>(coef + 2 * C)[g],
+                       reinterpret_cast<const float4*>(coef + 3 * C)[g]);
+    if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[gid];
+        o = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w);
+    }
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    reinterpret_cast<float4*>(out)[gid] = o;
+}
+int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu) {
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(rn_bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, res, out, n4, C / 4, relu);
+    return 0;
+}
+
+// dz = scale (dy' - c1 - xhat c2), dy' = dy [mask > 0]
+__global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
+                                                           const float* __restrict__ coef, float* __restrict__ dz, int64_t n4, int G) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n4) return;
+    const int g = (int)(gid % G), C = 4 * G;
+    const float4 zv = reinterpret_cast<const float4*>(z)[gid];
+    float4 d = reinterpret_cast<const float4*>(dy)[gid];
+    if (mask) {
+        const float4 m = reinterpret_cast<const float4*>(mask)[gid];
+        d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+    }
+    const float4 mu = reinterpret_cast<const float4*>(coef)[g], is = reinterpret_cast<const float4*>(coef + C)[g];
+    const float4 sc = reinterpret_cast<const float4*>(coef + 2 * C)[g], c1 = reinterpret_cast<const float4*>(coef + 4 * C)[g];
+    const float4 c2 = reinterpret_cast<const float4*>(coef + 5 * C)[g];
+    float4 o;
+    o.x = sc.x * (d.x - c1.x - (zv.x - mu.x) * is.x * c2.x);
+    o.y = sc.y * (d.y - c1.y - (zv.y - mu.y) * is.y * c2.y);
+    o.z = sc.z * (d.z - c1.z - (zv.z - mu.z) * is.z * c2.z);
+    o.w = sc.w * (d.w - c1.w - (zv.w - mu.w) * is.w * c2.w);
+    reinterpret_cast<float4*>(dz)[gid] = o;
+}
+int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C) {
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(rn_bn_bwd_dz_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
+    return 0;
+}
+
+// dst += dy [mask > 0]   (identity shortcut: the block input receives the gradient behind the block's final ReLU)
+__global__ __launch_bounds__(256) void rn_add_masked_kernel(float* __restrict__ dst, const float* __restrict__ dy, const float* __restrict__ mask, int64_t n4) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n4) return;
+    const float4 d = reinterpret_cast<const float4*>(dy)[gid], m = reinterpret_cast<const float4*>(mask)[gid];
+    float4 o = reinterpret_cast<float4*>(dst)[gid];
+    o = make_float4(o.x + (m.x > 0.f ? d.x : 0.f), o.y + (m.y > 0.f ? d.y : 0.f), o.z + (m.z > 0.f ? d.z : 0.f), o.w + (m.w > 0.f ? d.w : 0.f));
+    reinterpret_cast<float4*>(dst)[gid] = o;
+}
+int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n) {
+    hipLaunchKernelGGL(rn_add_masked_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, dy, mask, n / 4);
+    return 0;
+}

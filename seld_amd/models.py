@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-SUPPORTED_FIRST = ("simple_conv_block", "xception_block")
+SUPPORTED_FIRST = ("simple_conv_block", "xception_block", "resnet50_block")
 SUPPORTED_SECOND = ("bidirectional_GRU_block",)
 SUPPORTED_HEAD = ("simple_dense_block",)
 
@@ -28,7 +28,13 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
             raise ValueError(f"model_config[{key!r}]={model_config.get(key)!r}: only {ok} has MI355X kernels")
     fa = model_config["FIRST_ARGS"]
     xception = model_config["FIRST"] == "xception_block"
-    if xception:
+    resnet = model_config["FIRST"] == "resnet50_block"
+    if resnet:
+        # model_config/resnet50_gru.json:2-11; absent from the reference snapshot: spec/RESNET50_BLOCK.md is ours
+        if int(fa["filters"]) != 32 or len(fa["block_num"]) != 4:
+            raise ValueError("resnet50_block kernels are built for filters = 32 and four stages")
+        filters, pools = [2 * int(fa["filters"])], [(5, 4)]
+    elif xception:
         # model_config/xception_gru.json:2-11; the block is absent from the reference snapshot: spec/XCEPTION_BLOCK.md is ours
         # (entry conv2d_bn(2 filters) + MaxPool (5,4), block_num residual modules of 3 x [ReLU, SeparableConv2D, BN], ReLU + MaxPool (1,8))
         if int(fa["filters"]) != 32:
@@ -72,8 +78,12 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         a.doa_units[i] = u
     # models.py:19 default 14; train.py:306-307 overrides to 12 before building
     a.n_classes = int(model_config.get("n_classes", 14))
-    a.first_kind = 1 if xception else 0
+    a.first_kind = 2 if resnet else (1 if xception else 0)
     a.xc_blocks = int(fa["block_num"]) if xception else 0
+    if resnet:
+        a.rn_filters = int(fa["filters"])
+        for i, nb in enumerate(fa["block_num"]):
+            a.rn_blocks[i] = int(nb)
     return a
 
 

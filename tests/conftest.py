@@ -46,3 +46,13 @@ def xception_config(seldnet_config):
     cfg["FIRST"] = "xception_block"
     cfg["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
     return cfg
+
+
+@pytest.fixture(scope="session")
+def resnet50_config(seldnet_config):
+    """model_config/resnet50_gru.json of the reference, restated as data (n_classes = 12 as train.py:306-307 forces)."""
+    import copy
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST"] = "resnet50_block"
+    cfg["FIRST_ARGS"] = {"filters": 32, "block_num": [3, 4, 6, 3], "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    return cfg

@@ -47,7 +47,7 @@ def test_unsupported_blocks_raise_value_error():
     import pytest
     from seld_amd import models
     with pytest.raises(ValueError):
-        models._arch_from_config({"FIRST": "resnet50_block", "SECOND": "bidirectional_GRU_block", "SED": "simple_dense_block",
+        models._arch_from_config({"FIRST": "mother_block", "SECOND": "bidirectional_GRU_block", "SED": "simple_dense_block",
                                   "DOA": "simple_dense_block"}, 7, 64)
     with pytest.raises(ValueError):      # xception_block kernels exist for the JSON's width only (spec/XCEPTION_BLOCK.md)
         models._arch_from_config({"FIRST": "xception_block", "FIRST_ARGS": {"filters": 48, "block_num": 8},

@@ -550,3 +550,62 @@ def test_conv1_train_without_pre_bn_tensor(seld_lib, B, H, CIN):
     check(f"z-free dgamma {B,H}", dg.cpu().numpy(), gg.numpy())
     check(f"z-free dbeta {B,H}", dbe.cpu().numpy(), gbe.numpy())
     assert np.abs(db.cpu().numpy()).max() <= 1e-3 * np.abs(gw.numpy()).max()   # exact-arithmetic zero (bias before BN)
+
+
+# ---- resnet50_block pieces (spec/RESNET50_BLOCK.md) at the shapes its stages run them at: B*S*W pixels with W = 16, 8, 4, 2
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,stride_f", [(2, 30, 16, 64, 32, 1, 1), (2, 30, 16, 32, 32, 3, 1), (2, 30, 16, 128, 64, 1, 2),
+                                                           (4, 60, 2, 256, 256, 3, 1), (4, 60, 2, 256, 1024, 1, 1), (4, 60, 4, 512, 1024, 1, 2),
+                                                           (3, 7, 4, 128, 128, 3, 1)])
+def test_rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f):
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((ksize, ksize, Cin, Cout)) / np.sqrt(ksize * ksize * Cin)).astype(np.float32)
+    Wo = W // stride_f
+    dz = rng.standard_normal((B, H, Wo, Cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1).requires_grad_(True)
+    zt = torch.nn.functional.conv2d(xt, wt, stride=(1, stride_f), padding=ksize // 2)
+    zt.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
+    z = torch.full((B, H, Wo, Cout), float("nan"), device="cuda")
+    xd, wd, dzd = dev(x), dev(w), dev(dz)
+    assert seld_lib.seld_k_rn_conv(ptr(xd), ptr(wd), ptr(z), B, H, W, Cin, Cout, ksize, stride_f) == 0
+    check("rn_conv z", z.cpu().numpy(), zt.detach().permute(0, 2, 3, 1).numpy())
+    dw = torch.full((ksize, ksize, Cin, Cout), float("nan"), device="cuda")
+    dx = torch.full((B, H, W, Cin), float("nan"), device="cuda")
+    assert seld_lib.seld_k_rn_conv_bwd(ptr(xd), ptr(wd), ptr(dzd), ptr(dw), ptr(dx), B, H, W, Cin, Cout, ksize, stride_f) == 0
+    check("rn_conv dw", dw.cpu().numpy(), wt.grad.permute(2, 3, 1, 0).numpy())
+    check("rn_conv dx", dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize("npix,C,relu,with_res,with_mask", [(960, 32, 1, 0, 1), (480, 256, 1, 0, 1), (480, 1024, 1, 1, 1), (333, 96, 0, 0, 0),
+                                                            (7680, 64, 1, 1, 1)])
+def test_rn_bn_fwd_bwd(seld_lib, npix, C, relu, with_res, with_mask):
+    """Training-mode BatchNormalization (+ residual, ReLU) of resnet50_block and its backward with the gradient gated by the
+    ReLU's output, against float64 autograd."""
+    rng = np.random.default_rng(32)
+    z = (rng.standard_normal((npix, C)) * rng.uniform(0.5, 2.0, C) + rng.standard_normal(C)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((npix, C)).astype(np.float32) if with_res else None
+    dy = rng.standard_normal((npix, C)).astype(np.float32)
+    zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    gt, bt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True), torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    mean, var = zt.mean(0), zt.var(0, unbiased=False)
+    o = (zt - mean) * torch.rsqrt(var + 1e-3) * gt + bt
+    if with_res:
+        o = o + torch.tensor(res, dtype=torch.float64)
+    if relu:
+        o = torch.relu(o)
+    out = torch.full((npix, C), float("nan"), device="cuda")
+    zd, gd, bd, dyd = dev(z), dev(gamma), dev(beta), dev(dy)
+    rd = dev(res) if with_res else None
+    assert seld_lib.seld_k_rn_bn(ptr(zd), ptr(gd), ptr(bd), ptr(rd) if with_res else None, ptr(out), None, None, npix, C, relu) == 0
+    check("rn_bn out", out.cpu().numpy(), o.detach().numpy())
+    # backward: the product gates dy by (mask > 0) with mask = the layer's output; autograd's ReLU does the same
+    (o * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    dz = torch.full((npix, C), float("nan"), device="cuda")
+    dg, db = torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
+    use_mask = bool(relu and with_mask)
+    assert seld_lib.seld_k_rn_bn_bwd(ptr(zd), ptr(dyd), ptr(out) if use_mask else None, ptr(gd), ptr(dz), ptr(dg), ptr(db), npix, C) == 0
+    check("rn_bn dz", dz.cpu().numpy(), zt.grad.numpy())
+    check("rn_bn dgamma", dg.cpu().numpy(), gt.grad.numpy())
+    check("rn_bn dbeta", db.cpu().numpy(), bt.grad.numpy())
