@@ -90,6 +90,7 @@ struct seld_ctx {
     unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
     unsigned short *wsp_fwd[SELD_MAX_LAYERS] = {}, *wsp_bwd[SELD_MAX_LAYERS] = {};
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
+    bool gru_wgrad_batch = true;           // a GRU layer's four weight-gradient products in one launch (+ one combine)
     bool gram_active = false;              // the last training forward took that path
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
     hipEvent_t ev_gram = nullptr;
@@ -415,7 +416,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->feat_grad, rows * 128);
     for (int i = 0; i < a->n_gru; ++i)
         for (int d = 0; d < 2; ++d) { ALLOC(c->dgx[i][d], rows * 384); ALLOC(c->dgh[i][d], rows * 384); }
-    ALLOC(c->tn_slab_side, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
+    // the side stream's slabs: one 384 x 384 product over gemm_tn_max_splits() splits, or a GRU layer's four 128 x 384 ones
+    ALLOC(c->tn_slab_side, (size_t)gemm_tn_max_splits() * std::max<size_t>(384 * 384 + 384, 4 * (128 * 384 + 384)));
     // lowest priority: the side stream only carries work nobody waits for soon (weight-gradient GEMMs, the patch Gram
     // matrix); whenever the main stream has a kernel ready it should get the CUs
     int prio_lo = 0, prio_hi = 0;
@@ -503,6 +505,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -1052,13 +1055,23 @@ static int backward_impl(seld_ctx* c, const float* x) {
         // weight gradients of this layer: side stream (they overlap with the next layer's BPTT, which uses 2B of the 256 CUs)
         fork_side(c);
         if (i == (int)c->gru.size() - 1 && heads_lin(c)) heads_lin_side(c, rows);
+        TnJobs tj = {};
         for (int d = 0; d < 2; ++d) {
-            // kernel + input bias (bias row 0)
-            wgrad_dense(c, c->side, c->tn_slab_side, lin, G.in_feat, c->dgx[i][d], 384, rows, G.in_feat, 384, G.k_off[d], G.b_off[d], 0, 0);
-            // recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction h[t+1]) + bias row 1
-            wgrad_dense(c, c->side, c->tn_slab_side, G.h[d], 128, c->dgh[i][d], 384, rows, 128, 384, G.u_off[d], G.b_off[d] + 384, S,
-                        d == 0 ? -1 : 1);
+            // kernel + input bias (bias row 0); recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction
+            // h[t+1]) + bias row 1
+            tj.A[2 * d] = lin; tj.lda[2 * d] = G.in_feat; tj.B[2 * d] = c->dgx[i][d]; tj.shift[2 * d] = 0;
+            tj.out_w[2 * d] = c->grads + G.k_off[d]; tj.out_b[2 * d] = c->grads + G.b_off[d];
+            tj.A[2 * d + 1] = G.h[d]; tj.lda[2 * d + 1] = 128; tj.B[2 * d + 1] = c->dgh[i][d]; tj.shift[2 * d + 1] = d == 0 ? -1 : 1;
+            tj.out_w[2 * d + 1] = c->grads + G.u_off[d]; tj.out_b[2 * d + 1] = c->grads + G.b_off[d] + 384;
         }
+        int ns4 = 0;
+        if (c->gru_wgrad_batch && c->gemm_split_bf16 && G.in_feat == 128 && launch_gemm_tn_sb_batch(c->side, tj, 4, 384, c->tn_slab_side, &ns4, rows, 384, S, 1) == 0) {
+            // the layer's four products in one launch, their slabs combined by one more
+            launch_reduce_slabs2_batch(c->side, c->tn_slab_side, ns4, (int64_t)128 * 384 + 384, tj, 4, (int64_t)128 * 384, 384);
+        } else
+            for (int j = 0; j < 4; ++j)
+                wgrad_dense(c, c->side, c->tn_slab_side, tj.A[j], tj.lda[j], tj.B[j], 384, rows, j & 1 ? 128 : G.in_feat, 384,
+                            tj.out_w[j] - c->grads, tj.out_b[j] - c->grads, j & 1 ? S : 0, tj.shift[j]);
         hipEventRecord(c->ev_bucket[(int)c->gru.size() - 1 - i], c->side);   // this layer's (and, for the last layer, the heads') gradients are final
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for

@@ -172,6 +172,17 @@ int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int
                    int M, int K1, int N, int S, int shift, int want_bias, int max_splits = 0);
 // split-bf16 form with transposed LDS reads (gemm_tn_sb.hip): K1 = 128, N % 128 == 0; same slabs as launch_gemm_tn
 int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N);
+// several products of one shape in one launch (+ one combine launch): job j's slabs follow job j-1's (nslab each)
+#define TN_MAX_JOBS 4
+struct TnJobs {
+    const float* A[TN_MAX_JOBS];
+    const float* B[TN_MAX_JOBS];
+    int lda[TN_MAX_JOBS], shift[TN_MAX_JOBS];
+    float* out_w[TN_MAX_JOBS];      // combine targets (launch_reduce_slabs2_batch)
+    float* out_b[TN_MAX_JOBS];
+};
+int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int ldb, float* slab, int* nslab, int M, int N, int S, int want_bias);
+int launch_reduce_slabs2_batch(hipStream_t st, const float* slab, int nslab, int64_t stride, const TnJobs& jobs, int njobs, int64_t n_w, int64_t n_b);
 int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,
                       int shift, int want_bias);
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,

@@ -486,6 +486,33 @@ __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* __restr
     }
 }
 
+// the same for the jobs of launch_gemm_tn_sb_batch: blockIdx.y = job
+__global__ __launch_bounds__(256) void reduce_slabs2_batch_kernel(const float* __restrict__ slab, int nslab, int64_t stride, TnJobs jobs,
+                                                                  int64_t n_w, int64_t n_b) {
+    __shared__ double red[256];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
+    const int64_t n = n_w + n_b;
+    const float* src = slab + (size_t)blockIdx.y * nslab * stride;
+    double s = 0.0;
+    if (i < n)
+        for (int z = g; z < nslab; z += 8) s += (double)src[(size_t)z * stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + o];
+        if (i < n_w) jobs.out_w[blockIdx.y][i] = (float)t;
+        else jobs.out_b[blockIdx.y][i - n_w] = (float)t;
+    }
+}
+int launch_reduce_slabs2_batch(hipStream_t st, const float* slab, int nslab, int64_t stride, const TnJobs& jobs, int njobs, int64_t n_w, int64_t n_b) {
+    const int64_t n = n_w + n_b;
+    hipLaunchKernelGGL(reduce_slabs2_batch_kernel, dim3((unsigned)((n + 31) / 32), njobs), dim3(256), 0, st, slab, nslab, stride, jobs, n_w, n_b);
+    return 0;
+}
+
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b) {
     const int64_t n = n_w + n_b;

@@ -32,9 +32,13 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 
 #define TNSB_PL (32 * 256)     // bytes per plane: 32 rows x 128 bf16
 
-__global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                            float* __restrict__ slab, int M, int N, int rows_per_split, int S,
-                                                            int shift, int want_bias) {
+// blockIdx.y = job: up to TN_MAX_JOBS products of one shape (the four weight gradients of a GRU layer) in one launch; job j's slabs
+// follow job j-1's (gridDim.z slabs each)
+__global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
+                                                            int S, int want_bias) {
+    const float* __restrict__ A = jobs.A[blockIdx.y];
+    const float* __restrict__ Bm = jobs.B[blockIdx.y];
+    const int lda = jobs.lda[blockIdx.y], shift = jobs.shift[blockIdx.y];
     __shared__ __attribute__((aligned(16))) char Al[3 * TNSB_PL];
     __shared__ __attribute__((aligned(16))) char Bl[3 * TNSB_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(const float* __restr
 #undef TNSB_COMMIT
 #undef TNSB_PUT
 #undef TNSB_LOAD
-    float* out = slab + (size_t)blockIdx.z * ((size_t)128 * N + N);
+    float* out = slab + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)128 * N + N);
     const int li = lane & 31;
 #define TNSB_OUT(ACC_, kt_, nt_)                                                                      \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                    \
@@ -147,16 +151,22 @@ int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, i
     return K1 == 128 && (N % 128) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
 }
-int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,
-                      int shift, int want_bias) {
-    if (M <= 0 || !gemm_tn_sb_usable(A, lda, Bm, ldb, 128, N)) return -1;
+int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int ldb, float* slab, int* nslab, int M, int N, int S, int want_bias) {
+    if (M <= 0 || njobs < 1 || njobs > TN_MAX_JOBS) return -1;
+    for (int j = 0; j < njobs; ++j)
+        if (!gemm_tn_sb_usable(jobs.A[j], jobs.lda[j], jobs.B[j], ldb, 128, N)) return -1;
     int splits = (M + 159) / 160;
     if (splits > gemm_tn_max_splits()) splits = gemm_tn_max_splits();
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, 1, splits), dim3(256), 0, st, A, lda, Bm, ldb, slab, M, N, rps, S > 0 ? S : M,
-                       shift, want_bias);
+    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias);
     *nslab = splits;
     return 0;
+}
+int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,
+                      int shift, int want_bias) {
+    TnJobs jobs = {};
+    jobs.A[0] = A; jobs.B[0] = Bm; jobs.lda[0] = lda; jobs.shift[0] = shift;
+    return launch_gemm_tn_sb_batch(st, jobs, 1, ldb, slab, nslab, M, N, S, want_bias);
 }
