@@ -18,6 +18,27 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
 }
+// ---- MFMA 32x32 accumulator tile -> float4 stores.  A lane of the accumulator layout holds ONE output channel (column) of 16
+// pixels; stored as it stands that is 16 dword stores per tile, and a conv epilogue of 64 - 128 dword stores per wave was measured at
+// a quarter of the kernel (tools/tune_conv64.py: the same bytes as dwordx4 stores cost an eighth of that).  A 4 x 4 transpose inside
+// each quad of lanes (two DPP butterfly stages) turns registers 4q..4q+3 (pixels 8q + 4hi + 0..3, channel li) into pixel 8q + 4hi +
+// (li & 3), channels 4 (li >> 2) .. + 3: one float4.
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float4 quad_transpose4(float x0, float x1, float x2, float x3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float r;
+    r = dpp_quad_xor1(b0 ? x0 : x1); if (b0) x0 = r; else x1 = r;
+    r = dpp_quad_xor1(b0 ? x2 : x3); if (b0) x2 = r; else x3 = r;
+    r = dpp_quad_xor2(b1 ? x0 : x2); if (b1) x0 = r; else x2 = r;
+    r = dpp_quad_xor2(b1 ? x1 : x3); if (b1) x1 = r; else x3 = r;
+    return make_float4(x0, x1, x2, x3);
+}
+
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (it is a
 // workgroup-scope fence for global memory), which would serialise the prefetched global loads and the

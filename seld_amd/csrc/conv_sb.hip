@@ -598,19 +598,27 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
             wb ^= 1;
         }
         SBD_COMMIT_REGION()     // next tile's region (every wave passed the barrier after tap 8's reads)
+        // statistics in the accumulator layout (a lane = one channel), then a 4 x 4 transpose inside each quad of lanes so that the
+        // tile leaves as 8 dwordx4 stores per wave instead of 64 dword stores (common.h: quad_transpose4)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float bv = bias ? bias[c * 32 + li] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = wave * 32 + mfma_row(r, hi);          // pixel of the tile
-                const int t = t0 + (p >> WLOG2);
-                if (t < H) {
-                    const float v = (acc[c][r] + accs[c][r]) + bv;
-                    z[((size_t)(b * H + t) * W + (p & (W - 1))) * 64 + c * 32 + li] = v;
-                    s1[c] += v;
-                    s2[c] = fmaf(v, v, s2[c]);
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = (acc[c][4 * q + j] + accs[c][4 * q + j]) + bv;
+                    const int t = t0 + ((wave * 32 + 8 * q + 4 * hi + j) >> WLOG2);
+                    if (t < H) {
+                        s1[c] += v[j];
+                        s2[c] = fmaf(v[j], v[j], s2[c]);
+                    }
                 }
+                const float4 o = quad_transpose4(v[0], v[1], v[2], v[3], li);
+                const int p = wave * 32 + 8 * q + 4 * hi + (li & 3);      // pixel of the tile this lane stores
+                const int t = t0 + (p >> WLOG2);
+                if (t < H) *reinterpret_cast<float4*>(z + ((size_t)(b * H + t) * W + (p & (W - 1))) * 64 + c * 32 + (li & ~3)) = o;
             }
         }
         lds_barrier();          // the committed region is visible to every wave

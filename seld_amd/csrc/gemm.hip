@@ -142,6 +142,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #undef GEMM_LOAD
 #undef GEMM_COMMIT
     const int col = n0 + wc * 32 + li;
+    if ((mode == 0 || mode == 3) && m0 + wr * 32 + 32 <= M && n0 + wc * 32 + 32 <= N && (ldc & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (mode == 0 || (reinterpret_cast<uintptr_t>(C1) & 15) == 0)) {
+        // whole 32 x 32 tile: 4 dwordx4 stores per wave instead of 16 dword stores (common.h: quad_transpose4)
+        const float bv = bias ? bias[col] : 0.f;
+        const size_t o0 = (size_t)(m0 + wr * 32 + 4 * hi + (li & 3)) * ldc + n0 + wc * 32 + (li & ~3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v_[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v_[j] = (acc[4 * q + j] + acc1[4 * q + j]) + bv;
+                if (act == 1) v_[j] = 1.f / (1.f + expf(-v_[j]));
+                else if (act == 2) v_[j] = tanhf(v_[j]);
+            }
+            float4 o = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
+            float4* p = reinterpret_cast<float4*>(C + o0 + (size_t)(8 * q) * ldc);
+            if (accumulate) { const float4 c0 = *p; o = make_float4(o.x + c0.x, o.y + c0.y, o.z + c0.z, o.w + c0.w); }
+            *p = o;
+            if (mode == 3) *reinterpret_cast<float4*>(C1 + o0 + (size_t)(8 * q) * ldc) = o;
+        }
+        return;
+    }
     if (col < N) {
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -385,6 +407,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     float* out = slab + (size_t)blockIdx.z * ((size_t)K1 * N + N);
     if (do_bias && n0 + tid < N) out[(size_t)K1 * N + n0 + tid] = bsum;
     const int col = n0 + wc * 32 + li;
+    if (k10 + wr * 32 + 32 <= K1 && n0 + wc * 32 + 32 <= N && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        // whole tile: 4 dwordx4 stores (common.h: quad_transpose4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(out + (size_t)(k10 + wr * 32 + 8 * q + 4 * hi + (li & 3)) * N + n0 + wc * 32 + (li & ~3)) =
+                quad_transpose4(acc[4 * q] + acc1[4 * q], acc[4 * q + 1] + acc1[4 * q + 1], acc[4 * q + 2] + acc1[4 * q + 2],
+                                acc[4 * q + 3] + acc1[4 * q + 3], li);
+        return;
+    }
     if (col < N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
     const float bv0 = bias ? bias[n0 + li] : 0.f, bv1 = bias ? bias[n0 + 32 + li] : 0.f, bv2 = bias ? bias[n0 + 64 + li] : 0.f,
                 bv3 = bias ? bias[n0 + 96 + li] : 0.f;
     if (dbg & 2) return;
+    const bool full = m0 + 32 <= M;   // wave-uniform: every block but the last takes the unguarded stores
     float* crow = C + (size_t)(m0 + 4 * kg) * ldc + n0 + li;
     const int rows_left = M - m0 - 4 * kg;   // rows of this lane's stripe that exist
 #define GSB_STORE(ACC_, nt_, BV_)                                                            \
@@ -207,7 +208,6 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
         else if (act == 2) v = tanhf(v);                                                     \
         if (full || dr < rows_left) crow[(size_t)dr * ldc + (nt_) * 32] = v;                 \
     }
-    const bool full = m0 + 32 <= M;   // wave-uniform: every block but the last takes the unguarded stores
     if (act == 0 && full) {
 #define GSB_STORE_PLAIN(ACC_, nt_, BV_)                                                      \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * ldc + (nt_) * 32] = ACC_[r] + BV_;
@@ -341,6 +341,22 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     const int rbase = m0 + wr * 32 + 4 * kg;
     float* crow = C + (size_t)rbase * ldc + col;
     const int rows_left = M - rbase;
+    if (m0 + wr * 32 + 32 <= M && ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
+        // 4 dwordx4 stores per wave instead of 16 dword stores (common.h: quad_transpose4)
+        float* cq = C + (size_t)(rbase + (li & 3)) * ldc + n0 + wc * 32 + (li & ~3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v_[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v_[j] = (acc0[4 * q + j] + acc1[4 * q + j]) + bv;
+                if (act == 1) v_[j] = 1.f / (1.f + expf(-v_[j]));
+                else if (act == 2) v_[j] = tanhf(v_[j]);
+            }
+            *reinterpret_cast<float4*>(cq + (size_t)(8 * q) * ldc) = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);

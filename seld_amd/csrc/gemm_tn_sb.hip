@@ -127,9 +127,11 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
 #undef TNSB_LOAD
     float* out = slab + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)128 * N + N);
     const int li = lane & 31;
+    // 4 dwordx4 stores per accumulator tile (common.h: quad_transpose4): row 8 q + 4 kg + (li & 3), columns 4 (li >> 2) .. + 3
 #define TNSB_OUT(ACC_, kt_, nt_)                                                                      \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                    \
-        out[(size_t)(64 * kh + 32 * (kt_) + mfma_row(r, kg)) * N + n0 + 64 * nh + 32 * (nt_) + li] = ACC_[r];
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
+        *reinterpret_cast<float4*>(out + (size_t)(64 * kh + 32 * (kt_) + 8 * q + 4 * kg + (li & 3)) * N + n0 + 64 * nh + 32 * (nt_) + (li & ~3)) = \
+            quad_transpose4(ACC_[4 * q], ACC_[4 * q + 1], ACC_[4 * q + 2], ACC_[4 * q + 3], li);
     TNSB_OUT(c00, 0, 0) TNSB_OUT(c01, 0, 1) TNSB_OUT(c10, 1, 0) TNSB_OUT(c11, 1, 1)
 #undef TNSB_OUT
     if (want_bias) {      // colsum(B): 8 row groups x 32 float4 columns -> fixed-order sum through LDS
