@@ -1,0 +1,104 @@
+"""Data-parallel HIP path with more than one rank: two PROCESSES on the one test GPU, torch.distributed over gloo (RCCL refuses two
+ranks on one device; gloo carries device tensors through the host), each driving the real library — seld_train_fwd_bwd, the
+bucketed gradient all-reduce of seld_amd.parallel (seld_grads_bucket_ready events, communication stream), the MMSE denominator
+all-reduce, the synchronised-BatchNorm callback, seld_adam_step — through train.trainstep exactly as bench.py and train.main do.
+The updated weights of both ranks must be identical and equal the oracle's single-process step on the whole batch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import check
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, mode, sync_bn, B, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import SELDNET_CONFIG
+        from seld_amd import losses, models, parallel, train
+        from seld_amd.synthetic import synthetic_batch
+        from oracle import seldnet_oracle as O          # weights only: the gradient engine is the HIP library
+        spec = O.Spec.from_config(SELDNET_CONFIG)
+        w, st = O.random_weights(spec, 0)
+        x, ys, yd = synthetic_batch(B, T, seed=77)
+        per = B // world
+        sl = slice(rank * per, (rank + 1) * per)
+        model = models.seldnet((per, T, 64, 7), SELDNET_CONFIG)
+        model.set_weights(w, st)
+        if sync_bn:
+            parallel.enable_sync_batchnorm(model)
+        doa = losses.MSE if mode == "MSE" else losses.MMSE
+        y_p, sl_, dl_ = train.trainstep(model, x[sl], (ys[sl], yd[sl]), losses.BinaryCrossentropy(), doa, (1.0, 1000.0), train.Adam(1e-3))
+        torch.cuda.synchronize()
+        w1, st1 = model.get_weights()
+        q.put((rank, w1, st1, model.get_grads(), y_p[0].cpu().numpy(), y_p[1].cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,sync_bn", [("MSE", True), ("MMSE", True), ("MSE", False)])
+def test_two_process_dp_step_equals_single_process_batch(mode, sync_bn):
+    from __graft_entry__ import SELDNET_CONFIG
+    from oracle import seldnet_oracle as O
+    world, B, T = 2, 4, 100
+    port = 30100 + (os.getpid() % 400) + 400 * (["MSE", "MMSE"].index(mode) + 2 * int(sync_bn))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, sync_bn, B, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # both ranks hold the same all-reduced gradient and hence the same updated weights
+    np.testing.assert_array_equal(got[0][2], got[1][2])
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    spec = O.Spec.from_config(SELDNET_CONFIG)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T, seed=77)
+    sed = np.concatenate([got[r][3] for r in range(world)])
+    doa = np.concatenate([got[r][4] for r in range(world)])
+    if sync_bn:
+        # synchronised BatchNorm: the two half-batches ARE the single-device batch of B (layers.py:33)
+        ref = O.train_step(spec, w, st, x, ys, yd, doa_loss=mode, loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+        check(f"dp2 {mode} sed", sed, ref["sed"])
+        check(f"dp2 {mode} doa", doa, ref["doa"])
+        tr, _ = O.variable_specs(spec)
+        off = 0
+        for name, shape in tr:
+            n = int(np.prod(shape))
+            if not (name.startswith("conv") and name.endswith("bias")):
+                check(f"dp2 {mode} all-reduced grad {name}", got[0][2][off:off + n], ref["grad"][off:off + n])
+            off += n
+        check(f"dp2 {mode} BN moving stats", got[0][1], ref["new_state"])
+        # Adam at step 1 moves every weight by lr * g / (|g| + eps): compare where the gradient is resolved
+        big = np.abs(ref["grad"]) > 1e-3 * np.abs(ref["grad"]).max()
+        assert np.abs(got[0][0] - ref["new_w"])[big].max() <= 2e-3 * 1e-3 + 1e-7
+    else:
+        # per-replica statistics (the documented default): the summed gradient is the gradient of the global objective with each
+        # half normalised by its own statistics — the oracle evaluated that way
+        tr, nt = O.variable_specs(spec)
+        fw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        wd, sd = O.unflatten(fw, tr), O.unflatten(torch.tensor(st, dtype=torch.float64), nt)
+        per = B // world
+        outs = [O.forward(spec, wd, sd, torch.tensor(x[r * per:(r + 1) * per], dtype=torch.float64), True) for r in range(world)]
+        s_, d_ = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        obj, _, _ = O.losses_and_objective(s_, d_, torch.tensor(ys, dtype=torch.float64), torch.tensor(yd, dtype=torch.float64), mode, (1.0, 1000.0))
+        (g,) = torch.autograd.grad(obj, fw)
+        off = 0
+        for name, shape in tr:
+            n = int(np.prod(shape))
+            if not (name.startswith("conv") and name.endswith("bias")):
+                check(f"dp2 per-replica BN grad {name}", got[0][2][off:off + n], g.numpy()[off:off + n])
+            off += n
