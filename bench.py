@@ -68,8 +68,9 @@ def kernel_work(name, B, T, F=64, C=7):
         "gru_bwd": ("hbm", 2 * 4 * rows * (128 + 128 + 512 + 128 + 768)),
         "gru_inproj_gemm": ("mfma", 2 * 2 * rows * 128 * 384),
         "gru_bwd_gemms": ("mfma", 2 * 2 * rows * 128 * 384),   # main stream: the two input-gradient GEMMs of a layer
-        # reference op count (two Dense layers per head); the default build computes them as one 48-column product (heads_fused)
-        "heads_fwd": ("mfma", 2 * rows * (2 * 128 * 128 + 128 * 48)), "heads_bwd": ("mfma", 2 * 2 * rows * (2 * 128 * 128 + 128 * 48)),
+        # the default build computes both heads as ONE 48-column product with W1 W2 pre-multiplied (heads_fused): what is timed on the main
+        # stream is rows x 128 x 48 forward and the same again for the input gradient (the weight gradients run on the side stream)
+        "heads_fwd": ("mfma", 2 * rows * 128 * 48), "heads_bwd": ("mfma", 2 * rows * 128 * 48),
         "adam": ("hbm", 4 * 7 * N_PARAMS),
         # xception_block middle flow (spec/XCEPTION_BLOCK.md), per launch group on [B,S,16,64]: depthwise 3x3 = read + write the
         # tensor; pointwise 64 x 64 product; BatchNorm passes
