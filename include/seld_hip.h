@@ -34,6 +34,8 @@ extern "C" {
 
 #define SELD_DOA_MSE 0  /* tf.keras.losses.MSE function form (train.py:317-320): [B,S] rows, tape sums them */
 #define SELD_DOA_MMSE 1 /* losses.MMSE (losses.py:4-13) */
+#define SELD_DOA_MAE 2  /* tf.keras.losses.MAE function form (params.py:16-17 choice 'MAE', train.py:317-318) */
+#define SELD_DOA_MSLE 3 /* tf.keras.losses.MSLE function form (choice 'MSLE'): mean((log(max(p,1e-7)+1) - log(max(y,1e-7)+1))^2) */
 
 #define SELD_MAX_LAYERS 4
 
@@ -72,7 +74,7 @@ typedef struct seld_arch {
 
 /* Loss configuration = train.py:311-320 + the `loss_weight` flag (params.py:30). */
 typedef struct seld_loss_cfg {
-    int32_t doa_loss;        /* SELD_DOA_MSE | SELD_DOA_MMSE */
+    int32_t doa_loss;        /* SELD_DOA_MSE | SELD_DOA_MMSE | SELD_DOA_MAE | SELD_DOA_MSLE */
     float w_sed, w_doa;      /* loss_weight "1,1000" */
     float sed_grad_scale;    /* 1 on a single device; 1/world for data parallel MMSE runs */
     float mmse_den;          /* <=0: sum(mask) of this batch; >0: all-reduced global denominator */

@@ -412,6 +412,11 @@ def losses_and_objective(sed, doa, y_sed, y_doa, doa_loss: str, loss_weight):
     sloss = bce(y_sed, sed)
     if doa_loss == "MSE":
         dloss = keras_mse_fn(y_doa, doa)
+    elif doa_loss == "MAE":       # tf.keras.losses.MAE function (train.py:317-318 with --doa_loss MAE): mean over the last axis
+        dloss = (y_doa - doa).abs().mean(dim=-1)
+    elif doa_loss == "MSLE":      # tf.keras.losses.MSLE function: log(max(., epsilon()) + 1), epsilon() = 1e-7
+        eps = torch.tensor(1e-7, dtype=doa.dtype)
+        dloss = ((torch.log(torch.maximum(doa, eps) + 1.0) - torch.log(torch.maximum(y_doa, eps) + 1.0)) ** 2).mean(dim=-1)
     elif doa_loss == "MMSE":
         dloss = mmse(y_doa, doa)
     else:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SELD_HIP_LIB") or os.path.join(_HERE, "libseld_hip.so
 CSRC = os.path.join(_HERE, "csrc")
 
 SELD_OK = 0
-SELD_DOA_MSE, SELD_DOA_MMSE = 0, 1
+SELD_DOA_MSE, SELD_DOA_MMSE, SELD_DOA_MAE, SELD_DOA_MSLE = 0, 1, 2, 3
 SELD_DTYPE_F32 = 0
 SELD_DTYPE_F64 = 1
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # seld_allreduce_fn

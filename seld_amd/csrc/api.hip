@@ -897,7 +897,7 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
                       float* dloss, bool want_grads, bool defer_finalize = false) {
     hipStream_t st = c->stream;
     const int rows = c->B * c->S, nc = c->arch.n_classes;
-    if (cfg->doa_loss != SELD_DOA_MSE && cfg->doa_loss != SELD_DOA_MMSE) return fail(c, SELD_ERR_INVALID, "bad doa_loss");
+    if (cfg->doa_loss < SELD_DOA_MSE || cfg->doa_loss > SELD_DOA_MSLE) return fail(c, SELD_ERR_INVALID, "bad doa_loss");
     if (cfg->doa_loss == SELD_DOA_MMSE) {
         if (cfg->mmse_den > 0.f) {
             if (hipMemcpyAsync(c->den_dev, &cfg->mmse_den, 4, hipMemcpyHostToDevice, st) != hipSuccess)

@@ -1,5 +1,5 @@
 // loss_adam.hip — fused losses + optimizer of train.trainstep (train.py:22-36).
-//   losses_kernel   BinaryCrossentropy (train.py:312-313) + tf.keras.losses.MSE function form
+//   losses_kernel   BinaryCrossentropy (train.py:312-313) + tf.keras.losses.MSE / MAE / MSLE function form
 //                   (train.py:317-320; [B,S] rows that tape.gradient SUMS) or
 //                   losses.MMSE (losses.py:4-13): loss values and the gradients w.r.t. the
 //                   PRE-activation head outputs (sigmoid / tanh derivatives folded in).
@@ -90,12 +90,31 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ s
     const float* d = doa + (size_t)r * 3 * nc;
     const float* yd = y_doa + (size_t)r * 3 * nc;
     float dsum = 0.f;
-    if (doa_loss == 0) {
+    if (doa_loss != 1) {
+        // the Keras loss FUNCTIONS (mean over the last axis -> one value per row): MSE, MAE (mean |y - p|), MSLE (mean of the squared
+        // difference of log(max(., 1e-7) + 1); keras/losses.py mean_squared_logarithmic_error).  Gradients as tape.gradient forms
+        // them: d|e| = sign(e) (0 at e = 0), maximum() passes the gradient to the larger argument (half each on a tie)
         const float inv = 1.f / (float)(3 * nc);
         for (int k = q; k < 3 * nc; k += 4) {
-            const float e = yd[k] - d[k];
-            dsum += e * e;
-            if (ddoa_pre && live) ddoa_pre[(size_t)r * ld_doa + k] = w_doa * (-2.f * e * inv) * (1.f - d[k] * d[k]);
+            const float pk = d[k], yk = yd[k];
+            float term, dldp;
+            if (doa_loss == 0) {
+                const float e = yk - pk;
+                term = e * e;
+                dldp = -2.f * e;
+            } else if (doa_loss == 2) {
+                const float e = pk - yk;
+                term = fabsf(e);
+                dldp = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+            } else {
+                const float lp = logf(fmaxf(pk, BCE_EPS) + 1.f), ly = logf(fmaxf(yk, BCE_EPS) + 1.f);
+                const float e = lp - ly;
+                term = e * e;
+                const float pass = pk > BCE_EPS ? 1.f : (pk == BCE_EPS ? 0.5f : 0.f);
+                dldp = 2.f * e * pass / (fmaxf(pk, BCE_EPS) + 1.f);
+            }
+            dsum += term;
+            if (ddoa_pre && live) ddoa_pre[(size_t)r * ld_doa + k] = w_doa * (dldp * inv) * (1.f - pk * pk);
         }
         dsum = loss_quad_sum(dsum) * inv;
         if (dloss_rows && live && q == 0) dloss_rows[r] = dsum;
@@ -147,11 +166,11 @@ int launch_losses(hipStream_t st, const float* sed, const float* doa, const floa
     const int rows = B * S;
     // BCE is a mean over rows*nc elements.  With the Keras MSE *function* the per-row loss tensor
     // sloss*w0 + mse[b,s]*w1 is summed by tape.gradient, which multiplies the BCE term by rows.
-    const float coef_sed = w_sed * sed_grad_scale * (doa_loss == 0 ? (float)rows : 1.f) / ((float)rows * (float)nc);
+    const float coef_sed = w_sed * sed_grad_scale * (doa_loss != 1 ? (float)rows : 1.f) / ((float)rows * (float)nc);
     double* blockpart = reinterpret_cast<double*>(scratch);      // [nblocks][2]: rows / 32 doubles of the 2 * rows floats
     const int nblocks = (rows + 63) / 64;
     hipLaunchKernelGGL(losses_kernel, dim3(nblocks), dim3(256), 0, st, sed, doa, y_sed, y_doa, doa_loss, coef_sed, w_doa, den_dev,
-                       doa_loss == 0 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc, ld_sed, ld_doa);
+                       doa_loss != 1 ? dloss : nullptr, dsed_pre, ddoa_pre, blockpart, rows, nc, ld_sed, ld_doa);
     if (!defer_finalize) launch_losses_finalize(st, doa_loss, den_dev, sloss, dloss, scratch, B, S, nc);
     return 0;
 }

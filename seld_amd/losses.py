@@ -33,13 +33,28 @@ class _MMSE(_Loss):
     code = _lib.SELD_DOA_MMSE
 
 
+class _MAE(_MSE):
+    """tf.keras.losses.MAE *function* (`--doa_loss MAE`, params.py:16-17): mean |y - p| over the last axis -> [B,S], summed by
+    tape.gradient like MSE."""
+    name = "MAE"
+    code = _lib.SELD_DOA_MAE
+
+
+class _MSLE(_MSE):
+    """tf.keras.losses.MSLE *function* (`--doa_loss MSLE`): mean over the last axis of (log(max(p, 1e-7) + 1) - log(max(y, 1e-7) + 1))^2."""
+    name = "MSLE"
+    code = _lib.SELD_DOA_MSLE
+
+
 MSE = _MSE()
 MMSE = _MMSE()
+MAE = _MAE()
+MSLE = _MSLE()
 
 
 def get_doa_loss(name: str):
     """`getattr(tf.keras.losses, config.doa_loss)` / `getattr(losses, ...)` (train.py:317-320)."""
-    table = {"MSE": MSE, "MMSE": MMSE}
+    table = {"MSE": MSE, "MMSE": MMSE, "MAE": MAE, "MSLE": MSLE}
     if name not in table:
         raise ValueError(f"doa_loss {name!r} has no MI355X kernel (built: {sorted(table)})")
     return table[name]

@@ -59,10 +59,10 @@ def get_param(known=None, model_config_dir: str = './model_config'):
     with open(path, 'rb') as f:
         model_config = json.load(f)
     config.name = f'{config.model}_{model_config_name}_{config.doa_loss}_{config.name}_v_0'
-    if config.doa_loss not in ('MSE', 'MMSE'):
-        raise ValueError(f'--doa_loss {config.doa_loss} has no MI355X kernel (built: MSE, MMSE)')
     if config.sed_loss != 'BCE':
-        raise ValueError('--sed_loss FOCAL has no MI355X kernel (built: BCE)')
+        # the reference cannot run it either: train.py:314-315 builds losses.Focal_Loss(alpha=focal_g, gamma=focal_a), an object with
+        # a .call method but no __call__ (losses.py:38-48), and trainstep calls sed_loss(y, p) (train.py:26) -> TypeError
+        raise ValueError('--sed_loss FOCAL has no MI355X kernel (built: BCE); the reference raises on it too (Focal_Loss is not callable)')
     if config.use_tdm:
         raise ValueError('--use_tdm: time-domain mixing works on raw wavs outside the accelerated path (SURVEY.md §2); '
                          '--use_tfm and --use_acs run on the device')

@@ -20,7 +20,7 @@ class Adam:
 
 def _cfg(doa_loss, loss_weight: Sequence[float], sed_grad_scale: float = 1.0, mmse_den: float = 0.0) -> _lib.LossCfg:
     if not isinstance(doa_loss, (losses._MSE, losses._MMSE)):
-        raise ValueError("doa_loss must be seld_amd.losses.MSE or .MMSE")
+        raise ValueError("doa_loss must be seld_amd.losses.MSE, .MAE, .MSLE or .MMSE")
     return _lib.LossCfg(doa_loss.code, float(loss_weight[0]), float(loss_weight[1]), float(sed_grad_scale), float(mmse_den))
 
 

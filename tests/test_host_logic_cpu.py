@@ -21,8 +21,10 @@ def test_get_param_defaults_match_reference(tmp_path, seldnet_config):
     assert config.name == "seldnet_seldnet_MSE_x_v_0" and mc["FIRST"] == "simple_conv_block"
     with pytest.raises(ValueError):
         params.get_param(["--name", "x", "--model", "nope"], model_config_dir=str(d))
-    with pytest.raises(ValueError):
-        params.get_param(["--name", "x", "--doa_loss", "MAE"], model_config_dir=str(d))
+    for dl in ("MAE", "MSLE", "MMSE"):        # every --doa_loss choice of params.py:16-17 has a kernel
+        assert params.get_param(["--name", "x", "--doa_loss", dl], model_config_dir=str(d))[0].doa_loss == dl
+    with pytest.raises(ValueError):           # FOCAL: the reference builds a non-callable Focal_Loss (train.py:314-315, losses.py:38-48)
+        params.get_param(["--name", "x", "--sed_loss", "FOCAL"], model_config_dir=str(d))
     assert params.get_param(["--name", "x", "--agc", "False"], model_config_dir=str(d))[0].agc is True   # type=bool quirk
     # augmentation flags: masks and foa swapping run on the device; time-domain mixing is refused loudly
     cfg = params.get_param(["--name", "x", "--use_tfm", "--use_acs"], model_config_dir=str(d))[0]

@@ -365,7 +365,7 @@ def test_gru_fwd_bwd(seld_lib, B, S):
         check(f"gru_bwd dbrec dir{dirn}", g.sum(axis=(0, 1)), gb.numpy())
 
 
-@pytest.mark.parametrize("mode", ["MSE", "MMSE"])
+@pytest.mark.parametrize("mode", ["MSE", "MMSE", "MAE", "MSLE"])
 def test_losses(seld_lib, mode):
     import sys, os
     from seld_amd import _lib
@@ -382,11 +382,11 @@ def test_losses(seld_lib, mode):
     lw = (1.0, 1000.0)
     obj, sl, dl = O.losses_and_objective(sed, doa, torch.as_tensor(ys, dtype=torch.float64), torch.as_tensor(yd, dtype=torch.float64), mode, lw)
     gs, gd = torch.autograd.grad(obj, (tsp, tdp))
-    cfg = _lib.LossCfg(0 if mode == "MSE" else 1, lw[0], lw[1], 1.0, 0.0)
+    cfg = _lib.LossCfg({"MSE": 0, "MMSE": 1, "MAE": 2, "MSLE": 3}[mode], lw[0], lw[1], 1.0, 0.0)
     sedd, doad = dev(sed.detach().numpy()), dev(doa.detach().numpy())
     ysd, ydd = dev(ys), dev(yd)
     sl_d = torch.full((1,), float("nan"), device="cuda")
-    dl_d = torch.full((B * S if mode == "MSE" else 1,), float("nan"), device="cuda")
+    dl_d = torch.full((B * S if mode != "MMSE" else 1,), float("nan"), device="cuda")
     gsd, gdd = torch.full((B, S, nc), float("nan"), device="cuda"), torch.full((B, S, 3 * nc), float("nan"), device="cuda")
     assert seld_lib.seld_k_losses(ptr(sedd), ptr(doad), ptr(ysd), ptr(ydd), C.byref(cfg), ptr(sl_d), ptr(dl_d), ptr(gsd), ptr(gdd), B, S, nc) == 0
     check(f"losses sloss {mode}", sl_d.cpu().numpy(), sl.detach().numpy().reshape(1))

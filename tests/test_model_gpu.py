@@ -53,6 +53,7 @@ def test_forward_inference(seldnet_config, B, T):
 
 
 @pytest.mark.parametrize("B,T,doa_loss,opts", [(2, 50, "MSE", {}), (2, 50, "MMSE", {}), (3, 100, "MSE", {}),
+                                               (2, 50, "MAE", {}), (3, 100, "MSLE", {}),                  # the other two --doa_loss choices (params.py:16-17)
                                                (3, 100, "MSE", {"conv1_gram": 0}),                        # first block through the stored pre-BN tensor
                                                (2, 50, "MSE", {"conv1_gram": 0, "conv1_pool_fused": 0}),   # ... and the unfused pooling
                                                (2, 50, "MSE", {"conv64_split_bf16": 0}),                   # fp32-MFMA 64->64 convs
