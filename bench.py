@@ -170,29 +170,36 @@ def box_peaks(lib, dev_index):
 def features_leg(dev, clips=8, reps=6):
     """The on-device feature stage (feature_extractor.extract_features, feature_extractor.py:53-88) on 60-s FOA clips
     [4, 1 440 000] -> [3001, 64, 7]: clips/s and the achieved ALGORITHMIC HBM rate (23 040 000 B of wav in +
-    5 376 000 B of features out = 28 416 000 B per clip) of the extraction launches, timed with HIP events on their stream."""
+    5 376 000 B of features out = 28 416 000 B per clip) of the extraction launches, timed with HIP events on their stream.  The
+    clips go through `FeatureExtractor.batch` (one pair of launches for the batch of `clips` resident clips, each clip clamped by its
+    own maximum) — what a loader preprocessing a list of files does; the clip-by-clip rate is reported beside it."""
     from seld_amd import feature_extractor as FE
     n = 1440000
     rng = np.random.default_rng(0)
-    wavs = [torch.as_tensor((rng.standard_normal((4, n)) * 0.1).astype(np.float32)).to(dev) for _ in range(clips)]
+    wavs = torch.as_tensor((rng.standard_normal((clips, 4, n)) * 0.1).astype(np.float32)).to(dev)
     fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=dev.index)
     st = torch.cuda.current_stream(dev)
-    for wv in wavs[:2]:
-        fx(wv)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st.synchronize()
-    e0.record(st)           # the extraction launches go to torch's current stream (FeatureExtractor.__call__)
-    for _ in range(reps):
-        for wv in wavs:
-            out = fx(wv)
-    e1.record(st)
-    st.synchronize()
-    per = e0.elapsed_time(e1) / 1e3 / (reps * clips)
+
+    def timed(fn, per_call):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.synchronize()
+        e0.record(st)           # the extraction launches go to torch's current stream (FeatureExtractor.__call__ / .batch)
+        for _ in range(reps):
+            out = fn()
+        e1.record(st)
+        st.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / (reps * per_call), out
+
+    per, out = timed(lambda: fx.batch(wavs), clips)
+    per1, out1 = timed(lambda: [fx(wavs[i]) for i in range(clips)][-1], clips)
     bytes_clip = 4 * n * 4 + 3000 * 64 * 7 * 4
-    assert tuple(out.shape) == (3001, 64, 7) and bool(torch.isfinite(out).all())
+    assert tuple(out.shape) == (clips, 3001, 64, 7) and bool(torch.isfinite(out).all()) and bool(torch.equal(out[-1], out1))
     ach = bytes_clip / per / 1e9
-    return {"stage": "feature_extractor foa n_fft 1024 / win 960 / hop 480 -> [3001,64,7], 60-s clips resident in HBM",
+    return {"stage": f"feature_extractor foa n_fft 1024 / win 960 / hop 480 -> [3001,64,7], 60-s clips resident in HBM, {clips} clips per launch pair",
             "clips_per_s": round(1 / per, 1), "ms_per_clip": round(per * 1e3, 4), "algorithmic_bytes_per_clip": bytes_clip,
+            "clip_by_clip": {"clips_per_s": round(1 / per1, 1), "ms_per_clip": round(per1 * 1e3, 4)},
             "roofline": {"kernel": "feat_frame", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None}}
 
@@ -267,16 +274,16 @@ def main():
         if T != 3000:
             raise SystemExit("--with-features extracts 60-s clips: --frames must be 3000")
         rng = np.random.default_rng(77 + rank)
-        wavs = [torch.as_tensor((rng.standard_normal((4, 1440000)) * 0.1).astype(np.float32)).to(dev) for _ in range(B)]
+        wavs = torch.as_tensor((rng.standard_normal((B, 4, 1440000)) * 0.1).astype(np.float32)).to(dev)
         fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=local)
         f_mean = torch.full((64 * 7,), -3.0, device=dev)     # a fitted normalizer's statistics (data_loader.py:226-234), synthetic here
         f_std = torch.full((64 * 7,), 2.0, device=dev)
 
         def featurize():
             st_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            f = fx.batch(wavs)                                   # [B, 3001, 64, 7]: one pair of launches
             for b in range(B):
-                f = fx(wavs[b])                                  # [3001, 64, 7]
-                _lib.check(fx.lib.seld_feat_normalize(f.data_ptr(), f_mean.data_ptr(), f_std.data_ptr(), x[b].data_ptr(), 3001, 3000,
+                _lib.check(fx.lib.seld_feat_normalize(f[b].data_ptr(), f_mean.data_ptr(), f_std.data_ptr(), x[b].data_ptr(), 3001, 3000,
                                                       64 * 7, 1e-8, st_))
 
     def barrier():

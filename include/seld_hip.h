@@ -176,6 +176,10 @@ int seld_feat_set_option(seld_feat* f, const char* key, int value);
 int64_t seld_feat_frames(const seld_feat* f, int64_t n_samples);
 int seld_feat_channels(const seld_feat* f);
 int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_samples, float* out, void* stream);
+/* The same for `n_clips` clips of ONE length in one pair of launches (what a data loader preprocessing a list of equal-length files,
+ * feature_extractor.py:238-262, does clip by clip): wav [n_clips][n_ch][n_samples] -> out [n_clips][frames][n_mels][7|10]; the
+ * top_db clamp stays per clip.  Launch overheads and the tail of a 3 001-frame grid amortise over the batch. */
+int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_ch, int64_t n_samples, float* out, void* stream);
 /* (x - mean)/max(std, eps) per (freq, chan), rows trimmed / zero-padded (before normalising, as the reference does) to T_out */
 int seld_feat_normalize(const float* feat, const float* mean, const float* stdv, float* out, int64_t T_in, int64_t T_out,
                         int FC, float eps, void* stream);

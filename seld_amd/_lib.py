@@ -93,6 +93,7 @@ SIGNATURES = {
     "seld_feat_frames": (_L, [_P, _L]),
     "seld_feat_channels": (_I, [_P]),
     "seld_feat_extract": (_I, [_P, _P, _I, _L, _P, _P]),
+    "seld_feat_extract_batch": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "seld_feat_normalize": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
     "seld_frame_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "seld_overlap_average": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -35,7 +35,8 @@ struct seld_feat {
     int* trips = nullptr;       // [16] per-slot loop bounds of the wave kernel
     int dbg = 0;                // timing ablations of the wave kernel (tools/tune_features.py): 1 no loads, 2 no FFT passes, 4 no mel
     int use_wave_kernel = 1;    // 0: the workgroup-per-frame radix-2 kernel for every size (A/B and parity of the fallback)
-    float* gmax = nullptr;      // [FEAT_MAX_PARTS]: per-workgroup maxima of the dB channels of the running clip (no atomics: thousands
+    int gmax_clips = 1;         // clips the maxima buffer holds
+    float* gmax = nullptr;      // [clips][FEAT_MAX_PARTS]: per-workgroup maxima of the dB channels of the running clip (no atomics: thousands
                                 // of atomic maxima on ONE word serialise at ~88 per microsecond and were 40 % of the kernel)
     std::string err;
 };
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(256) void feat_frame_kernel(const float* __restrict
     const int tid = threadIdx.x;
     for (int i = tid; i < N / 2; i += 256) tw[i] = tw_g[i];
     float lmax = -INFINITY;
+    wav += (size_t)blockIdx.y * 4 * n_samples;                         // blockIdx.y = clip of a batch
+    out += (size_t)blockIdx.y * n_frames * n_mels * C_OUT;
+    gmax += (size_t)blockIdx.y * gridDim.x;
     for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {      // grid <= FEAT_MAX_PARTS: one maximum per workgroup
     // ---- windowed, reflect-padded frame (torch.stft center=True): sample index t*hop + n - N/2
     const float* x0 = wav;
@@ -333,7 +337,7 @@ __device__ __forceinline__ void feat_load_pair(float2 (&v)[1][WF<LOGN>::NB4][4],
     }
 }
 
-#define FEAT_WAVES 6
+#define FEAT_WAVES 16
 // LDS of one wave: ONE transform buffer; the same bytes later hold four per-bin value planes [4][NB + 3] and then the staged frame
 static size_t feat_wave_bytes(int n_fft, int n_mels, int c_out) {
     const size_t fft = (size_t)n_fft * sizeof(float2), planes = (size_t)4 * (n_fft / 2 + 4) * sizeof(float);
@@ -350,7 +354,7 @@ static size_t feat_wave_bytes(int n_fft, int n_mels, int c_out) {
 // The mel filters are read 16 bytes at a time: filter m covers cnt4[m] aligned float4 chunks of a plane from bin start4[m]
 // (a multiple of 4), its weights zero-padded to match (seld_feat_create).
 template <int MODE, int LOGN>
-__global__ __launch_bounds__(64 * FEAT_WAVES, MODE == 0 ? 3 : 2) void feat_wave_kernel(
+__global__ __launch_bounds__(64 * FEAT_WAVES, 1) void feat_wave_kernel(
     const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, int n_melw4, int maxc4,
     const float* __restrict__ win_g, const float2* __restrict__ tw_g, const int* __restrict__ mel_start4,
     const int* __restrict__ mel_cnt4, const int* __restrict__ mel_off4, const float* __restrict__ mel_w4, float* __restrict__ out,
@@ -382,6 +386,10 @@ __global__ __launch_bounds__(64 * FEAT_WAVES, MODE == 0 ? 3 : 2) void feat_wave_
     __syncthreads();
     float lmax = -INFINITY;
     float2* const b1[1] = {buf};
+    // a batch of clips of one length: blockIdx.y = clip ([clips][4][n_samples] in, [clips][T][n_mels][C_OUT] out, maxima per clip)
+    wav += (size_t)blockIdx.y * 4 * n_samples;
+    out += (size_t)blockIdx.y * T * n_mels * C_OUT;
+    gmax += (size_t)blockIdx.y * gridDim.x;
     for (int64_t t = (int64_t)blockIdx.x * FEAT_WAVES + wave; t < T; t += (int64_t)gridDim.x * FEAT_WAVES) {
         // `lane` made opaque per frame: everything indexed by it (twiddles of every pass, window, table offsets) is otherwise
         // hoisted out of this loop and held in ~100 registers for the one or two frames a wave sees
@@ -542,6 +550,8 @@ __global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out
                                                          int64_t n_tm, int c_out, float top_db) {
     __shared__ float red[256];
     float m = -INFINITY;
+    gmax += (size_t)blockIdx.y * nparts;          // blockIdx.y = clip of a batch
+    out += (size_t)blockIdx.y * n_tm * c_out;
     for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, gmax[i]);
     red[threadIdx.x] = m;
     __syncthreads();
@@ -705,8 +715,16 @@ int seld_feat_set_option(seld_feat* f, const char* key, int value) {
 int64_t seld_feat_frames(const seld_feat* f, int64_t n_samples) { return f ? 1 + n_samples / f->hop : -1; }
 int seld_feat_channels(const seld_feat* f) { return f ? (f->mode == 0 ? 7 : 10) : -1; }
 
-int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_samples, float* out, void* stream) {
-    if (!f || !wav || !out) return SELD_ERR_INVALID;
+int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_ch, int64_t n_samples, float* out, void* stream) {
+    if (!f || !wav || !out || n_clips < 1) return SELD_ERR_INVALID;
+    if (n_clips > f->gmax_clips) {          // per-clip maxima: [clips][FEAT_MAX_PARTS]
+        hipSetDevice(f->device);
+        float* g = nullptr;
+        if (hipMalloc(&g, (size_t)n_clips * FEAT_MAX_PARTS * sizeof(float)) != hipSuccess) return ffail(f, SELD_ERR_NOMEM, "feat_extract_batch: maxima buffer");
+        hipStreamSynchronize((hipStream_t)stream);
+        hipFree(f->gmax);
+        f->gmax = g; f->gmax_clips = n_clips;
+    }
     if (n_ch != 4) return ffail(f, SELD_ERR_UNSUPPORTED, "feature stage is built for 4-channel (FOA / MIC) audio");
     if (n_samples <= f->n_fft / 2) return ffail(f, SELD_ERR_INVALID, "clip shorter than the reflect padding (n_fft/2)");
     hipStream_t st = (hipStream_t)stream;
@@ -724,7 +742,7 @@ int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_sample
 #define FEAT_WAVE_CASE(MODE_, LOGN_)                                                                                            \
         {                                                                                                                       \
             hipFuncSetAttribute(reinterpret_cast<const void*>(feat_wave_kernel<MODE_, LOGN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            hipLaunchKernelGGL((feat_wave_kernel<MODE_, LOGN_>), dim3((unsigned)blocks), dim3(64 * FEAT_WAVES), smem, st, wav, n_samples, T, \
+            hipLaunchKernelGGL((feat_wave_kernel<MODE_, LOGN_>), dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * FEAT_WAVES), smem, st, wav, n_samples, T, \
                                f->hop, f->n_mels, f->n_melw4, f->maxc4, f->win, f->tw, f->mel_start4, f->mel_cnt4, f->mel_off4, f->mel_w4, \
                                out, f->gmax, (int)wb, f->dbg, f->trips);                                                                      \
             launched = true; nparts = (int)blocks;                                                                              \
@@ -742,21 +760,25 @@ int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_sample
     const size_t smem = (size_t)(4 * N) * sizeof(float2) + (size_t)(N / 2) * sizeof(float2) + (vals + 256) * sizeof(float);
     if (f->mode == 0) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(feat_frame_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(feat_frame_kernel<0>, dim3((unsigned)nparts), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
+        hipLaunchKernelGGL(feat_frame_kernel<0>, dim3((unsigned)nparts, (unsigned)n_clips), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
                            f->win, f->tw, f->mel_start, f->mel_count, f->mel_off, f->mel_w, out, f->gmax);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(feat_frame_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(feat_frame_kernel<1>, dim3((unsigned)nparts), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
+        hipLaunchKernelGGL(feat_frame_kernel<1>, dim3((unsigned)nparts, (unsigned)n_clips), dim3(256), smem, st, wav, n_samples, T, N, f->logn, f->hop, f->n_mels,
                            f->win, f->tw, f->mel_start, f->mel_count, f->mel_off, f->mel_w, out, f->gmax);
     }
     }
     const int64_t n_tm = T * f->n_mels;
     int64_t tb = (n_tm * 4 + 255) / 256;
     if (tb > 1024) tb = 1024;
-    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)tb), dim3(256), 0, st, out, f->gmax, nparts, n_tm, f->mode == 0 ? 7 : 10, 80.f);
+    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)tb, (unsigned)n_clips), dim3(256), 0, st, out, f->gmax, nparts, n_tm, f->mode == 0 ? 7 : 10, 80.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ffail(f, SELD_ERR_HIP, std::string("feat_extract: ") + hipGetErrorString(e));
     return SELD_OK;
+}
+
+int seld_feat_extract(seld_feat* f, const float* wav, int n_ch, int64_t n_samples, float* out, void* stream) {
+    return seld_feat_extract_batch(f, wav, 1, n_ch, n_samples, out, stream);
 }
 
 int seld_feat_normalize(const float* feat, const float* mean, const float* stdv, float* out, int64_t T_in, int64_t T_out, int FC,

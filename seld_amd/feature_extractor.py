@@ -59,6 +59,22 @@ class FeatureExtractor:
             raise _lib.SeldError(rc, self.lib.seld_feat_last_error(self.h).decode())
         return out
 
+    def batch(self, wavs) -> torch.Tensor:
+        """wavs [n_clips, 4, n] (clips of one length, or a list of such tensors) -> device tensor [n_clips, 1 + n//hop, n_mels, 7|10]:
+        the whole batch in one pair of launches (seld_feat_extract_batch); each clip's top_db clamp is its own."""
+        if isinstance(wavs, (list, tuple)):
+            wavs = torch.stack([torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w) for w in wavs])
+        w = torch.as_tensor(np.asarray(wavs) if not isinstance(wavs, torch.Tensor) else wavs).to(self._dev, torch.float32).contiguous()
+        if w.dim() != 3:
+            raise ValueError("wavs must be [clips, channels, samples]")
+        T = int(self.lib.seld_feat_frames(self.h, w.shape[2]))
+        out = torch.empty((w.shape[0], T, self.n_mels, self.channels), dtype=torch.float32, device=self._dev)
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        rc = self.lib.seld_feat_extract_batch(self.h, w.data_ptr(), int(w.shape[0]), int(w.shape[1]), int(w.shape[2]), out.data_ptr(), st)
+        if rc:
+            raise _lib.SeldError(rc, self.lib.seld_feat_last_error(self.h).decode())
+        return out
+
     def normalize(self, feat: torch.Tensor, mean, std, n_frames: int = 3000, eps: float = 1e-8) -> torch.Tensor:
         """preprocess_features_labels (pad/trim to n_frames, :117-149) + apply_normalizer (:226-234)."""
         FC = feat.shape[1] * feat.shape[2]

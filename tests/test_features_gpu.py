@@ -74,3 +74,17 @@ def test_full_clip_and_normalize(seld_lib):
     check("normalised", out.cpu().numpy(), FO.apply_normalizer(ref[:3000], mean, std))
     with pytest.raises(ValueError):
         FE.FeatureExtractor(24000, "stereo")
+
+
+@pytest.mark.parametrize("mode", ["foa", "mic"])
+def test_batch_extraction_equals_clip_by_clip(seld_lib, mode):
+    """seld_feat_extract_batch: several clips of one length in one pair of launches — bit for bit what clip-by-clip extraction gives
+    (every clip keeps its own top_db clamp: the clips here differ in level by 40 dB)."""
+    from seld_amd import feature_extractor as FE
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    fx = FE.FeatureExtractor(24000, mode, 64, **kw)
+    wavs = np.stack([_wav(24000 + 77, seed=s, scale=sc) for s, sc in ((1, 0.1), (2, 0.001), (3, 0.05))])
+    got = fx.batch(wavs).cpu().numpy()
+    assert got.shape == (3, 1 + (24000 + 77) // 480, 64, 7 if mode == "foa" else 10)
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], fx(wavs[i]).cpu().numpy())

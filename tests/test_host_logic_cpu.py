@@ -148,3 +148,16 @@ def test_keras_h5_name_mapping_on_a_hand_built_name_list():
     bad = [(n, (3, 3, 10, 64) if n == "conv2d_4/kernel:0" else s) for n, s in kv]
     with pytest.raises(ValueError):                       # a mic-feature checkpoint into a foa model
         K.check_shapes(K.map_keras_variables(bad), bad, ours)
+
+
+def test_seldnet_v1_json_is_the_same_network(seldnet_config):
+    """model_config/seldnet_v1.json differs from seldnet.json only in DOA_ARGS lacking 'activation' — a key nothing reads:
+    simple_dense_block takes 'dense_activation' (modules.py:356) and models.seldnet hard-codes sigmoid / tanh on the output layers
+    (models.py:27-30).  Both JSONs must map to the same architecture."""
+    import copy
+    import ctypes as C
+    from seld_amd import models
+    v1 = copy.deepcopy(seldnet_config)
+    del v1["DOA_ARGS"]["activation"]
+    a, b = models._arch_from_config(seldnet_config, 7, 64), models._arch_from_config(v1, 7, 64)
+    assert bytes(C.string_at(C.addressof(a), C.sizeof(a))) == bytes(C.string_at(C.addressof(b), C.sizeof(b)))
