@@ -35,6 +35,8 @@ struct seld_feat {
     int* trips = nullptr;       // [16] per-slot loop bounds of the wave kernel
     int dbg = 0;                // timing ablations of the wave kernel (tools/tune_features.py): 1 no loads, 2 no FFT passes, 4 no mel
     int use_wave_kernel = 1;    // 0: the workgroup-per-frame radix-2 kernel for every size (A/B and parity of the fallback)
+    uint4* dft_tab = nullptr;   // foa, n_fft 1024: constant MFMA fragments + twiddles of feat_dft_kernel (DFT_TAB_BYTES)
+    bool use_dft = true;
     int gmax_clips = 1;         // clips the maxima buffer holds
     float* gmax = nullptr;      // [clips][FEAT_MAX_PARTS]: per-workgroup maxima of the dB channels of the running clip (no atomics: thousands
                                 // of atomic maxima on ONE word serialise at ~88 per microsecond and were 40 % of the kernel)
@@ -544,6 +546,240 @@ __global__ __launch_bounds__(64 * FEAT_WAVES, 1) void feat_wave_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// feat_dft_kernel — foa, n_fft = 1024: the transform on the MATRIX cores.  1024 = 32 x 32: with n = 32 n1 + n2, k = k1 + 32 k2,
+//     X[k1 + 32 k2] = sum_n2 W32^(n2 k2) . W1024^(n2 k1) . [ sum_n1 x[32 n1 + n2] W32^(n1 k1) ]
+// is two 32 x 32 x 32 products with a pointwise twiddle between them, and a frame's data never leaves the registers of ITS wave:
+//   step 1   Y^T[n2][k1] = x^T F32          A operand = the frame as loaded (lane n2 holds x[32 n1 + n2], 8 consecutive n1 per k-group)
+//   twiddle  Z = Y . W1024^(n2 k1)          in the accumulator layout (row n2 = mfma_row(r, g), column k1 = lane & 31)
+//   step 3   [Fr; Fi] Z                      B operand = Z exactly where it lies: the K slots are assigned to the rows a lane holds (the
+//            constant A operand is built in the same order); rows 0..15 of the stacked constant matrix are Re W32^(n2 k2), rows 16..31
+//            Im, so X_re[k2] = P[r] - Q[r + 8], X_im[k2] = Q[r] + P[r + 8] are lane-local (P = [Fr; Fi] Zr, Q = [Fr; Fi] Zi).
+// Operands: fp32 values split into TWO f16 terms (hi + lo, 22 bits) and three products (hi hi, lo hi, hi lo) accumulated in fp32;
+// the frame is scaled by a power of two so that its largest sample sits in [2^13, 2^14), the constant matrices by 2^10, the twiddle
+// table carries 2^-15: every f16 operand stays in the normal range and every scaling is exact.  No LDS passes, no barriers: LDS holds
+// the constant fragments, the twiddles and — as in feat_wave_kernel, whose second half this kernel shares — the per-bin planes of the
+// sparse mel projection.  A lane ends with bins k = (lane & 31) + 32 k2, k2 = mfma_row(i, lane >> 5), i < 8 (+ bin 512 on lane 0).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+#define DFT_WAVES 12
+#define DFT_TAB_BYTES (8 * 1024 + 4 * 1024 + 8 * 1024)        // f1 [2][re|im][hi|lo][64] x 16 B | a3 [2][hi|lo][64] x 16 B | tw2 [16][64] float2
+
+// two fp32 values -> their f16 hi terms (truncation: the fp32 bits masked to 10 mantissa bits IS the round-toward-zero f16 in the
+// normal range; below it the mask keeps more than f16 does, an error of at most one f16 subnormal step, 2^-38 of the frame's largest
+// sample) and lo terms (the exact remainders, truncated), packed as elements j, j + 1 of the two fragments
+__device__ __forceinline__ void dft_split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {      // one packed word each
+    const float h0 = __uint_as_float(__float_as_uint(v0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(v1) & 0xffffe000u);
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1));
+}
+typedef unsigned dft_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h16x8 dft_frag(const unsigned (&w)[4]) { return __builtin_bit_cast(h16x8, dft_u32x4{w[0], w[1], w[2], w[3]}); }
+
+__device__ __forceinline__ int dft_bin(int i, int lane) {      // NB (= out of range) for the slots a lane does not own
+    if (i < 8) return (lane & 31) + 32 * ((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5));
+    return lane == 0 ? 512 : 513;
+}
+
+__global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
+    const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, int n_melw4, const float* __restrict__ win_g,
+    const uint4* __restrict__ dft_g, const int* __restrict__ mel_start4, const int* __restrict__ mel_cnt4, const int* __restrict__ mel_off4,
+    const float* __restrict__ mel_w4, float* __restrict__ out, float* __restrict__ gmax, int wave_bytes, const int* __restrict__ trips_g) {
+    constexpr int N = 1024, NB = 513, NBP = 516, NBI = 9, C_OUT = 7;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* win = smem;                                             // [N]
+    float* melw = win + N;                                         // [n_melw4]
+    int* mst = reinterpret_cast<int*>(melw + n_melw4);
+    int* mct = mst + n_mels;
+    int* mof = mct + n_mels;
+    int* trips = mof + ((n_mels + 3) & ~3);                       // [16]
+    size_t toff = (size_t)(reinterpret_cast<char*>(trips + 16) - reinterpret_cast<char*>(smem));
+    toff = (toff + 15) & ~(size_t)15;
+    char* dtab = reinterpret_cast<char*>(smem) + toff;
+    const h16x8* f1 = reinterpret_cast<const h16x8*>(dtab);                       // [(s * 2 + c) * 2 + t][lane]
+    const h16x8* a3 = reinterpret_cast<const h16x8*>(dtab + 8 * 1024);            // [s * 2 + t][lane]
+    const float2* tw2 = reinterpret_cast<const float2*>(dtab + 12 * 1024);        // [r][lane]
+    const int tid = threadIdx.x, lane_id = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (size_t)wave * wave_bytes);
+    for (int i = tid; i < N; i += 64 * DFT_WAVES) win[i] = win_g[i];
+    for (int i = tid; i < n_melw4; i += 64 * DFT_WAVES) melw[i] = mel_w4[i];
+    for (int i = tid; i < n_mels; i += 64 * DFT_WAVES) { mst[i] = mel_start4[i]; mct[i] = mel_cnt4[i]; mof[i] = mel_off4[i]; }
+    for (int i = tid; i < DFT_TAB_BYTES / 16; i += 64 * DFT_WAVES) reinterpret_cast<uint4*>(dtab)[i] = dft_g[i];
+    if (tid < 16) trips[tid] = trips_g[tid];
+    __syncthreads();
+    float lmax = -INFINITY;
+    wav += (size_t)blockIdx.y * 4 * n_samples;                     // blockIdx.y = clip of a batch
+    out += (size_t)blockIdx.y * T * n_mels * C_OUT;
+    gmax += (size_t)blockIdx.y * gridDim.x;
+    float xr[16];                                                  // the samples the next channel iteration works on
+    bool first_frame = true;
+    for (int64_t t = (int64_t)blockIdx.x * DFT_WAVES + wave; t < T; t += (int64_t)gridDim.x * DFT_WAVES) {
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));                             // see feat_wave_kernel: keeps lane-indexed values out of LICM
+        const int li = lane & 31, g = lane >> 5;
+        float2 X0[NBI];
+        float IV[3][NBI];
+        // the window at this lane's 16 sample slots (slot u -> n1 = 16 (u >> 3) + 8 g + (u & 7), n = 32 n1 + li): the same for the four channels
+        float wn[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wn[u] = win[512 * (u >> 3) + 256 * g + 32 * (u & 7) + li];
+        // raw samples of (frame, channel) in A-operand order; channel c + 1 is requested before channel c is processed, so that a wave
+        // waits for global memory once per frame instead of four times (-5 % same box, although 16 more registers spill a little)
+        auto load16 = [&](float (&dst)[16], int64_t tt, int cc) {
+            const int64_t s0_ = tt * hop - N / 2;
+            const bool interior_ = s0_ >= 0 && s0_ + N <= n_samples;
+            const float* xc_ = wav + (size_t)cc * n_samples;
+            if (interior_) {                                   // wave-uniform: one base address per lane, compile-time offsets
+                const float* p_ = xc_ + (s0_ + 256 * g + li);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) dst[u] = p_[512 * (u >> 3) + 32 * (u & 7)];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    int64_t i = s0_ + 512 * (u >> 3) + 256 * g + 32 * (u & 7) + li;
+                    if (i < 0) i = -i;
+                    if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+                    dst[u] = xc_[i];
+                }
+            }
+        };
+        const int64_t t_next = t + (int64_t)gridDim.x * DFT_WAVES < T ? t + (int64_t)gridDim.x * DFT_WAVES : t;
+        float xn[16];
+        if (first_frame) { load16(xr, t, 0); first_frame = false; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) load16(xn, t, c + 1);                   // the next channel; after the last one: channel 0 of this wave's NEXT frame
+            else load16(xn, t_next, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float xw[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) xw[u] = wn[u] * xr[u];
+            float amax = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) amax = fmaxf(amax, fabsf(xw[u]));
+            amax = wave_max(amax);
+            // power-of-two scale per channel and frame: largest sample into [2^13, 2^14)
+            const int ex = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 14;       // amax = f 2^ex, f in [0.5, 1)
+            const float sc_in = __builtin_amdgcn_ldexpf(1.f, 14 - ex);
+            const float sc_out = __builtin_amdgcn_ldexpf(1.f, ex - 19);               // X = acc3 2^-5 / sc_in
+            const float sc_ny = __builtin_amdgcn_ldexpf(1.f, ex - 24);                // X[512] = sum(+-acc1) 2^-10 / sc_in
+            unsigned ahw[2][4], alw[2][4];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) dft_split_pair(xw[u] * sc_in, xw[u + 1] * sc_in, ahw[u >> 3][(u & 7) >> 1], alw[u >> 3][(u & 7) >> 1]);
+            const h16x8 ah[2] = {dft_frag(ahw[0]), dft_frag(ahw[1])}, al[2] = {dft_frag(alw[0]), dft_frag(alw[1])};
+            f32x16 yr = zero16(), yi = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const h16x8 frh = f1[((s * 2 + 0) * 2 + 0) * 64 + lane], frl = f1[((s * 2 + 0) * 2 + 1) * 64 + lane];
+                const h16x8 fih = f1[((s * 2 + 1) * 2 + 0) * 64 + lane], fil = f1[((s * 2 + 1) * 2 + 1) * 64 + lane];
+                yr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], frh, yr, 0, 0, 0);
+                yi = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], fih, yi, 0, 0, 0);
+                yr = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], frh, yr, 0, 0, 0);
+                yi = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], fih, yi, 0, 0, 0);
+                yr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], frl, yr, 0, 0, 0);
+                yi = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], fil, yi, 0, 0, 0);
+            }
+            // bin 512 = sum_n2 (-1)^n2 Y[n2][k1 = 0] (real): the rows of this lane have parity r & 1
+            float ny = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ny += (r & 1) ? -yr[r] : yr[r];
+            ny = (ny + __shfl_xor(ny, 32)) * sc_ny;                // meaningful on lanes 0 / 32 (k1 = 0)
+            unsigned zrhw[2][4], zrlw[2][4], zihw[2][4], zilw[2][4];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float2 w0 = tw2[r * 64 + lane], w1 = tw2[(r + 1) * 64 + lane];
+                const float zr0 = fmaf(yr[r], w0.x, -yi[r] * w0.y), zi0 = fmaf(yr[r], w0.y, yi[r] * w0.x);
+                const float zr1 = fmaf(yr[r + 1], w1.x, -yi[r + 1] * w1.y), zi1 = fmaf(yr[r + 1], w1.y, yi[r + 1] * w1.x);
+                dft_split_pair(zr0, zr1, zrhw[r >> 3][(r & 7) >> 1], zrlw[r >> 3][(r & 7) >> 1]);
+                dft_split_pair(zi0, zi1, zihw[r >> 3][(r & 7) >> 1], zilw[r >> 3][(r & 7) >> 1]);
+            }
+            const h16x8 zrh[2] = {dft_frag(zrhw[0]), dft_frag(zrhw[1])}, zrl[2] = {dft_frag(zrlw[0]), dft_frag(zrlw[1])};
+            const h16x8 zih[2] = {dft_frag(zihw[0]), dft_frag(zihw[1])}, zil[2] = {dft_frag(zilw[0]), dft_frag(zilw[1])};
+            f32x16 Pa = zero16(), Qa = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const h16x8 ch = a3[(s * 2 + 0) * 64 + lane], cl = a3[(s * 2 + 1) * 64 + lane];
+                Pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, zrh[s], Pa, 0, 0, 0);
+                Qa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, zih[s], Qa, 0, 0, 0);
+                Pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, zrl[s], Pa, 0, 0, 0);
+                Qa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, zil[s], Qa, 0, 0, 0);
+                Pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, zrh[s], Pa, 0, 0, 0);
+                Qa = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, zih[s], Qa, 0, 0, 0);
+            }
+            // this lane's bins: power straight into the channel's plane (pad entries zeroed below), intensity components kept
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const int i8 = i < 8 ? i : 0;
+                const float2 xc = i < 8 ? make_float2((Pa[i8] - Qa[i8 + 8]) * sc_out, (Qa[i8] + Pa[i8 + 8]) * sc_out) : make_float2(ny, 0.f);
+                const int k = dft_bin(i, lane);
+                if (i < 8 || k < NB) val[c * NBP + k] = xc.x * xc.x + xc.y * xc.y;
+                if (c == 0) X0[i] = xc;
+                else IV[c == 3 ? 0 : c][i] = X0[i].x * xc.x + X0[i].y * xc.y;      // IVx <- ch3, IVy <- ch1, IVz <- ch2: Re(conj(W) X_c)
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) xr[u] = xn[u];
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const float ivx = IV[0][i], ivy = IV[1][i], ivz = IV[2][i];
+            const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ivx * ivx + ivy * ivy + ivz * ivz), 1e-8f));
+            IV[0][i] = ivx * inv; IV[1][i] = ivy * inv; IV[2][i] = ivz * inv;
+        }
+        // (the pad entries of the four planes: the filters read whole float4 chunks)
+        if (lane < 4 * (NBP - NB)) val[(lane / (NBP - NB)) * NBP + NB + lane % (NBP - NB)] = 0.f;
+        WAVE_LDS_FENCE();
+        auto mel_dot = [&](int m, int c, int trips_) -> float {
+            const int c4n = mct[m];
+            const float4* wv = reinterpret_cast<const float4*>(melw + mof[m]);
+            const float4* vv = reinterpret_cast<const float4*>(val + c * NBP + mst[m]);
+            float acc = 0.f;
+            for (int i = 0; i < trips_; ++i)
+                if (i < c4n) {
+                    const float4 w = wv[i], x = vv[i];
+                    acc = fmaf(w.x, x.x, acc); acc = fmaf(w.y, x.y, acc); acc = fmaf(w.z, x.z, acc); acc = fmaf(w.w, x.w, acc);
+                }
+            return acc;
+        };
+        float* frame_out = out + (size_t)t * n_mels * C_OUT;
+        for (int q = 0; 64 * q < 4 * n_mels; ++q) {
+            const int idx = lane + 64 * q;
+            const int tr = __builtin_amdgcn_readfirstlane(trips[q]);
+            if (idx < 4 * n_mels) {
+                const float md = mel_dot(idx >> 2, idx & 3, tr);
+                const float o = 3.0102999566f * __builtin_amdgcn_logf(fmaxf(md, 1e-10f));
+                lmax = fmaxf(lmax, o);
+                frame_out[(idx >> 2) * C_OUT + (idx & 3)] = o;
+            }
+        }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int k = dft_bin(i, lane);
+            if (k < NB) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) val[c * NBP + k] = IV[c][i];
+            }
+        }
+        WAVE_LDS_FENCE();
+        for (int q = 0; 64 * q < 3 * n_mels; ++q) {
+            const int idx = lane + 64 * q;
+            const int tr = __builtin_amdgcn_readfirstlane(trips[8 + q]);
+            if (idx < 3 * n_mels) frame_out[(idx / 3) * C_OUT + 4 + idx % 3] = mel_dot(idx / 3, idx % 3, tr);
+        }
+        WAVE_LDS_FENCE();
+    }
+    lmax = wave_max(lmax);
+    __syncthreads();
+    if (lane_id == 0) reinterpret_cast<float*>(trips)[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = -INFINITY;
+        for (int w = 0; w < DFT_WAVES; ++w) m = fmaxf(m, reinterpret_cast<float*>(trips)[w]);
+        gmax[blockIdx.x] = m;
+    }
+}
+
 // top_db clamp: x_db = max(x_db, max over the clip - top_db) on the four dB channels.  Every workgroup first reduces the
 // per-workgroup maxima the extraction kernel left in gmax[0 .. nparts), then walks its share of the [T * n_mels] rows.
 __global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out, const float* __restrict__ gmax, int nparts,
@@ -586,6 +822,46 @@ int ffail(seld_feat* f, int code, const std::string& msg) {
 }
 
 }  // namespace
+
+
+// float -> IEEE half bits, round to nearest even (host side of feat_dft_kernel's constant fragments)
+static unsigned short feat_f2h(float x) {
+    unsigned u; memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    int e = (int)((u >> 23) & 0xff) - 127 + 15;
+    unsigned m = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (unsigned short)(sign | 0x7c00u | (m ? 0x200u : 0u));
+    if (e >= 31) return (unsigned short)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (unsigned short)sign;
+        m |= 0x800000u;
+        const int sh = 14 - e;                       // 24-bit significand -> 10 bits, shifted by 1 - e more
+        unsigned r = m >> sh;
+        const unsigned rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (unsigned short)(sign | r);
+    }
+    unsigned r = ((unsigned)e << 10) | (m >> 13);
+    const unsigned rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;       // a carry into the exponent is the right answer
+    return (unsigned short)(sign | r);
+}
+static float feat_h2f(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const unsigned m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400u), e - 25);
+    unsigned u; memcpy(&u, &v, 4); u |= sign; memcpy(&v, &u, 4);
+    return v;
+}
+// hi + lo f16 split of v: hi = round(v), lo = round(v - hi)
+static void feat_split_h(double v, unsigned short& hi, unsigned short& lo) {
+    hi = feat_f2h((float)v);
+    lo = feat_f2h((float)(v - (double)feat_h2f(hi)));
+}
 
 extern "C" {
 
@@ -688,6 +964,40 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
     hipMemcpy(f->mel_cnt4, mcnt4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_off4, moff4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_w4, mw4.data(), mw4.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (mode == 0 && n_fft == 1024) {
+        // feat_dft_kernel's constants, in the lane order of the MFMA operands (see the kernel's header comment)
+        std::vector<unsigned short> tab(DFT_TAB_BYTES / 2, 0);
+        auto mrow = [](int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; };
+        for (int sidx = 0; sidx < 2; ++sidx)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int li = lane & 31, g = lane >> 5;
+                for (int j = 0; j < 8; ++j) {
+                    // step 1, B operand: F[n1][k1 = li] = exp(-2 pi i n1 k1 / 32) * 2^10, n1 = 16 s + 8 g + j
+                    const int n1 = 16 * sidx + 8 * g + j;
+                    const double ang = -2.0 * PI * (double)((n1 * li) & 31) / 32.0;
+                    unsigned short h, l;
+                    feat_split_h(cos(ang) * 1024.0, h, l);
+                    tab[((((sidx * 2 + 0) * 2 + 0) * 64 + lane) * 8) + j] = h; tab[((((sidx * 2 + 0) * 2 + 1) * 64 + lane) * 8) + j] = l;
+                    feat_split_h(sin(ang) * 1024.0, h, l);
+                    tab[((((sidx * 2 + 1) * 2 + 0) * 64 + lane) * 8) + j] = h; tab[((((sidx * 2 + 1) * 2 + 1) * 64 + lane) * 8) + j] = l;
+                    // step 3, A operand: row rho = li: rho < 16 -> Re W32^(n2 k2), else Im, k2 = rho & 15, n2 = mfma_row(8 s + j, g)
+                    const int n2 = mrow(8 * sidx + j, g), k2 = li & 15;
+                    const double a2 = -2.0 * PI * (double)((n2 * k2) & 31) / 32.0;
+                    feat_split_h((li < 16 ? cos(a2) : sin(a2)) * 1024.0, h, l);
+                    tab[4096 + (((sidx * 2 + 0) * 64 + lane) * 8) + j] = h; tab[4096 + (((sidx * 2 + 1) * 64 + lane) * 8) + j] = l;
+                }
+            }
+        float* tw2 = reinterpret_cast<float*>(tab.data() + 6144);            // byte offset 12 KB
+        for (int r = 0; r < 16; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n2 = mrow(r, lane >> 5), k1 = lane & 31;
+                const double ang = -2.0 * PI * (double)(n2 * k1) / 1024.0;
+                tw2[(r * 64 + lane) * 2] = (float)(cos(ang) / 32768.0);
+                tw2[(r * 64 + lane) * 2 + 1] = (float)(sin(ang) / 32768.0);
+            }
+        if (hipMalloc(&f->dft_tab, DFT_TAB_BYTES) != hipSuccess) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
+        hipMemcpy(f->dft_tab, tab.data(), DFT_TAB_BYTES, hipMemcpyHostToDevice);
+    }
     f->n_melw4 = (int)mw4.size();
     hipMemcpy(f->trips, trips.data(), 16 * sizeof(int), hipMemcpyHostToDevice);
     f->maxc4 = maxc4;
@@ -700,7 +1010,7 @@ void seld_feat_destroy(seld_feat* f) {
     hipSetDevice(f->device);
     hipDeviceSynchronize();
     hipFree(f->win); hipFree(f->tw); hipFree(f->mel_start); hipFree(f->mel_count); hipFree(f->mel_off); hipFree(f->mel_w);
-    hipFree(f->gmax);
+    hipFree(f->gmax); hipFree(f->dft_tab);
     hipFree(f->mel_start4); hipFree(f->mel_cnt4); hipFree(f->mel_off4); hipFree(f->mel_w4); hipFree(f->trips);
     delete f;
 }
@@ -708,6 +1018,7 @@ void seld_feat_destroy(seld_feat* f) {
 int seld_feat_set_option(seld_feat* f, const char* key, int value) {
     if (!f || !key) return SELD_ERR_INVALID;
     if (!strcmp(key, "wave_kernel")) { f->use_wave_kernel = value != 0; return SELD_OK; }
+    if (!strcmp(key, "dft")) { f->use_dft = value != 0; return SELD_OK; }
     if (!strcmp(key, "dbg")) { f->dbg = value; return SELD_OK; }
     return ffail(f, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -733,7 +1044,23 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     int nparts = 0;
     bool launched = false;
     // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
-    if (f->logn >= 8 && f->logn <= 10 && f->use_wave_kernel && f->n_mels <= 128 && f->n_mels <= N) {
+    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128) {
+        // foa, n_fft 1024: the transform on the matrix cores (feat_dft_kernel)
+        size_t tables = (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) + (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
+        tables = ((tables + 15) & ~(size_t)15) + DFT_TAB_BYTES;
+        const size_t wb = ((size_t)4 * (N / 2 + 4) * sizeof(float) + 15) & ~(size_t)15;      // the four per-bin planes of a wave
+        const size_t smem = tables + DFT_WAVES * wb;
+        // persistent workgroups: one per CU over the whole batch (a workgroup loads 30 KB of tables; a wave that walks several frames
+        // has the next frame's first channel in flight while it finishes the current one)
+        int64_t blocks = (T + DFT_WAVES - 1) / DFT_WAVES;
+        const int64_t per_clip = std::max<int64_t>(1, (256 + n_clips - 1) / n_clips);
+        if (blocks > per_clip) blocks = per_clip;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(feat_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(feat_dft_kernel, dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * DFT_WAVES), smem, st, wav, n_samples, T, f->hop,
+                           f->n_mels, f->n_melw4, f->win, f->dft_tab, f->mel_start4, f->mel_cnt4, f->mel_off4, f->mel_w4, out, f->gmax, (int)wb, f->trips);
+        launched = true; nparts = (int)blocks;
+    }
+    if (!launched && f->logn >= 8 && f->logn <= 10 && f->use_wave_kernel && f->n_mels <= 128 && f->n_mels <= N) {
         const size_t tables = (size_t)(N / 2) * sizeof(float2) + (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) +
                               (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
         const size_t wb = feat_wave_bytes(N, f->n_mels, f->mode == 0 ? 7 : 10), smem = tables + FEAT_WAVES * wb;
