@@ -407,8 +407,10 @@ def main():
             out["comm"] = comm
         if world == 1 and not args.no_features:
             out["features"] = features_leg(dev)
-            ft = traffic_tab.get("feat_frame", {}).get("hbm_bytes_per_launch")
-            out["features"]["roofline"]["traffic"] = ft
+            # PMC bytes of the extraction kernel per LAUNCH (tools/bench_features.py: 8 clips per launch) -> per clip, like `achieved`
+            ft = traffic_tab.get("feat_dft", traffic_tab.get("feat_frame", {})).get("hbm_bytes_per_launch")
+            out["features"]["roofline"]["traffic"] = None if ft is None else int(ft / (8 if "feat_dft" in traffic_tab else 1))
+            out["features"]["roofline"]["kernel"] = "feat_dft" if "feat_dft" in traffic_tab else "feat_frame"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config)
         print(json.dumps(out), flush=True)

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
     const int tid = threadIdx.x, lane_id = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (size_t)wave * wave_bytes);
+    float* stage = val + 4 * NBP;                                  // [n_mels][7]: the frame's outputs, stored as ONE contiguous run
     for (int i = tid; i < N; i += 64 * DFT_WAVES) win[i] = win_g[i];
     for (int i = tid; i < n_melw4; i += 64 * DFT_WAVES) melw[i] = mel_w4[i];
     for (int i = tid; i < n_mels; i += 64 * DFT_WAVES) { mst[i] = mel_start4[i]; mct[i] = mel_cnt4[i]; mof[i] = mel_off4[i]; }
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
                 const float md = mel_dot(idx >> 2, idx & 3, tr);
                 const float o = 3.0102999566f * __builtin_amdgcn_logf(fmaxf(md, 1e-10f));
                 lmax = fmaxf(lmax, o);
-                frame_out[(idx >> 2) * C_OUT + (idx & 3)] = o;
+                stage[(idx >> 2) * C_OUT + (idx & 3)] = o;
             }
         }
         WAVE_LDS_FENCE();
@@ -784,8 +785,12 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
         for (int q = 0; 64 * q < 3 * n_mels; ++q) {
             const int idx = lane + 64 * q;
             const int tr = __builtin_amdgcn_readfirstlane(trips[8 + q]);
-            if (idx < 3 * n_mels) frame_out[(idx / 3) * C_OUT + 4 + idx % 3] = mel_dot(idx / 3, idx % 3, tr);
+            if (idx < 3 * n_mels) stage[(idx / 3) * C_OUT + 4 + idx % 3] = mel_dot(idx / 3, idx % 3, tr);
         }
+        WAVE_LDS_FENCE();
+        // whole 128-byte lines, written once: with seven scattered dword stores per frame the lines of a batch's 43 MB of output were
+        // evicted half-written and went to HBM in pieces (PMC: 16.4 MB written per clip for 5.4 MB of output)
+        for (int j = lane; j < n_mels * C_OUT / 4; j += 64) reinterpret_cast<float4*>(frame_out)[j] = reinterpret_cast<const float4*>(stage)[j];
         WAVE_LDS_FENCE();
     }
     lmax = wave_max_dpp(lmax);
@@ -1063,11 +1068,11 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     int nparts = 0;
     bool launched = false;
     // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
-    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128) {
+    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128 && (f->n_mels & 3) == 0) {
         // foa, n_fft 1024: the transform on the matrix cores (feat_dft_kernel)
         size_t tables = (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) + (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
         tables = ((tables + 15) & ~(size_t)15) + DFT_TAB_BYTES;
-        const size_t wb = ((size_t)4 * (N / 2 + 4) * sizeof(float) + 15) & ~(size_t)15;      // the four per-bin planes of a wave
+        const size_t wb = (((size_t)4 * (N / 2 + 4) + (size_t)f->n_mels * 7) * sizeof(float) + 15) & ~(size_t)15;      // the four per-bin planes of a wave + its staged output frame
         const size_t smem = tables + DFT_WAVES * wb;
         // persistent workgroups: one per CU over the whole batch (a workgroup loads 30 KB of tables; a wave that walks several frames
         // has the next frame's first channel in flight while it finishes the current one)
