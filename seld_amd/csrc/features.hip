@@ -637,9 +637,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
         float2 X0[NBI];
         float IV[3][NBI];
         // the window at this lane's 16 sample slots (slot u -> n1 = 16 (u >> 3) + 8 g + (u & 7), n = 32 n1 + li): the same for the four channels
-        float wn[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) wn[u] = win[512 * (u >> 3) + 256 * g + 32 * (u & 7) + li];
+        const float* wn = win + 256 * g + li;                    // slot u at offset 512 (u >> 3) + 32 (u & 7): re-read per channel (16 registers fewer)
         // raw samples of (frame, channel) in A-operand order; channel c + 1 is requested before channel c is processed, so that a wave
         // waits for global memory once per frame instead of four times (-5 % same box, although 16 more registers spill a little)
         auto load16 = [&](float (&dst)[16], int64_t tt, int cc) {
@@ -652,10 +650,10 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
                 for (int u = 0; u < 16; ++u) dst[u] = p_[512 * (u >> 3) + 32 * (u & 7)];
             } else {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    int64_t i = s0_ + 512 * (u >> 3) + 256 * g + 32 * (u & 7) + li;
+                for (int u = 0; u < 16; ++u) {           // (sample indices of one clip fit 32 bits: checked by the launcher)
+                    int i = (int)s0_ + 512 * (u >> 3) + 256 * g + 32 * (u & 7) + li;
                     if (i < 0) i = -i;
-                    if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+                    if (i >= (int)n_samples) i = 2 * ((int)n_samples - 1) - i;
                     dst[u] = xc_[i];
                 }
             }
@@ -670,7 +668,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             __builtin_amdgcn_sched_barrier(0);
             float xw[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) xw[u] = wn[u] * xr[u];
+            for (int u = 0; u < 16; ++u) xw[u] = wn[512 * (u >> 3) + 32 * (u & 7)] * xr[u];
             float amax = 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) amax = fmaxf(amax, fabsf(xw[u]));
@@ -1068,7 +1066,7 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     int nparts = 0;
     bool launched = false;
     // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
-    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128 && (f->n_mels & 3) == 0) {
+    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128 && (f->n_mels & 3) == 0 && n_samples < (int64_t)1 << 30) {
         // foa, n_fft 1024: the transform on the matrix cores (feat_dft_kernel)
         size_t tables = (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) + (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
         tables = ((tables + 15) & ~(size_t)15) + DFT_TAB_BYTES;
