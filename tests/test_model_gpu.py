@@ -760,3 +760,46 @@ def test_resnet50_gru_train_step(resnet50_config, B, T, blocks, doa_loss):
     # [3,4,6,3]: 5e-4 — fifty-three training-mode BatchNormalizations deep the fp32 forward is already 1e-4 off at the outputs
     worst = _per_var(model, "resnet50 routed grad", g, ref_r["grad"], tol=5e-4 if len(O.resnet_plan(spec)) > 8 else 1e-4)
     print(f"[routing] resnet50 {blocks}: worst variable against the fp64 oracle WITH the library's decisions: {worst:.2e}")
+
+
+def test_full_size_first_block_gram_form_vs_stored_z_form(seldnet_config):
+    """At the headline size (32 clips of [3000,64,7]) the default first-block kernel gradient — dW = ka (G W + g b) + g kb + M from
+    the patch Gram matrix, no pre-BN tensor stored (conv_gram.hip) — against the same step with `conv1_gram = 0` (the pre-BN tensor
+    stored; BN / ReLU / pool backward and a dense kernel-gradient product from it).  The two forms pick a pooling window's maximum
+    from different fp32 values (the pre-BN accumulators resp. the BatchNormalised values), so they, too, differ in a few routing
+    decisions at near-ties (counted here from seld_debug_pool_routing) and hence by the same kind of error as either differs from the
+    fp64 oracle: 4 of 19.7 M decisions, worth 3.4e-3 of conv0.kernel's maximum — the bar for the conv / BN
+    variables is the golden fixture's (3 x the fp32 oracle's own error, floor 5e-4: the later blocks' routing sees the last-bit
+    differences of the first block's statistics); the GRU and head gradients do not pass through any routing: 1e-6."""
+    import ctypes as C
+    import os
+    from conftest import ROOT
+    from seld_amd import _lib, losses, train
+    B, T = 32, 3000
+    z = np.load(os.path.join(ROOT, "tests", "golden", "seldnet_full_b32_t3000_mse.npz"))
+    O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
+    args = (losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+
+    def run():
+        train.trainstep(model, x, (ys, yd), *args)
+        pos = torch.empty((B, T // 5, 16, 64), dtype=torch.uint8, device="cuda")
+        gate = torch.empty((B, T // 5, 16, 64), dtype=torch.uint8, device="cuda")
+        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, 0, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
+        return model.get_grads(), pos.cpu(), gate.cpu()
+
+    g_gram, pos_a, gate_a = run()
+    model.set_weights(w, st)
+    model.set_option("conv1_gram", 0)
+    g_z, pos_b, gate_b = run()
+    n_diff = int(((pos_a != pos_b) & (gate_a > 0) & (gate_b > 0)).sum()) + int((gate_a != gate_b).sum())
+    print(f"[routing] first block, Gram form vs stored-z form: {n_diff} of {pos_a.numel()} routing decisions differ")
+    assert n_diff <= 1e-5 * pos_a.numel()
+    bars = dict(zip([n for n, _, _ in model.variables], z["bar_fp32"])) if "bar_fp32" in z.files else {}
+    for n, off, sh in model.variables:
+        k = int(np.prod(sh))
+        if n.startswith("conv") and n.endswith("bias"):
+            continue
+        if n.startswith("conv") or n.startswith("bn"):
+            check(f"gram vs stored-z {n}", g_gram[off:off + k], g_z[off:off + k], tol=max(5e-4, 3.0 * float(bars.get(n, 0.0))))
+        else:
+            check(f"gram vs stored-z {n}", g_gram[off:off + k], g_z[off:off + k], tol=1e-6)
