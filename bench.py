@@ -238,11 +238,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    # rehearsal of the N > 1 code path on a one-GPU box (tests/test_dp_gpu.py::test_bench_two_ranks_rehearsal): every rank on device
+    # SELD_BENCH_DEVICE over the gloo backend (RCCL refuses two ranks on one device).  The driver's runs set neither variable.
+    if os.environ.get("SELD_BENCH_DEVICE") is not None:
+        local = int(os.environ["SELD_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dist = torch.distributed
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SELD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from seld_amd import losses, models, train
     from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only

@@ -102,3 +102,24 @@ def test_two_process_dp_step_equals_single_process_batch(mode, sync_bn):
             if not (name.startswith("conv") and name.endswith("bias")):
                 check(f"dp2 per-replica BN grad {name}", got[0][2][off:off + n], g.numpy()[off:off + n])
             off += n
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 code path (rank environment, barrier + max-over-ranks timing, the gradient buckets, the exposed-communication
+    leg, rank 0's JSON line) run as the driver launches it — `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` —
+    but with both ranks on the one test GPU over gloo (SELD_BENCH_DEVICE / SELD_BENCH_BACKEND): a crash in this path would cost the
+    round its scaling curve."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SELD_BENCH_DEVICE="0", SELD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 31500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4", "--frames", "300"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["comm"]["exposed_ms_per_step_by_rank"]) == 2
