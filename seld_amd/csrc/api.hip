@@ -109,7 +109,8 @@ struct seld_ctx {
     seld_allreduce_fn sync_fn = nullptr;          // synchronised BatchNorm (seld_set_sync_bn)
     void* sync_user = nullptr;
     int sync_world = 1;
-    double* sync_buf = nullptr;                   // [128] sums handed to sync_fn
+    double* sync_buf = nullptr;                   // [128] (resnet50_block: [16][128]) sums handed to sync_fn
+    bool sync_failed = false;                     // the all-reduce callback failed inside a helper: reported at the end of the pass
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
@@ -438,7 +439,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             seld_destroy(c);
             return fail(nullptr, SELD_ERR_HIP, "event creation failed");
         }
-    ALLOC(c->sync_buf, 128);
+    ALLOC(c->sync_buf, resn ? 16 * 128 : 128);
     for (int hd = 0; hd < 2; ++hd)
         for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
     {
@@ -785,7 +786,6 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     }
     if (c->arch.first_kind == SELD_FIRST_RESNET50) {
         // ---- resnet50_block stages (spec/RESNET50_BLOCK.md): every convolution a product on the fp32 MFMA GEMM
-        if (training && c->sync_fn) return fail(c, SELD_ERR_UNSUPPORTED, "synchronised BatchNorm is not wired into resnet50_block");
         PROF(c, "rn_stages_fwd");
         const float* X = in;      // [B,S,Win,Cin]
         for (auto& R : c->rn) {
@@ -813,6 +813,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             }
             X = R.out;
         }
+        if (c->sync_failed) { c->sync_failed = false; return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed"); }
         in = X;       // [B,S,2,1024] = [B,S,2048]
     }
     const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
@@ -963,14 +964,28 @@ static void wgrad_conv(seld_ctx* c, hipStream_t st, const float* A, int lda, con
 static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training) {
     int nbx = 0;
     if (training) launch_rn_bn_stats(st, cv.z, c->rn_part, &nbx, M, cv.Cout);
-    launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, c->params + cv.g_off, c->params + cv.be_off, c->state + cv.mm_off,
-                          c->state + cv.mv_off, cv.coef, cv.Cout, training);
+    float *g = c->params + cv.g_off, *be = c->params + cv.be_off, *mm = c->state + cv.mm_off, *mv = c->state + cv.mv_off;
+    if (training && c->sync_fn) {
+        // synchronised BatchNorm: this rank's per-chunk sums -> the host's all-reduce -> coefficients of the GLOBAL batch
+        const int nd = (cv.Cout + 63) / 64 * 128;
+        launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 1);
+        if (c->sync_fn(c->sync_user, c->sync_buf, nd, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
+        launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M * c->sync_world, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 2);
+        return;
+    }
+    launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
 }
 // backward of the same: dz = BN'(dy [mask > 0]) into `dz`, dgamma / dbeta into the gradient buffer
 static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, const float* mask, float* dz, int64_t M) {
     int nbx = 0;
     launch_rn_bn_bwd_reduce(st, cv.z, dy, mask, cv.coef, c->rn_part, &nbx, M, cv.Cout);
-    launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout);
+    if (c->sync_fn) {
+        const int nd = (cv.Cout + 63) / 64 * 128;
+        launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 1);
+        if (c->sync_fn(c->sync_user, c->sync_buf, nd, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
+        launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M * c->sync_world, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 2);
+    } else
+        launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout);
     launch_rn_bn_bwd_dz(st, cv.z, dy, mask, cv.coef, dz, M, cv.Cout);
 }
 
@@ -1124,6 +1139,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             g = dX;
             flip ^= 1;
         }
+        if (c->sync_failed) { c->sync_failed = false; return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed"); }
         dp = c->conv[0].dp;
     }
     if (c->arch.first_kind == SELD_FIRST_XCEPTION) {

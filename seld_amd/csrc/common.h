@@ -134,8 +134,9 @@ int launch_rn_bn_stats(hipStream_t st, const float* z, float* partial, int* nbx,
 int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* partial, int* nbx,
                             int64_t npix, int C);
 int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double count, const float* gamma, const float* beta, float* mov_mean,
-                          float* mov_var, float* coef, int C, int training);
-int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C);
+                          float* mov_var, float* coef, int C, int training, double* sums = nullptr, int phase = 0);
+int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C,
+                              double* sums = nullptr, int phase = 0);
 int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu);
 int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C);
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n);

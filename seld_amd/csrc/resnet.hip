@@ -118,20 +118,31 @@ int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, con
     return 0;
 }
 
-// one workgroup per 64-channel chunk: the chunk's partials [nbx][128] -> coef = [mean | invstd | scale | shift | c1 | c2] x C
+// one workgroup per 64-channel chunk: the chunk's partials [nbx][128] -> coef = [mean | invstd | scale | shift | c1 | c2] x C.
+// Synchronised BatchNorm (seld_set_sync_bn) splits it around the host's all-reduce: phase 1 stops after the chunk's sums
+// (sums[chunk][128] doubles), phase 2 starts from the all-reduced sums with the global count; phase 0 does both in one go.
 __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const float* __restrict__ partial, int nbx, double count, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ mov_mean,
-                                                             float* __restrict__ mov_var, float* __restrict__ coef, int C, int training) {
+                                                             float* __restrict__ mov_var, float* __restrict__ coef, int C, int training,
+                                                             double* __restrict__ sums, int phase) {
     __shared__ double red[256];
     __shared__ double tot[128];
     const int c0 = blockIdx.x * 64, tid = threadIdx.x;
-    if (training) {
+    if (training && phase != 2) {
         const int v = tid & 127, part = tid >> 7;
         double s = 0.0;
         for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
         red[tid] = s;
         __syncthreads();
         if (tid < 128) tot[tid] = red[tid] + red[128 + tid];
+        __syncthreads();
+        if (phase == 1) {
+            if (tid < 128) sums[(size_t)blockIdx.x * 128 + tid] = tot[tid];
+            return;
+        }
+    }
+    if (training && phase == 2) {
+        if (tid < 128) tot[tid] = sums[(size_t)blockIdx.x * 128 + tid];
         __syncthreads();
     }
     if (tid >= 64) return;
@@ -154,27 +165,44 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const float* __rest
     }
 }
 int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double count, const float* gamma, const float* beta, float* mov_mean,
-                          float* mov_var, float* coef, int C, int training) {
+                          float* mov_var, float* coef, int C, int training, double* sums, int phase) {
     hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, gamma, beta, mov_mean, mov_var, coef, C,
-                       training);
+                       training, sums, phase);
     return 0;
 }
+// backward: [sum dy' | sum dy' xhat] per chunk.  phase 0: dgamma / dbeta and c1 / c2 = the sums / count.  Synchronised BatchNorm:
+// phase 1 writes THIS rank's dgamma / dbeta (they are all-reduced with the gradient buffer like every other gradient) and the chunk's
+// sums for the host's all-reduce; phase 2 forms c1 / c2 from the global sums and the global count.
 __global__ __launch_bounds__(256) void rn_bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbx, double count, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, float* __restrict__ coef, int C) {
+                                                                 float* __restrict__ dbeta, float* __restrict__ coef, int C,
+                                                                 double* __restrict__ sums, int phase) {
     __shared__ double red[256];
     const int c0 = blockIdx.x * 64, tid = threadIdx.x, v = tid & 127, part = tid >> 7;
-    double s = 0.0;
-    for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
-    red[tid] = s;
-    __syncthreads();
-    if (tid >= 128) return;
-    const double t = red[tid] + red[128 + tid];
+    double t;
+    if (phase == 2) {
+        if (tid >= 128) return;
+        t = sums[(size_t)blockIdx.x * 128 + tid];
+    } else {
+        double s = 0.0;
+        for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
+        red[tid] = s;
+        __syncthreads();
+        if (tid >= 128) return;
+        t = red[tid] + red[128 + tid];
+        if (phase == 1) sums[(size_t)blockIdx.x * 128 + tid] = t;
+    }
     if (c0 + (tid & 63) >= C) return;
-    if (tid < 64) { dbeta[c0 + tid] = (float)t; coef[4 * C + c0 + tid] = (float)(t / count); }
-    else { dgamma[c0 + tid - 64] = (float)t; coef[5 * C + c0 + tid - 64] = (float)(t / count); }
+    if (tid < 64) {
+        if (phase != 2) dbeta[c0 + tid] = (float)t;
+        if (phase != 1) coef[4 * C + c0 + tid] = (float)(t / count);
+    } else {
+        if (phase != 2) dgamma[c0 + tid - 64] = (float)t;
+        if (phase != 1) coef[5 * C + c0 + tid - 64] = (float)(t / count);
+    }
 }
-int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C) {
-    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, dgamma, dbeta, coef, C);
+int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C,
+                              double* sums, int phase) {
+    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, dgamma, dbeta, coef, C, sums, phase);
     return 0;
 }
 

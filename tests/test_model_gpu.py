@@ -544,8 +544,8 @@ def test_parity_given_identical_routing(seldnet_config):
     _per_var(model, "routed grad", g, ref["grad"])
 
 
-@pytest.mark.parametrize("which", ["seldnet", "xception_gru"])
-def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xception_config, which):
+@pytest.mark.parametrize("which", ["seldnet", "xception_gru", "resnet50_gru"])
+def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xception_config, resnet50_config, which):
     """seld_set_sync_bn: two replicas (two ctxs on the one test GPU, driven by two host threads, their all-reduce callback a
     rendezvous that sums the two 128-double buffers on the host) each train on half of a batch; with synchronised BatchNorm the
     SUM of their gradient buffers, their outputs and their BN moving statistics must equal the oracle's single-process step on
@@ -556,13 +556,15 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
     from oracle import seldnet_oracle as O
     from seld_amd import _lib, losses, models, train
     import copy
-    seldnet_config = copy.deepcopy(seldnet_config if which == "seldnet" else xception_config)
-    if which != "seldnet":
+    seldnet_config = copy.deepcopy({"seldnet": seldnet_config, "xception_gru": xception_config, "resnet50_gru": resnet50_config}[which])
+    if which == "xception_gru":
         seldnet_config["FIRST_ARGS"]["block_num"] = 2
-    n_bn = 3 if which == "seldnet" else 1 + 3 * 2
+    if which == "resnet50_gru":
+        seldnet_config["FIRST_ARGS"]["block_num"] = [1, 1, 1, 1]     # 4 bottlenecks, each 3 + 1 (projection) BatchNormalizations
+    n_bn = {"seldnet": 3, "xception_gru": 1 + 3 * 2, "resnet50_gru": 1 + 4 * 4}[which]
     spec = O.Spec.from_config(seldnet_config)
     w, st = O.random_weights(spec, 0)
-    B, T = 4, 100
+    B, T = (4, 100) if which != "resnet50_gru" else (4, 300)
     x, ys, yd = O.synthetic_batch(B, T, seed=31)
     reps = [models.seldnet((B // 2, T, 64, 7), seldnet_config) for _ in range(2)]
     host = [None, None]
@@ -573,7 +575,7 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
     def make_cb(r):
         def cb(_user, buf, count, dtype, _stream):
             try:
-                assert dtype == _lib.SELD_DTYPE_F64 and count == 128
+                assert dtype == _lib.SELD_DTYPE_F64 and count % 128 == 0 and (count == 128 or which == "resnet50_gru")
                 from seld_amd.parallel import _F64Ptr
                 t = torch.as_tensor(_F64Ptr(int(buf), int(count)), device="cuda")
                 torch.cuda.current_stream().synchronize()        # the library enqueued the sums on this thread's current stream
@@ -622,7 +624,35 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
     ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64)
     check("syncbn sed", np.concatenate([out[0][0], out[1][0]]), ref["sed"])
     check("syncbn doa", np.concatenate([out[0][1], out[1][1]]), ref["doa"])
-    _per_var(reps[0], "syncbn grad", out[0][2] + out[1][2], ref["grad"])
+    if which == "resnet50_gru":
+        # the block's ReLU gates make its gradients routing-sensitive (test_resnet50_gru_train_step): against the oracle GIVEN the two
+        # replicas' decisions (their gates and stem routing, concatenated over the batch)
+        S = T // 5
+        routing = {}
+        pos_l, gate_l = [], []
+        for m in reps:
+            pos = torch.empty((B // 2, S, 16, 64), dtype=torch.uint8, device="cuda")
+            gate = torch.empty((B // 2, S, 16, 64), dtype=torch.uint8, device="cuda")
+            _lib.check(m.lib.seld_debug_pool_routing(m.ctx, 0, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), m.ctx)
+            pos_l.append(pos.cpu().to(torch.int64)); gate_l.append(gate.cpu().bool())
+        routing[0] = (torch.cat(pos_l), torch.cat(gate_l))
+        buf = torch.empty((B // 2) * S * 16 * 128, device="cuda")
+        cnt = C.c_int64()
+        free = {}
+        O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64, record_routing=free)
+        for bi, (s_, b, ci, wd, stf, proj) in enumerate(O.resnet_plan(spec)):
+            for wh, nm in enumerate(("y0", "y1", "out")):
+                key = f"rn{s_}.{b}.{nm}"
+                parts = []
+                for m in reps:
+                    _lib.check(m.lib.seld_debug_relu_output(m.ctx, bi, wh, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), m.ctx)
+                    shp = (B // 2,) + tuple(free[key]["gate"].shape[1:])
+                    parts.append((buf[:cnt.value] > 0).cpu().reshape(shp))
+                routing[key] = torch.cat(parts)
+        ref_r = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64, routing=routing)
+        _per_var(reps[0], "syncbn routed grad", out[0][2] + out[1][2], ref_r["grad"])
+    else:
+        _per_var(reps[0], "syncbn grad", out[0][2] + out[1][2], ref["grad"])
     check("syncbn moving stats rank0", out[0][3], ref["new_state"])
     check("syncbn moving stats rank1", out[1][3], ref["new_state"])
     # gradient buckets: last GRU layer + heads | earlier GRU layers ... | conv/BN
