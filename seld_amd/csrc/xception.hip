@@ -26,7 +26,9 @@ __device__ __forceinline__ float4 fma4v(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
-// one thread per (pixel, group of 4 channels); C = 64 -> 16 groups; k [9][64] (Keras depthwise_kernel [3,3,64,1])
+// one thread per (pixel, group of 4 channels); C = 64 -> 16 groups; k [9][64] (Keras depthwise_kernel [3,3,64,1]).  (A sliding-window
+// form — a thread walks image rows, keeps its 3 x 3 neighbourhood in registers and loads one new row per output — was measured: 1.8
+// against 1.4 ms per step forward: the nine L1-served loads of 4.9 M independent threads beat a third of the loads from 0.3 M.)
 template <bool BWD>
 __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ src, const float* __restrict__ k, const float* __restrict__ xin,
                                                     const float* __restrict__ add, float* __restrict__ dst, int64_t npix, int H, int W) {
