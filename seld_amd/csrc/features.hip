@@ -339,7 +339,10 @@ __device__ __forceinline__ void feat_load_pair(float2 (&v)[1][WF<LOGN>::NB4][4],
     }
 }
 
-#define FEAT_WAVES 16
+#define FEAT_WAVES_MAX 16
+// waves per workgroup of feat_wave_kernel: 16 (four per SIMD, 128 registers) except the 1 024-point mic kernel, whose four spectra
+// spill at that cap: 12 (0.080 against 0.090 ms per clip; foa at n_fft 512: 0.034 with 16 against 0.038 with 12)
+#define FEAT_WAVES_OF(MODE_, LOGN_) (((MODE_) == 1 && (LOGN_) == 10) ? 12 : 16)
 // LDS of one wave: ONE transform buffer; the same bytes later hold four per-bin value planes [4][NB + 3] and then the staged frame
 static size_t feat_wave_bytes(int n_fft, int n_mels, int c_out) {
     const size_t fft = (size_t)n_fft * sizeof(float2), planes = (size_t)4 * (n_fft / 2 + 4) * sizeof(float);
@@ -356,12 +359,13 @@ static size_t feat_wave_bytes(int n_fft, int n_mels, int c_out) {
 // The mel filters are read 16 bytes at a time: filter m covers cnt4[m] aligned float4 chunks of a plane from bin start4[m]
 // (a multiple of 4), its weights zero-padded to match (seld_feat_create).
 template <int MODE, int LOGN>
-__global__ __launch_bounds__(64 * FEAT_WAVES, 1) void feat_wave_kernel(
+__global__ __launch_bounds__(64 * FEAT_WAVES_OF(MODE, LOGN), 1) void feat_wave_kernel(
     const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, int n_melw4, int maxc4,
     const float* __restrict__ win_g, const float2* __restrict__ tw_g, const int* __restrict__ mel_start4,
     const int* __restrict__ mel_cnt4, const int* __restrict__ mel_off4, const float* __restrict__ mel_w4, float* __restrict__ out,
     float* __restrict__ gmax, int wave_bytes, int dbg, const int* __restrict__ trips_g) {
     using G = WF<LOGN>;
+    constexpr int FEAT_WAVES = FEAT_WAVES_OF(MODE, LOGN);
     constexpr int N = G::N, NB = G::NB, NBP = G::NBP, NBI = G::NBI, NB4 = G::NB4;
     constexpr int C_OUT = MODE == 0 ? 7 : 10;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1085,13 +1089,14 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     if (!launched && f->logn >= 8 && f->logn <= 10 && f->use_wave_kernel && f->n_mels <= 128 && f->n_mels <= N) {
         const size_t tables = (size_t)(N / 2) * sizeof(float2) + (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) +
                               (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
-        const size_t wb = feat_wave_bytes(N, f->n_mels, f->mode == 0 ? 7 : 10), smem = tables + FEAT_WAVES * wb;
-        int64_t blocks = (T + FEAT_WAVES - 1) / FEAT_WAVES;
+        const int fw = FEAT_WAVES_OF(f->mode, f->logn);
+        const size_t wb = feat_wave_bytes(N, f->n_mels, f->mode == 0 ? 7 : 10), smem = tables + fw * wb;
+        int64_t blocks = (T + fw - 1) / fw;
         if (blocks > 1024) blocks = 1024;
 #define FEAT_WAVE_CASE(MODE_, LOGN_)                                                                                            \
         {                                                                                                                       \
             hipFuncSetAttribute(reinterpret_cast<const void*>(feat_wave_kernel<MODE_, LOGN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            hipLaunchKernelGGL((feat_wave_kernel<MODE_, LOGN_>), dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * FEAT_WAVES), smem, st, wav, n_samples, T, \
+            hipLaunchKernelGGL((feat_wave_kernel<MODE_, LOGN_>), dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * FEAT_WAVES_OF(MODE_, LOGN_)), smem, st, wav, n_samples, T, \
                                f->hop, f->n_mels, f->n_melw4, f->maxc4, f->win, f->tw, f->mel_start4, f->mel_cnt4, f->mel_off4, f->mel_w4, \
                                out, f->gmax, (int)wb, f->dbg, f->trips);                                                                      \
             launched = true; nparts = (int)blocks;                                                                              \
