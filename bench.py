@@ -75,6 +75,8 @@ def kernel_work(name, B, T, F=64, C=7):
         # xception_block middle flow (spec/XCEPTION_BLOCK.md), per launch group on [B,S,16,64]: depthwise 3x3 = read + write the
         # tensor; pointwise 64 x 64 product; BatchNorm passes
         "xc_depthwise_fwd": ("hbm", 4 * 2 * px2 * 64), "xc_pointwise_fwd": ("mfma", 2 * px2 * 64 * 64),
+        # fused unit forward (default): read the unit's input once, write the depthwise output and z
+        "xc_unit_fwd": ("hbm", 4 * 3 * px2 * 64),
         "xc_bn_fwd": ("hbm", 4 * 3 * px2 * 64), "xc_bn_bwd": ("hbm", 4 * 5 * px2 * 64),
         "xc_pointwise_bwd": ("mfma", 2 * 2 * px2 * 64 * 64), "xc_depthwise_bwd": ("hbm", 4 * 5 * px2 * 64),
     }

@@ -90,6 +90,7 @@ struct seld_ctx {
     unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
     unsigned short *wsp_fwd[SELD_MAX_LAYERS] = {}, *wsp_bwd[SELD_MAX_LAYERS] = {};
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
+    bool xc_fused_fwd = true;              // xception_block: depthwise + pointwise + BN statistics of a unit in one kernel
     bool gru_wgrad_batch = true;           // a GRU layer's four weight-gradient products in one launch (+ one combine)
     bool gram_active = false;              // the last training forward took that path
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
@@ -507,6 +508,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -751,7 +753,18 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         for (size_t i = 0; i < c->xc.size(); ++i) {
             XcUnit& U = c->xc[i];
             const size_t b = i / 3, u = i % 3;
-            const float* uin = u == 0 ? c->xc_x[b] : c->xc[i - 1].a;
+            // with the fused unit kernel the previous unit's BatchNormalization is applied on load (relu(z scale + shift) of ITS pre-BN
+            // tensor): units 0 and 1 of a module then never materialise their normalised output
+            const bool fold = c->xc_fused_fwd && u > 0;
+            const float* uin = u == 0 ? c->xc_x[b] : (fold ? c->xc[i - 1].z : c->xc[i - 1].a);
+            const float* aff = fold ? c->xc[i - 1].scale : nullptr;      // [scale 64 | shift 64]
+            int np = 0;
+            if (c->xc_fused_fwd) {
+                // depthwise + pointwise + BatchNorm statistics in one pass over the unit's input (xception.hip: xc_unit_fwd_kernel)
+                PROF2(c, "xc_unit_fwd");
+                if (launch_xc_unit_fwd(st, uin, c->params + U.dw_off, c->params + U.pw_off, U.dwo, U.z, training ? c->xc_part : nullptr, &np, B, S, 16, aff))
+                    return fail(c, SELD_ERR_UNSUPPORTED, "xc_unit_fwd");
+            } else {
             {
                 PROF2(c, "xc_depthwise_fwd");
                 launch_dw3x3_fwd(st, uin, c->params + U.dw_off, U.dwo, B, S, 16);       // ReLU on load, no bias
@@ -760,10 +773,10 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 PROF2(c, "xc_pointwise_fwd");
                 launch_gemm(st, U.dwo, 64, c->params + U.pw_off, 64, nullptr, U.z, 64, (int)npix, 64, 64, 0, 0, 0);
             }
+            }
             PROF2(c, "xc_bn_fwd");
             if (training) {
-                int np = 0;
-                launch_xc_bn_stats(st, U.z, c->xc_part, &np, npix);
+                if (!c->xc_fused_fwd) launch_xc_bn_stats(st, U.z, c->xc_part, &np, npix);
                 if (c->sync_fn) {      // synchronised BatchNorm: global sums through the host's all-reduce (see the conv blocks above)
                     launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf);
                     if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
@@ -776,7 +789,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 launch_bn_eval_coeffs(st, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off, c->state + U.mv_off, U.scale,
                                       U.shift, 64);
             }
-            launch_xc_bn_apply(st, U.z, U.scale, U.shift, u == 2 ? c->xc_x[b] : nullptr, u == 2 ? c->xc_x[b + 1] : U.a, npix);
+            if (u == 2 || !c->xc_fused_fwd)
+                launch_xc_bn_apply(st, U.z, U.scale, U.shift, u == 2 ? c->xc_x[b] : nullptr, u == 2 ? c->xc_x[b + 1] : U.a, npix);
         }
         // exit: ReLU -> MaxPooling2D((1, 8)) = the BN+ReLU+pool kernel with identity coefficients
         PROF2(c, "xc_exit_pool");
@@ -1158,7 +1172,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const float* gY = X;
             for (int u = 2; u >= 0; --u) {
                 XcUnit& U = c->xc[(size_t)b * 3 + u];
-                const float* uin = u == 0 ? c->xc_x[b] : c->xc[(size_t)b * 3 + u - 1].a;
+                const bool fold = c->xc_fused_fwd && u > 0;       // the forward applied the previous unit's BatchNormalization on load
+                const float* uin = u == 0 ? c->xc_x[b] : (fold ? c->xc[(size_t)b * 3 + u - 1].z : c->xc[(size_t)b * 3 + u - 1].a);
+                const float* aff = fold ? c->xc[(size_t)b * 3 + u - 1].scale : nullptr;
                 int np = 0, ns = 0;
                 {
                     PROF2(c, "xc_bn_bwd");
@@ -1180,11 +1196,11 @@ static int backward_impl(seld_ctx* c, const float* x) {
                     launch_gemm(st, c->dzbuf, 64, c->params + U.pw_off, 64, nullptr, F1, 64, (int)npix, 64, 64, 1, 0, 0);
                 }
                 PROF2(c, "xc_depthwise_bwd");
-                launch_dw3x3_bwd_w(st, uin, F1, c->xc_slab, &ns, B, S, 16);
+                launch_dw3x3_bwd_w(st, uin, F1, c->xc_slab, &ns, B, S, 16, aff);
                 launch_reduce_slabs(st, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
                 // gradient w.r.t. the unit's input, through its ReLU; the module's first unit adds the residual branch's X
                 float* gin = (u == 0 && b == 0) ? c->conv[0].dp : F2;
-                launch_dw3x3_bwd_data(st, F1, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16);
+                launch_dw3x3_bwd_data(st, F1, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16, aff);
                 gY = gin;
             }
             if (b > 0) { float* t_ = X; X = F2; F2 = t_; }      // the module's input gradient is the next module's output gradient

@@ -141,10 +141,13 @@ int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const 
 int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C);
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n);
 // xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
+int launch_xc_unit_fwd(hipStream_t st, const float* x, const float* kdw, const float* wpw, float* dwo, float* z, float* partial, int* npartial,
+                       int B, int H, int W, const float* aff = nullptr);
 int xc_partial_capacity();
-int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W);
-int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H, int W);
-int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W);
+int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W, const float* aff = nullptr);
+int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H, int W,
+                          const float* aff = nullptr);
+int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W, const float* aff = nullptr);
 int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npartial, int64_t npix);
 int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
                             int* npartial, int64_t npix);

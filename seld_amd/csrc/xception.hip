@@ -29,9 +29,12 @@ __device__ __forceinline__ float4 fma4v(float4 a, float4 b, float4 c) {
 // one thread per (pixel, group of 4 channels); C = 64 -> 16 groups; k [9][64] (Keras depthwise_kernel [3,3,64,1]).  (A sliding-window
 // form — a thread walks image rows, keeps its 3 x 3 neighbourhood in registers and loads one new row per output — was measured: 1.8
 // against 1.4 ms per step forward: the nine L1-served loads of 4.9 M independent threads beat a third of the loads from 0.3 M.)
-template <bool BWD>
+// `aff` (optional, [scale 64 | shift 64]): the unit's input is relu(x scale + shift) of a stored pre-BN tensor x instead of a stored
+// activation (the previous unit's BatchNormalization folded into this unit's loads): forward source / backward gate source
+template <bool BWD, bool AFF>
 __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ src, const float* __restrict__ k, const float* __restrict__ xin,
-                                                    const float* __restrict__ add, float* __restrict__ dst, int64_t npix, int H, int W) {
+                                                    const float* __restrict__ add, float* __restrict__ dst, int64_t npix, int H, int W,
+                                                    const float* __restrict__ aff) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= npix * 16) return;
     const int g = (int)(gid & 15);
@@ -45,12 +48,14 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ sr
         const int tt = BWD ? t - dt : t + dt, ff = BWD ? f - df : f + df;
         if (tt >= 0 && tt < H && ff >= 0 && ff < W) {
             float4 v = *reinterpret_cast<const float4*>(src + (p + (int64_t)(BWD ? -1 : 1) * (dt * W + df)) * 64 + 4 * g);
+            if (!BWD && AFF) v = fma4v(v, reinterpret_cast<const float4*>(aff)[g], reinterpret_cast<const float4*>(aff + 64)[g]);
             if (!BWD) v = relu4(v);
             acc = fma4v(reinterpret_cast<const float4*>(k + tap * 64)[g], v, acc);
         }
     }
     if (BWD) {
-        const float4 xv = *reinterpret_cast<const float4*>(xin + p * 64 + 4 * g);
+        float4 xv = *reinterpret_cast<const float4*>(xin + p * 64 + 4 * g);
+        if (AFF) xv = fma4v(xv, reinterpret_cast<const float4*>(aff)[g], reinterpret_cast<const float4*>(aff + 64)[g]);
         acc = make_float4(xv.x > 0.f ? acc.x : 0.f, xv.y > 0.f ? acc.y : 0.f, xv.z > 0.f ? acc.z : 0.f, xv.w > 0.f ? acc.w : 0.f);
         if (add) {
             const float4 a = *reinterpret_cast<const float4*>(add + p * 64 + 4 * g);
@@ -60,15 +65,17 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ sr
     *reinterpret_cast<float4*>(dst + p * 64 + 4 * g) = acc;
 }
 
-int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W) {
+int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W, const float* aff) {
     const int64_t npix = (int64_t)B * H * W;
-    hipLaunchKernelGGL(dw3x3_kernel<false>, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W);
+    if (aff) hipLaunchKernelGGL((dw3x3_kernel<false, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff);
+    else hipLaunchKernelGGL((dw3x3_kernel<false, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff);
     return 0;
 }
 int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H,
-                          int W) {
+                          int W, const float* aff) {
     const int64_t npix = (int64_t)B * H * W;
-    hipLaunchKernelGGL(dw3x3_kernel<true>, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W);
+    if (aff) hipLaunchKernelGGL((dw3x3_kernel<true, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff);
+    else hipLaunchKernelGGL((dw3x3_kernel<true, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff);
     return 0;
 }
 
@@ -77,14 +84,17 @@ int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const
 // and keeps the 3 x 3 x 4 sums in registers; the three input rows it needs are read once each per output row through L1 (the
 // neighbouring columns belong to the neighbouring threads of the same workgroup).  Slots combined through LDS in a fixed order
 // -> slab[blockIdx][9][64]
+template <bool AFF>
 __global__ __launch_bounds__(256) void dw3x3_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab,
-                                                          int64_t nrows, int H, int W) {
+                                                          int64_t nrows, int H, int W, const float* __restrict__ aff) {
     __shared__ float red[16][9 * 64 + 4];
     const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
     float4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 asc = make_float4(1.f, 1.f, 1.f, 1.f), ash = zero4;          // identity unless the input is a pre-BN tensor (see dw3x3_kernel)
+    if (AFF) { asc = reinterpret_cast<const float4*>(aff)[g]; ash = reinterpret_cast<const float4*>(aff + 64)[g]; }
     for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
         const int t = (int)(r % H);
         for (int f = slot; f < W; f += 16) {
@@ -96,6 +106,14 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_w_kernel(const float* __restric
                 const int dt = tap / 3 - 1, df = tap % 3 - 1;
                 const bool ok = t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W;
                 v[tap] = ok ? *reinterpret_cast<const float4*>(x + (p + dt * W + df) * 64 + 4 * g) : zero4;
+            }
+            if (AFF) {                                   // after all nine loads are in flight; padding stays 0 (the ACTIVATION is zero-padded)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dt = tap / 3 - 1, df = tap % 3 - 1;
+                    const bool ok = t + dt >= 0 && t + dt < H && f + df >= 0 && f + df < W;
+                    if (ok) v[tap] = fma4v(v[tap], asc, ash);
+                }
             }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) acc[tap] = fma4v(relu4(v[tap]), d, acc[tap]);
@@ -112,11 +130,122 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_w_kernel(const float* __restric
     }
 }
 
-int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W) {
+int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W, const float* aff) {
     const int64_t nrows = (int64_t)B * H;
     int64_t blocks = nrows < XC_MAX_PARTIAL ? nrows : XC_MAX_PARTIAL;
-    hipLaunchKernelGGL(dw3x3_bwd_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, slab, nrows, H, W);
+    if (aff) hipLaunchKernelGGL(dw3x3_bwd_w_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, slab, nrows, H, W, aff);
+    else hipLaunchKernelGGL(dw3x3_bwd_w_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, slab, nrows, H, W, aff);
     *nslab = (int)blocks;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One separable-convolution unit's forward in ONE pass (W = 16):  x -> ReLU -> depthwise 3x3 -> dwo (stored: the backward's pointwise
+// kernel gradient needs it) -> pointwise 64 x 64 on the fp32 MFMA -> z, with BatchNorm's [sum z | sum z^2] partials from the
+// accumulators.  Run as three kernels (depthwise, GEMM, statistics) the unit moves 550 MB through HBM; this way 236 MB.
+// Tile = 8 image rows x 16 columns = 128 pixels, 4 waves; LDS: the ReLU'd input rows with a one-row halo [10][16][64] (40 KB) and
+// the depthwise output TRANSPOSED [64 ch][128 px + pad] (33 KB) = the MFMA's A operand (lane = pixel, k = channel: one ds_read_b32
+// per MFMA, conflict-free); the pointwise weights live in 64 registers per lane (B operand).  Persistent workgroups, two per CU:
+// one's loads and depthwise phase run beside the other's MFMAs.
+#define XU_ROWS 8
+#define XU_LDA 129      // odd row stride: the transposed depthwise writes (row 4 g + j, 16 groups per wave) spread over the banks
+#define XU_MAX_BLOCKS 512
+__global__ __launch_bounds__(256, 2) void xc_unit_fwd_kernel(const float* __restrict__ x, const float* __restrict__ kdw, const float* __restrict__ wpw,
+                                                             float* __restrict__ dwo, float* __restrict__ z, float* __restrict__ partial, int B, int H,
+                                                             int want_stats, const float* __restrict__ aff) {
+    constexpr int W = 16, TP = XU_ROWS * W;
+    extern __shared__ __attribute__((aligned(16))) float xu_smem[];
+    float* R = xu_smem;                          // [(XU_ROWS + 2)][16][64]
+    float* At = R + (XU_ROWS + 2) * W * 64;      // [64][XU_LDA]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kk = lane >> 5;
+    const int g = tid & 15, pslot = tid >> 4;
+    float4 kw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kw[i] = reinterpret_cast<const float4*>(kdw + i * 64)[g];
+    float wreg[2][32];                           // B operand: W[2 s + kk][32 c + li]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s_ = 0; s_ < 32; ++s_) wreg[c][s_] = wpw[(2 * s_ + kk) * 64 + 32 * c + li];
+    const int tiles_per_img = (H + XU_ROWS - 1) / XU_ROWS, ntiles = B * tiles_per_img;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * XU_ROWS;
+        // ---- input rows t0 - 1 .. t0 + XU_ROWS (zeros outside the image), ReLU on the way in
+        for (int i = tid; i < (XU_ROWS + 2) * W * 16; i += 256) {
+            const int rr = i / (W * 16), rem = i - rr * (W * 16);
+            const int t = t0 - 1 + rr;
+            float4 v = zero4;
+            if (t >= 0 && t < H) {
+                v = reinterpret_cast<const float4*>(x + ((size_t)(b * H + t) * W) * 64)[rem];
+                if (aff) v = fma4v(v, reinterpret_cast<const float4*>(aff)[rem & 15], reinterpret_cast<const float4*>(aff + 64)[rem & 15]);
+                v = relu4(v);
+            }
+            reinterpret_cast<float4*>(R)[i] = v;
+        }
+        __syncthreads();
+        // ---- depthwise: pixel p = 16 it + pslot (row p >> 4, column p & 15), channels 4 g ..
+#pragma unroll
+        for (int it = 0; it < TP / 16; ++it) {
+            const int p = 16 * it + pslot, r = p >> 4, f = p & 15;
+            float4 acc = zero4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dt = tap / 3, df = tap % 3 - 1;           // region row r + dt holds image row t0 + r + dt - 1
+                if (f + df >= 0 && f + df < W) acc = fma4v(kw[tap], reinterpret_cast<const float4*>(R + ((r + dt) * W + f + df) * 64)[g], acc);
+            }
+            if (t0 + r < H) *reinterpret_cast<float4*>(dwo + ((size_t)(b * H + t0 + r) * W + f) * 64 + 4 * g) = acc;
+            At[(4 * g + 0) * XU_LDA + p] = acc.x; At[(4 * g + 1) * XU_LDA + p] = acc.y;
+            At[(4 * g + 2) * XU_LDA + p] = acc.z; At[(4 * g + 3) * XU_LDA + p] = acc.w;
+        }
+        __syncthreads();
+        // ---- pointwise: wave w = pixels 32 w .. 32 w + 31 of the tile, two 32-channel output tiles
+        f32x16 acc[2] = {zero16(), zero16()};
+        const float* arow = At + kk * XU_LDA + 32 * wave + li;
+#pragma unroll
+        for (int s_ = 0; s_ < 32; ++s_) {
+            const float a = arow[2 * s_ * XU_LDA];
+            acc[0] = MFMA_F32_32x32x2(a, wreg[0][s_], acc[0]);
+            acc[1] = MFMA_F32_32x32x2(a, wreg[1][s_], acc[1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pq = 32 * wave + 8 * q + 4 * kk;          // pixels pq .. pq + 3 of the tile in registers 4 q .. 4 q + 3
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t0 + ((pq + j) >> 4) < H) { s1[c] += acc[c][4 * q + j]; s2[c] = fmaf(acc[c][4 * q + j], acc[c][4 * q + j], s2[c]); }
+                const float4 o = quad_transpose4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3], li);
+                const int p = pq + (li & 3);
+                if (t0 + (p >> 4) < H)
+                    *reinterpret_cast<float4*>(z + ((size_t)(b * H + t0 + (p >> 4)) * W + (p & 15)) * 64 + 32 * c + (li & ~3)) = o;
+            }
+        __syncthreads();        // At and R are free for the next tile
+    }
+    if (want_stats) {
+        float* red = R;          // [4][128]
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { s1[c] += __shfl_xor(s1[c], 32); s2[c] += __shfl_xor(s2[c], 32); }
+        if (kk == 0) {
+            red[wave * 128 + li] = s1[0]; red[wave * 128 + 32 + li] = s1[1];
+            red[wave * 128 + 64 + li] = s2[0]; red[wave * 128 + 96 + li] = s2[1];
+        }
+        __syncthreads();
+        if (tid < 128) partial[(size_t)blockIdx.x * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+    }
+}
+int launch_xc_unit_fwd(hipStream_t st, const float* x, const float* kdw, const float* wpw, float* dwo, float* z, float* partial, int* npartial,
+                       int B, int H, int W, const float* aff) {
+    if (W != 16) return -2;
+    const int ntiles = B * ((H + XU_ROWS - 1) / XU_ROWS);
+    const int grid = ntiles < XU_MAX_BLOCKS ? ntiles : XU_MAX_BLOCKS;
+    const size_t smem = (size_t)((XU_ROWS + 2) * 16 * 64 + 64 * XU_LDA) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(xc_unit_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(xc_unit_fwd_kernel, dim3(grid), dim3(256), smem, st, x, kdw, wpw, dwo, z, partial, B, H, partial ? 1 : 0, aff);
+    if (npartial) *npartial = grid;
     return 0;
 }
 
