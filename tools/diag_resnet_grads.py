@@ -30,12 +30,3 @@ print(f"{'variable':28s} {'|ref|max':>10s} {'hip':>10s} {'fp32 oracle':>12s}")
 for n, off, sh in model.variables:
     k = int(np.prod(sh)); r = r64[off:off + k]; den = np.abs(r).max() or 1.0
     print(f"{n:28s} {den:10.3e} {np.abs(g[off:off+k]-r).max()/den:10.3e} {np.abs(r32[off:off+k]-r).max()/den:12.3e}")
-dd = os.environ.get("SELD_DEBUG_DUMP")
-if dd:
-    for nm, var in (("dbeta1", f"rn3.0.c1.beta"), ("dgamma1", "rn3.0.c1.gamma")):
-        v = np.fromfile(f"{dd}/{nm}.bin", np.float32)
-        n, off, sh = next(t for t in model.variables if t[0] == var)
-        r = r64[off:off + v.size]
-        print(nm, "dump vs final grads", np.abs(v - g[off:off + v.size]).max(), " dump vs oracle rel", np.abs(v - r).max() / np.abs(r).max())
-        bad = np.argsort(-np.abs(v - r))[:8]
-        print("  worst channels", bad, (v - r)[bad], r[bad])
