@@ -39,6 +39,7 @@ struct RnConv {
     int k = 1, Cin = 0, Cout = 0;
     int64_t w_off = 0, g_off = 0, be_off = 0, mm_off = 0, mv_off = 0;
     float *col = nullptr, *z = nullptr, *coef = nullptr;     // im2col of the input (k = 3), pre-BN output, [mean|invstd|scale|shift|c1|c2] x Cout
+    unsigned short *wsp = nullptr, *wsp_t = nullptr;         // pre-split bf16 planes of the kernel / its transpose (shapes the split-bf16 GEMM takes)
 };
 struct RnBlock {
     int Cin, w, stride_f, Win, Wout;
@@ -99,6 +100,8 @@ struct seld_ctx {
     int conv1_pool_fused = 1;              // 1: first block's (5,4) pool window reduction inside the conv epilogue (conv_pool.hip)
     int heads_fused = 1;                   // 1: heads of two LINEAR-then-activated layers run as one product with W1 W2 (see heads_lin)
     float *weff = nullptr, *dy_all = nullptr, *headF = nullptr;   // [K + 1][NT], [rows][NT], [K][NT] + [NT]
+    int rn_split_bf16 = 1;                 // resnet50_block: products with N % 128 == 0 (stages 2-3, the expand / shortcut convolutions of
+                                           // stages 0-1) on the split-bf16 kernels; 0: everything on the fp32 MFMA GEMM
     int gemm_split_bf16 = 1;               // 1: GRU input projections / heads' first Conv1D (and their input gradients) on the
                                            //    split-bf16 GEMM (gemm_sb.hip) where the shapes allow; 0: exact-fp32 MFMA GEMM
     unsigned short* gsplit = nullptr;      // pre-split weight operands of those products, refreshed by every forward
@@ -394,6 +397,13 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             mx_out = std::max(mx_out, M * 4 * R.w); mx_w = std::max(mx_w, M * R.w); mx_col = std::max(mx_col, M * 9 * R.w);
             mx_in = std::max(mx_in, (size_t)B * S * R.Win * R.Cin);
         }
+        for (auto& R : c->rn)
+            for (RnConv* cv : {&R.c[0], &R.c[1], &R.c[2], &R.sc}) {
+                const int K = cv->k * cv->k * cv->Cin, N = cv->Cout;
+                if (!N) continue;
+                if (rn_sb_fwd_ok(K, N)) ALLOC(cv->wsp, gemm_sb_split_elems(K, N));
+                if (rn_sb_dgrad_ok(K, N)) ALLOC(cv->wsp_t, gemm_sb_split_elems(K, N));
+            }
         ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
         ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
         ALLOC(c->rn_bz, mx_out); ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bb, mx_w); ALLOC(c->rn_bcol, mx_col);
@@ -509,6 +519,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
+    if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -799,26 +810,42 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         in = c->xc_feat;
     }
     if (c->arch.first_kind == SELD_FIRST_RESNET50) {
-        // ---- resnet50_block stages (spec/RESNET50_BLOCK.md): every convolution a product on the fp32 MFMA GEMM
+        // ---- resnet50_block stages (spec/RESNET50_BLOCK.md): every convolution a product (resnet.hip: launch_rn_product_*)
         PROF(c, "rn_stages_fwd");
+        const bool sb = c->rn_split_bf16 != 0;
+        if (sb) {      // this step's weight planes, 16 operands per launch
+            const float* src[16]; unsigned short* dst[16]; int ldb[16], tb[16], Ks[16], Ns[16];
+            int n = 0;
+            auto add = [&](const float* w, unsigned short* d, int ld, int transb, int k, int nn) {
+                src[n] = w; dst[n] = d; ldb[n] = ld; tb[n] = transb; Ks[n] = k; Ns[n] = nn;
+                if (++n == 16) { launch_gemm_split_b(st, n, src, dst, ldb, tb, Ks, Ns); n = 0; }
+            };
+            for (auto& R : c->rn)
+                for (RnConv* cv : {&R.c[0], &R.c[1], &R.c[2], &R.sc}) {
+                    const int K = cv->k * cv->k * cv->Cin, N = cv->Cout;
+                    if (cv->wsp) add(c->params + cv->w_off, cv->wsp, N, 0, K, N);
+                    if (cv->wsp_t && save) add(c->params + cv->w_off, cv->wsp_t, N, 1, N, K);
+                }
+            if (n) launch_gemm_split_b(st, n, src, dst, ldb, tb, Ks, Ns);
+        }
         const float* X = in;      // [B,S,Win,Cin]
         for (auto& R : c->rn) {
             const int64_t M = (int64_t)B * S * R.Wout;
             const int w = R.w;
             // 1x1 (frequency stride = doubled row stride of the operand), BN, ReLU
-            launch_gemm(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, w, nullptr, R.c[0].z, w, (int)M, w, R.Cin, 0, 0, 0);
+            launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w);
             rn_bn(c, st, R.c[0], M, training);
             launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1);
             // 3x3 through im2col, BN, ReLU
             launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
-            launch_gemm(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, w, nullptr, R.c[1].z, w, (int)M, w, 9 * w, 0, 0, 0);
+            launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
             rn_bn(c, st, R.c[1], M, training);
             launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1);
             // 1x1 expand, BN; shortcut; out = ReLU(y + r)
-            launch_gemm(st, R.y1, w, c->params + R.c[2].w_off, 4 * w, nullptr, R.c[2].z, 4 * w, (int)M, 4 * w, w, 0, 0, 0);
+            launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w);
             rn_bn(c, st, R.c[2], M, training);
             if (R.proj) {
-                launch_gemm(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, 4 * w, nullptr, R.sc.z, 4 * w, (int)M, 4 * w, R.Cin, 0, 0, 0);
+                launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
                 rn_bn(c, st, R.sc, M, training);
                 launch_rn_bn_apply(st, R.sc.z, R.sc.coef, nullptr, R.out, M, 4 * w, 0);
                 launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, R.out, R.out, M, 4 * w, 1);
@@ -967,10 +994,8 @@ static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A
 
 // dW[K1,N] = A^T B for a bias-free convolution of a FIRST block (xception / resnet50), as many short splits as the slab buffer holds
 static void wgrad_conv(seld_ctx* c, hipStream_t st, const float* A, int lda, const float* Bm, int M, int K1, int N, int64_t w_off) {
-    int ns = 0;
-    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384) / ((int64_t)K1 * N + N);
-    launch_gemm_tn(st, A, lda, Bm, N, c->tn_slab, &ns, M, K1, N, 0, 0, 0, (int)std::max<int64_t>(1, std::min<int64_t>(cap, 512)));
-    launch_reduce_slabs2(st, c->tn_slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, nullptr, 0);
+    launch_rn_product_wgrad(st, A, lda, Bm, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + w_off, M, K1, N,
+                            c->rn_split_bf16);
 }
 
 
@@ -1119,6 +1144,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
     if (c->arch.first_kind == SELD_FIRST_RESNET50) {
         // ---- resnet50_block backward, blocks last to first; g = gradient w.r.t. the block's output
         PROF(c, "rn_stages_bwd");
+        const bool sb = c->rn_split_bf16 != 0;
         const float* g = dout;
         int flip = 0;
         for (int bi = (int)c->rn.size() - 1; bi >= 0; --bi) {
@@ -1131,22 +1157,22 @@ static int backward_impl(seld_ctx* c, const float* x) {
             // main branch: BN2 (behind the block's ReLU: mask = out), 1x1 expand
             rn_bn_bwd(c, st, R.c[2], g, R.out, c->rn_bz, M);
             wgrad_conv(c, st, R.y1, w, c->rn_bz, (int)M, w, 4 * w, R.c[2].w_off);
-            launch_gemm(st, c->rn_bz, 4 * w, c->params + R.c[2].w_off, 4 * w, nullptr, c->rn_ba, w, (int)M, w, 4 * w, 1, 0, 0);
+            launch_rn_product_dgrad(st, c->rn_bz, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
             // BN1 (mask = y1), 3x3 through im2col / col2im
             rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, c->rn_bb, M);
             wgrad_conv(c, st, R.c[1].col, 9 * w, c->rn_bb, (int)M, 9 * w, w, R.c[1].w_off);
-            launch_gemm(st, c->rn_bb, w, c->params + R.c[1].w_off, w, nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 1, 0, 0);
+            launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
             launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
             // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
             rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, c->rn_bb, M);
             wgrad_conv(c, st, X, ldx, c->rn_bb, (int)M, R.Cin, w, R.c[0].w_off);
             if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
-            launch_gemm(st, c->rn_bb, w, c->params + R.c[0].w_off, w, nullptr, dX, ldx, (int)M, R.Cin, w, 1, 0, 0);
+            launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0);
             // shortcut
             if (R.proj) {
                 rn_bn_bwd(c, st, R.sc, g, R.out, c->rn_bz, M);
                 wgrad_conv(c, st, X, ldx, c->rn_bz, (int)M, R.Cin, 4 * w, R.sc.w_off);
-                launch_gemm(st, c->rn_bz, 4 * w, c->params + R.sc.w_off, 4 * w, nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1, 0, 1);
+                launch_rn_product_dgrad(st, c->rn_bz, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1);
             } else {
                 launch_rn_add_masked(st, dX, g, R.out, M * 4 * w);
             }

@@ -140,6 +140,16 @@ int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, dou
 int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu);
 int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C);
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n);
+// the three products of a convolution ([M,K] rows x [K,N] kernel): split-bf16 kernels when the shape allows and pre-split planes are
+// given (wsp: launch_gemm_split_b of w, wsp_t: of w^T), else the fp32 MFMA GEMM
+int rn_sb_fwd_ok(int K, int N);
+int rn_sb_dgrad_ok(int K, int N);
+int rn_sb_wgrad_ok(int K, int N);
+int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N);
+int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, const unsigned short* wsp_t, float* dA, int ldd, int M, int K, int N,
+                            int accumulate);
+int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float* dz, float* slab, int64_t slab_cap, float* dw, int M, int K, int N,
+                            int split_bf16);
 // xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
 int launch_xc_unit_fwd(hipStream_t st, const float* x, const float* kdw, const float* wpw, float* dwo, float* z, float* partial, int* npartial,
                        int B, int H, int W, const float* aff = nullptr);
@@ -184,14 +194,15 @@ int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda
                        const float* bias, float* C, int ldc, int M, int N, int K, int transb, int act, int accumulate);
 // split-bf16 GEMM (gemm_sb.hip): weights pre-split into bf16 planes by launch_gemm_split_b (up to 16 operands per launch),
 // then C = act(A B + bias) with mode 0 / 1 (two products sharing A) / 2 (one product over a concatenated K).
-// Usable when K % 32 == 0, N % 128 == 0, lda % 4 == 0 and A is 16-byte aligned (gemm_sb_usable); no accumulate form.
+// Usable when K % 32 == 0, N % 128 == 0, lda % 4 == 0 and A is 16-byte aligned (gemm_sb_usable).
 extern int g_gsb_dbg;   // tools/tune_gemm.py: 1 no loads in the 4-wave loop, 2 no stores, 4 force the 4-wave form, 8 the 16-wave form
 size_t gemm_sb_split_elems(int K, int N);
 int gemm_sb_usable(const void* A, int lda, int N, int K);
 int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsigned short* const* dst, const int* ldb,
                         const int* transb, const int* K, const int* N);
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
-                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode);
+                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
+                   int accum = 0);      // accum: C += (the shortcut's input gradient lands on the reduce convolution's)
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
@@ -211,6 +222,9 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
 int launch_reduce_slabs2_batch(hipStream_t st, const float* slab, int nslab, int64_t stride, const TnJobs& jobs, int njobs, int64_t n_w, int64_t n_b);
 int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,
                       int shift, int want_bias);
+// one product with K1 % 128 == 0 (resnet50_block's kernel gradients): slabs of K1 * N floats, `slab_cap` floats available
+int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int64_t slab_cap, int* nslab,
+                            int M, int K1, int N);
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b);
 int gemm_tn_max_splits();

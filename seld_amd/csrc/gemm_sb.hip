@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
-                                                         int K, int act, int mode, int dbg) {
+                                                         int K, int act, int mode, int dbg, int accum) {
     __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 5, li = lane & 31;
@@ -206,9 +206,12 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
         float v = ACC_[r] + BV_;                                                             \
         if (act == 1) v = 1.f / (1.f + expf(-v));                                            \
         else if (act == 2) v = tanhf(v);                                                     \
-        if (full || dr < rows_left) crow[(size_t)dr * ldc + (nt_) * 32] = v;                 \
+        if (full || dr < rows_left) {                                                        \
+            if (accum) v += crow[(size_t)dr * ldc + (nt_) * 32];                             \
+            crow[(size_t)dr * ldc + (nt_) * 32] = v;                                         \
+        }                                                                                    \
     }
-    if (act == 0 && full) {
+    if (act == 0 && full && !accum) {
 #define GSB_STORE_PLAIN(ACC_, nt_, BV_)                                                      \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * ldc + (nt_) * 32] = ACC_[r] + BV_;
         GSB_STORE_PLAIN(acc0, 0, bv0) GSB_STORE_PLAIN(acc1, 1, bv1) GSB_STORE_PLAIN(acc2, 2, bv2) GSB_STORE_PLAIN(acc3, 3, bv3)
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
-                                                         int K, int act, int mode) {
+                                                         int K, int act, int mode, int accum) {
     __shared__ __attribute__((aligned(16))) unsigned short Al[2][3 * 128 * GSB_KC];      // 2 x 24 KB
     __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -353,7 +356,12 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
                 if (act == 1) v_[j] = 1.f / (1.f + expf(-v_[j]));
                 else if (act == 2) v_[j] = tanhf(v_[j]);
             }
-            *reinterpret_cast<float4*>(cq + (size_t)(8 * q) * ldc) = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
+            float4 o_ = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
+            if (accum) {
+                const float4 p_ = *reinterpret_cast<const float4*>(cq + (size_t)(8 * q) * ldc);
+                o_.x += p_.x; o_.y += p_.y; o_.z += p_.z; o_.w += p_.w;
+            }
+            *reinterpret_cast<float4*>(cq + (size_t)(8 * q) * ldc) = o_;
         }
         return;
     }
@@ -363,13 +371,14 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         float v = (acc0[r] + acc1[r]) + bv;
         if (act == 1) v = 1.f / (1.f + expf(-v));
         else if (act == 2) v = tanhf(v);
-        if (dr < rows_left) crow[(size_t)dr * ldc] = v;
+        if (dr < rows_left) crow[(size_t)dr * ldc] = accum ? v + crow[(size_t)dr * ldc] : v;
     }
 }
 
 int g_gsb_dbg = 0;
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
-                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode) {
+                   const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
+                   int accum) {
     if (M <= 0 || N <= 0 || K <= 0 || !gemm_sb_usable(A0, lda, N, K)) return -1;
     if (mode == 2 && !gemm_sb_usable(A1, lda, N, K)) return -1;
     dim3 grid(N / GSB_BN * (mode == 1 ? 2 : 1), (M + 127) / 128);
@@ -378,13 +387,13 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     if ((g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide)
         if (K == 128 && mode != 2 && !(g_gsb_dbg & 32))
             hipLaunchKernelGGL(gemm_sb_kernel<4>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
-                               mode, g_gsb_dbg & 3);
+                               mode, g_gsb_dbg & 3, accum);
         else
             hipLaunchKernelGGL(gemm_sb_kernel<0>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
-                               mode, g_gsb_dbg & 3);
+                               mode, g_gsb_dbg & 3, accum);
     else {
         const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
-#define G16_GO(NG_) hipLaunchKernelGGL(gemm_sb16_kernel<NG_>, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode)
+#define G16_GO(NG_) hipLaunchKernelGGL(gemm_sb16_kernel<NG_>, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum)
         if (g_gsb_dbg & 16) G16_GO(0);
         else if (ng == 24) G16_GO(24);       // the GRU input gradients: K = 2 x 384
         else if (ng == 12) G16_GO(12);

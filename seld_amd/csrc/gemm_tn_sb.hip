@@ -11,6 +11,7 @@
 // the 64-B unit u of row m is stored at u ^ (m & 3): the 4 rows of a transposed-read block then cover the 64 banks.
 // Splits over rows write slabs in gemm_tn's layout ([128*N | N] per split), combined by reduce_slabs2 in a fixed order.
 #include "common.h"
+#include <algorithm>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -34,11 +35,14 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 
 // blockIdx.y = job: up to TN_MAX_JOBS products of one shape (the four weight gradients of a GRU layer) in one launch; job j's slabs
 // follow job j-1's (gridDim.z slabs each)
+// tile_stride > 0 (the convolution kernel gradients of resnet50_block, K1 = a multiple of 128): ONE product, blockIdx.y = the
+// 128-row tile of C (columns 128 y .. of A); a split's slab is the whole [K1][N] matrix, tile_stride floats apart
 __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
-                                                            int S, int want_bias) {
-    const float* __restrict__ A = jobs.A[blockIdx.y];
-    const float* __restrict__ Bm = jobs.B[blockIdx.y];
-    const int lda = jobs.lda[blockIdx.y], shift = jobs.shift[blockIdx.y];
+                                                            int S, int want_bias, long long tile_stride) {
+    const int job = tile_stride ? 0 : blockIdx.y;
+    const float* __restrict__ A = jobs.A[job] + (tile_stride ? 128 * blockIdx.y : 0);
+    const float* __restrict__ Bm = jobs.B[job];
+    const int lda = jobs.lda[job], shift = jobs.shift[job];
     __shared__ __attribute__((aligned(16))) char Al[3 * TNSB_PL];
     __shared__ __attribute__((aligned(16))) char Bl[3 * TNSB_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
 #undef TNSB_COMMIT
 #undef TNSB_PUT
 #undef TNSB_LOAD
-    float* out = slab + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)128 * N + N);
+    float* out = tile_stride ? slab + (size_t)blockIdx.z * tile_stride + (size_t)blockIdx.y * 128 * N
+                             : slab + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)128 * N + N);
     const int li = lane & 31;
     // 4 dwordx4 stores per accumulator tile (common.h: quad_transpose4): row 8 q + 4 kg + (li & 3), columns 4 (li >> 2) .. + 3
 #define TNSB_OUT(ACC_, kt_, nt_)                                                                      \
@@ -162,8 +167,29 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias);
+    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL);
     *nslab = splits;
+    return 0;
+}
+// C[K1][N] = A^T B with K1 % 128 == 0: one launch, (K1/128) x (N/128) tiles x splits blocks; slabs of K1 * N floats each (no bias part).
+// The split count fills the card about once (768 resident blocks) within the slab buffer's capacity.
+int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int64_t slab_cap, int* nslab,
+                            int M, int K1, int N) {
+    if (M <= 0 || K1 <= 0 || (K1 % 128) || !gemm_tn_sb_usable(A, lda, Bm, ldb, 128, N)) return -1;
+    const int tiles = (K1 / 128) * (N / 128);
+    int64_t splits = (768 + tiles - 1) / tiles;
+    splits = std::min<int64_t>(splits, slab_cap / ((int64_t)K1 * N));
+    splits = std::min<int64_t>(splits, 128);
+    splits = std::min<int64_t>(splits, (M + 127) / 128);         // at least four 32-row chunks per split
+    if (splits < 1) return -1;
+    int rps = (int)((M + splits - 1) / splits);
+    rps = (rps + 31) / 32 * 32;
+    splits = (M + rps - 1) / rps;
+    TnJobs jobs = {};
+    jobs.A[0] = A; jobs.B[0] = Bm; jobs.lda[0] = lda; jobs.shift[0] = 0;
+    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+                       (long long)K1 * N);
+    *nslab = (int)splits;
     return 0;
 }
 int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab, int M, int N, int S,

@@ -11,6 +11,7 @@
 namespace {
 int g_conv64_split_bf16 = 1;
 int g_conv1_split_bf16 = 1;
+int g_rn_split_bf16 = 1;
 int g_gemm_tn_sb = 1;
 struct Scratch {
     std::vector<void*> p;
@@ -39,6 +40,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!strcmp(key, "cpsb_stagger")) { g_cpsb_stagger = value; return SELD_OK; }
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
+    if (!strcmp(key, "rn_split_bf16")) { g_rn_split_bf16 = value != 0; return SELD_OK; }
     return SELD_ERR_INVALID;
 }
 
@@ -360,20 +362,31 @@ int seld_k_valu_clock_mhz(int blocks, double* mhz) {
 }
 
 // ---- resnet50_block pieces (resnet.hip + the fp32 GEMMs), as api.hip composes them
+// split `w` ([K,N]; transposed: the planes of w^T) into scratch planes when the split-bf16 product takes the shape, as the model does per step
+static unsigned short* rn_k_split(Scratch& s, const float* w, int K, int N, int transposed) {
+    if (!g_rn_split_bf16 || !(transposed ? rn_sb_dgrad_ok(K, N) : rn_sb_fwd_ok(K, N))) return nullptr;
+    unsigned short* d = reinterpret_cast<unsigned short*>(s.get((gemm_sb_split_elems(K, N) + 1) / 2));
+    if (!d) return nullptr;
+    const float* src[1] = {w}; unsigned short* dst[1] = {d};
+    const int ldb[1] = {N}, tb[1] = {transposed}, Ks[1] = {transposed ? N : K}, Ns[1] = {transposed ? K : N};
+    return launch_gemm_split_b(0, 1, src, dst, ldb, tb, Ks, Ns) ? nullptr : d;
+}
+
 int seld_k_rn_conv(const float* x, const float* w, float* z, int B, int H, int W, int Cin, int Cout, int ksize, int stride_f) {
     if (!x || !w || !z) return SELD_ERR_INVALID;
     if ((ksize != 1 && ksize != 3) || (ksize == 3 && stride_f != 1) || stride_f < 1 || W % stride_f || Cin % 4) return SELD_ERR_UNSUPPORTED;
     const int Wo = W / stride_f;
-    const int M = B * H * Wo;
+    const int M = B * H * Wo, K = ksize * ksize * Cin;
+    Scratch s;
+    const unsigned short* wsp = rn_k_split(s, w, K, Cout, 0);
     if (ksize == 1) {
-        if (launch_gemm(0, x, Cin * stride_f, w, Cout, nullptr, z, Cout, M, Cout, Cin, 0, 0, 0)) return SELD_ERR_INVALID;
+        if (launch_rn_product_fwd(0, x, Cin * stride_f, w, wsp, z, M, K, Cout)) return SELD_ERR_INVALID;
         return done();
     }
-    Scratch s;
     float* col = s.get((size_t)M * 9 * Cin);
     if (!col) return SELD_ERR_NOMEM;
     launch_im2col3x3(0, x, col, B, H, W, Cin);
-    if (launch_gemm(0, col, 9 * Cin, w, Cout, nullptr, z, Cout, M, Cout, 9 * Cin, 0, 0, 0)) return SELD_ERR_INVALID;
+    if (launch_rn_product_fwd(0, col, K, w, wsp, z, M, K, Cout)) return SELD_ERR_INVALID;
     return done();
 }
 
@@ -383,25 +396,22 @@ int seld_k_rn_conv_bwd(const float* x, const float* w, const float* dz, float* d
     if ((ksize != 1 && ksize != 3) || (ksize == 3 && stride_f != 1) || stride_f < 1 || W % stride_f || Cin % 4) return SELD_ERR_UNSUPPORTED;
     const int Wo = W / stride_f, M = B * H * Wo, K1 = ksize * ksize * Cin;
     Scratch s;
-    const int64_t per = (int64_t)K1 * Cout + Cout;
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)gemm_tn_max_splits() * (384 * 384 + 384)) / per));
-    float* slab = s.get((size_t)splits * per);
+    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384);     // the model's slab buffer
+    float* slab = s.get((size_t)cap);
     float* col = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
     float* dcol = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
     if (!slab || (ksize == 3 && (!col || !dcol))) return SELD_ERR_NOMEM;
-    int ns = 0;
+    const unsigned short* wsp_t = rn_k_split(s, w, K1, Cout, 1);
     if (ksize == 3) {
         launch_im2col3x3(0, x, col, B, H, W, Cin);
-        launch_gemm_tn(0, col, K1, dz, Cout, slab, &ns, M, K1, Cout, 0, 0, 0, splits);
-        launch_reduce_slabs2(0, slab, ns, per, dw, (int64_t)K1 * Cout, nullptr, 0);
-        launch_gemm(0, dz, Cout, w, Cout, nullptr, dcol, K1, M, K1, Cout, 1, 0, 0);
+        if (launch_rn_product_wgrad(0, col, K1, dz, slab, cap, dw, M, K1, Cout, g_rn_split_bf16)) return SELD_ERR_INVALID;
+        if (launch_rn_product_dgrad(0, dz, w, wsp_t, dcol, K1, M, K1, Cout, 0)) return SELD_ERR_INVALID;
         launch_col2im3x3(0, dcol, dx, B, H, W, Cin);
     } else {
         const int ldx = Cin * stride_f;
-        launch_gemm_tn(0, x, ldx, dz, Cout, slab, &ns, M, K1, Cout, 0, 0, 0, splits);
-        launch_reduce_slabs2(0, slab, ns, per, dw, (int64_t)K1 * Cout, nullptr, 0);
+        if (launch_rn_product_wgrad(0, x, ldx, dz, slab, cap, dw, M, K1, Cout, g_rn_split_bf16)) return SELD_ERR_INVALID;
         if (stride_f > 1 && hipMemsetAsync(dx, 0, (size_t)B * H * W * Cin * sizeof(float), 0) != hipSuccess) return SELD_ERR_HIP;
-        launch_gemm(0, dz, Cout, w, Cout, nullptr, dx, ldx, M, Cin, Cout, 1, 0, 0);
+        if (launch_rn_product_dgrad(0, dz, w, wsp_t, dx, ldx, M, K1, Cout, 0)) return SELD_ERR_INVALID;
     }
     return done();
 }

@@ -11,6 +11,7 @@
 //   rn_bn_bwd_dz              dz = scale (dy' - c1 - xhat c2)
 //   rn_add_masked             dst += dy [mask > 0]
 #include "common.h"
+#include <algorithm>
 
 #define RN_MAX_PARTIAL 256
 int rn_partial_capacity() { return RN_MAX_PARTIAL; }
@@ -118,23 +119,42 @@ int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, con
     return 0;
 }
 
+// The chunk's partials [nbx][128] summed in double by a 1024-thread workgroup: thread (v, part) takes partials part, part + 8, ... on four
+// independent accumulators (a lone dependent chain of 128 loads per thread made these two finalisations 33 us launches, 15 % of the
+// resnet50_gru step); the assignment is fixed, so the sum is the same bits every run.  Returns the total for v in threads 0..127.
+__device__ __forceinline__ double rn_sum_partials(const float* __restrict__ partial, int chunk, int nbx, double* red /* [1024] */) {
+    const int tid = threadIdx.x, v = tid & 127, part = tid >> 7;
+    const float* p = partial + (size_t)chunk * nbx * 128 + v;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = part;
+    for (; i + 24 < nbx; i += 32) {
+        const float a = p[(size_t)i * 128], b = p[(size_t)(i + 8) * 128], c = p[(size_t)(i + 16) * 128], d = p[(size_t)(i + 24) * 128];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+    }
+    for (; i < nbx; i += 8) s0 += (double)p[(size_t)i * 128];
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    double t = 0.0;
+    if (tid < 128) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 128 + tid];
+    }
+    return t;
+}
+
 // one workgroup per 64-channel chunk: the chunk's partials [nbx][128] -> coef = [mean | invstd | scale | shift | c1 | c2] x C.
 // Synchronised BatchNorm (seld_set_sync_bn) splits it around the host's all-reduce: phase 1 stops after the chunk's sums
 // (sums[chunk][128] doubles), phase 2 starts from the all-reduced sums with the global count; phase 0 does both in one go.
-__global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const float* __restrict__ partial, int nbx, double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void rn_bn_finalize_kernel(const float* __restrict__ partial, int nbx, double count, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ mov_mean,
                                                              float* __restrict__ mov_var, float* __restrict__ coef, int C, int training,
                                                              double* __restrict__ sums, int phase) {
-    __shared__ double red[256];
+    __shared__ double red[1024];
     __shared__ double tot[128];
     const int c0 = blockIdx.x * 64, tid = threadIdx.x;
     if (training && phase != 2) {
-        const int v = tid & 127, part = tid >> 7;
-        double s = 0.0;
-        for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < 128) tot[tid] = red[tid] + red[128 + tid];
+        const double t = rn_sum_partials(partial, blockIdx.x, nbx, red);
+        if (tid < 128) tot[tid] = t;
         __syncthreads();
         if (phase == 1) {
             if (tid < 128) sums[(size_t)blockIdx.x * 128 + tid] = tot[tid];
@@ -166,29 +186,25 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const float* __rest
 }
 int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double count, const float* gamma, const float* beta, float* mov_mean,
                           float* mov_var, float* coef, int C, int training, double* sums, int phase) {
-    hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, gamma, beta, mov_mean, mov_var, coef, C,
+    hipLaunchKernelGGL(rn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nbx, count, gamma, beta, mov_mean, mov_var, coef, C,
                        training, sums, phase);
     return 0;
 }
 // backward: [sum dy' | sum dy' xhat] per chunk.  phase 0: dgamma / dbeta and c1 / c2 = the sums / count.  Synchronised BatchNorm:
 // phase 1 writes THIS rank's dgamma / dbeta (they are all-reduced with the gradient buffer like every other gradient) and the chunk's
 // sums for the host's all-reduce; phase 2 forms c1 / c2 from the global sums and the global count.
-__global__ __launch_bounds__(256) void rn_bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbx, double count, float* __restrict__ dgamma,
+__global__ __launch_bounds__(1024) void rn_bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbx, double count, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, float* __restrict__ coef, int C,
                                                                  double* __restrict__ sums, int phase) {
-    __shared__ double red[256];
-    const int c0 = blockIdx.x * 64, tid = threadIdx.x, v = tid & 127, part = tid >> 7;
+    __shared__ double red[1024];
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
     double t;
     if (phase == 2) {
         if (tid >= 128) return;
         t = sums[(size_t)blockIdx.x * 128 + tid];
     } else {
-        double s = 0.0;
-        for (int i = part; i < nbx; i += 2) s += (double)partial[((size_t)blockIdx.x * nbx + i) * 128 + v];
-        red[tid] = s;
-        __syncthreads();
+        t = rn_sum_partials(partial, blockIdx.x, nbx, red);
         if (tid >= 128) return;
-        t = red[tid] + red[128 + tid];
         if (phase == 1) sums[(size_t)blockIdx.x * 128 + tid] = t;
     }
     if (c0 + (tid & 63) >= C) return;
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_finalize_kernel(const float* __
 }
 int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C,
                               double* sums, int phase) {
-    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nbx, count, dgamma, dbeta, coef, C, sums, phase);
+    hipLaunchKernelGGL(rn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nbx, count, dgamma, dbeta, coef, C, sums, phase);
     return 0;
 }
 
@@ -267,4 +283,37 @@ __global__ __launch_bounds__(256) void rn_add_masked_kernel(float* __restrict__ 
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n) {
     hipLaunchKernelGGL(rn_add_masked_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, dy, mask, n / 4);
     return 0;
+}
+
+// ---- the products of a resnet50_block convolution ---------------------------------------------------------------------
+// A convolution here is a product on [M = B*S*Wout] rows (1x1: the input rows, a frequency stride is a doubled row stride; 3x3: the
+// im2col rows).  Where the shape allows, the product runs on the split-bf16 kernels of gemm_sb.hip / gemm_tn_sb.hip (fp32 operands split
+// exactly into three bf16 terms, 6 MFMA products, fp32-level error) from weight planes the caller pre-split for this step; every other
+// shape (the 32- and 64-channel products of the first two stages) takes the fp32 MFMA GEMM.
+int rn_sb_fwd_ok(int K, int N) { return (K % 32) == 0 && (N % 128) == 0; }               // z = A w           [M,K] x [K,N]
+int rn_sb_dgrad_ok(int K, int N) { return (N % 32) == 0 && (K % 128) == 0; }             // dA = dz w^T       [M,N] x [N,K]
+int rn_sb_wgrad_ok(int K, int N) { return (K % 128) == 0 && (N % 128) == 0; }            // dw = A^T dz       [K,M] x [M,N]
+
+int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N) {
+    if (wsp && rn_sb_fwd_ok(K, N) && gemm_sb_usable(A, lda, N, K))
+        return launch_gemm_sb(st, A, nullptr, lda, wsp, nullptr, nullptr, nullptr, z, nullptr, N, M, N, K, 0, 0);
+    return launch_gemm(st, A, lda, w, N, nullptr, z, N, M, N, K, 0, 0, 0);
+}
+// wsp_t: the planes of w^T (launch_gemm_split_b with transb = 1, K' = N, N' = K)
+int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, const unsigned short* wsp_t, float* dA, int ldd, int M, int K, int N,
+                            int accumulate) {
+    if (wsp_t && rn_sb_dgrad_ok(K, N) && gemm_sb_usable(dz, N, K, N))
+        return launch_gemm_sb(st, dz, nullptr, N, wsp_t, nullptr, nullptr, nullptr, dA, nullptr, ldd, M, K, N, 0, 0, accumulate);
+    return launch_gemm(st, dz, N, w, N, nullptr, dA, ldd, M, K, N, 1, 0, accumulate);
+}
+// slab: scratch of slab_cap floats for the row splits, combined in a fixed order into dw
+int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float* dz, float* slab, int64_t slab_cap, float* dw, int M, int K, int N,
+                            int split_bf16) {
+    int ns = 0;
+    if (split_bf16 && rn_sb_wgrad_ok(K, N) && launch_gemm_tn_sb_tiles(st, A, lda, dz, N, slab, slab_cap, &ns, M, K, N) == 0)
+        return launch_reduce_slabs2(st, slab, ns, (int64_t)K * N, dw, (int64_t)K * N, nullptr, 0);
+    const int64_t per = (int64_t)K * N + N;
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, slab_cap / per));
+    if (launch_gemm_tn(st, A, lda, dz, N, slab, &ns, M, K, N, 0, 0, 0, splits)) return -1;
+    return launch_reduce_slabs2(st, slab, ns, per, dw, (int64_t)K * N, nullptr, 0);
 }

@@ -555,8 +555,20 @@ def test_conv1_train_without_pre_bn_tensor(seld_lib, B, H, CIN):
 # ---- resnet50_block pieces (spec/RESNET50_BLOCK.md) at the shapes its stages run them at: B*S*W pixels with W = 16, 8, 4, 2
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,stride_f", [(2, 30, 16, 64, 32, 1, 1), (2, 30, 16, 32, 32, 3, 1), (2, 30, 16, 128, 64, 1, 2),
                                                            (4, 60, 2, 256, 256, 3, 1), (4, 60, 2, 256, 1024, 1, 1), (4, 60, 4, 512, 1024, 1, 2),
-                                                           (3, 7, 4, 128, 128, 3, 1)])
-def test_rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f):
+                                                           (3, 7, 4, 128, 128, 3, 1), (2, 30, 16, 32, 128, 1, 1), (2, 61, 4, 128, 512, 1, 1)])
+@pytest.mark.parametrize("split", [1, 0])
+def test_rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f, split):
+    """A resnet50_block convolution as its three products (forward, input gradient, kernel gradient) against float64 autograd: on the
+    split-bf16 kernels where the shape allows (Cout, resp. K, a multiple of 128: the last five shapes at least in part) and on the fp32
+    MFMA GEMM (`rn_split_bf16 = 0`, and every other shape)."""
+    assert seld_lib.seld_k_set_option(b"rn_split_bf16", split) == 0
+    try:
+        _rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f)
+    finally:
+        seld_lib.seld_k_set_option(b"rn_split_bf16", 1)
+
+
+def _rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f):
     rng = np.random.default_rng(31)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((ksize, ksize, Cin, Cout)) / np.sqrt(ksize * ksize * Cin)).astype(np.float32)
