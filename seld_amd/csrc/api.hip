@@ -40,6 +40,7 @@ struct RnConv {
     int64_t w_off = 0, g_off = 0, be_off = 0, mm_off = 0, mv_off = 0;
     float *col = nullptr, *z = nullptr, *coef = nullptr;     // im2col of the input (k = 3), pre-BN output, [mean|invstd|scale|shift|c1|c2] x Cout
     unsigned short *wsp = nullptr, *wsp_t = nullptr;         // pre-split bf16 planes of the kernel / its transpose (shapes the split-bf16 GEMM takes)
+    unsigned short *wsp9 = nullptr, *wsp9_flip = nullptr;    // 3x3, 64 -> 64 (stage 1): tap planes for the implicit-GEMM kernels of conv_sb.hip
 };
 struct RnBlock {
     int Cin, w, stride_f, Win, Wout;
@@ -403,6 +404,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
                 if (!N) continue;
                 if (rn_sb_fwd_ok(K, N)) ALLOC(cv->wsp, gemm_sb_split_elems(K, N));
                 if (rn_sb_dgrad_ok(K, N)) ALLOC(cv->wsp_t, gemm_sb_split_elems(K, N));
+                if (cv->k == 3 && cv->Cin == 64 && N == 64) { ALLOC(cv->wsp9, (size_t)9 * 3 * 4096); ALLOC(cv->wsp9_flip, (size_t)9 * 3 * 4096); }
             }
         ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
         ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
@@ -642,7 +644,9 @@ static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orien
     return flush();
 }
 
-static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training);
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have = 0);
+// the 3x3 convolution of a stage-1 bottleneck (64 -> 64 channels on a width conv_sb.hip / conv_wgrad_sb.hip have kernels for)
+static bool rn_c1_direct(const RnBlock& R) { return R.c[1].wsp9 && (R.Wout == 16 || R.Wout == 8 || R.Wout == 4); }
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     hipStream_t st = c->stream;
@@ -827,6 +831,15 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                     if (cv->wsp_t && save) add(c->params + cv->w_off, cv->wsp_t, N, 1, N, K);
                 }
             if (n) launch_gemm_split_b(st, n, src, dst, ldb, tb, Ks, Ns);
+            const float* w9[8]; unsigned short* d9[8]; int f9[8];
+            n = 0;
+            for (auto& R : c->rn) {
+                if (!rn_c1_direct(R)) continue;
+                w9[n] = c->params + R.c[1].w_off; d9[n] = R.c[1].wsp9; f9[n++] = 0;
+                if (save) { w9[n] = c->params + R.c[1].w_off; d9[n] = R.c[1].wsp9_flip; f9[n++] = 1; }
+                if (n >= 7) { launch_split_weights_batch(st, n, w9, d9, f9); n = 0; }
+            }
+            if (n) launch_split_weights_batch(st, n, w9, d9, f9);
         }
         const float* X = in;      // [B,S,Win,Cin]
         for (auto& R : c->rn) {
@@ -836,10 +849,17 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w);
             rn_bn(c, st, R.c[0], M, training);
             launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1);
-            // 3x3 through im2col, BN, ReLU
-            launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
-            launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
-            rn_bn(c, st, R.c[1], M, training);
+            // 3x3, BN, ReLU: 64 -> 64 (stage 1) on the implicit-GEMM kernel of the conv blocks (BatchNorm's sums from its epilogue),
+            // the other widths as a product on im2col rows
+            if (sb && rn_c1_direct(R)) {
+                int npart = 0;
+                launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout);
+                rn_bn(c, st, R.c[1], M, training, npart);
+            } else {
+                launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
+                launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
+                rn_bn(c, st, R.c[1], M, training);
+            }
             launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1);
             // 1x1 expand, BN; shortcut; out = ReLU(y + r)
             launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w);
@@ -1000,9 +1020,10 @@ static void wgrad_conv(seld_ctx* c, hipStream_t st, const float* A, int lda, con
 
 
 // BatchNormalization of a resnet50_block convolution: statistics (training) or moving statistics -> cv.coef
-static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training) {
-    int nbx = 0;
-    if (training) launch_rn_bn_stats(st, cv.z, c->rn_part, &nbx, M, cv.Cout);
+// nbx_have > 0: the convolution's epilogue already left that many [sum | sum of squares] partials in rn_part (Cout = 64)
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have) {
+    int nbx = nbx_have;
+    if (training && !nbx_have) launch_rn_bn_stats(st, cv.z, c->rn_part, &nbx, M, cv.Cout);
     float *g = c->params + cv.g_off, *be = c->params + cv.be_off, *mm = c->state + cv.mm_off, *mv = c->state + cv.mv_off;
     if (training && c->sync_fn) {
         // synchronised BatchNorm: this rank's per-chunk sums -> the host's all-reduce -> coefficients of the GLOBAL batch
@@ -1160,9 +1181,16 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_rn_product_dgrad(st, c->rn_bz, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
             // BN1 (mask = y1), 3x3 through im2col / col2im
             rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, c->rn_bb, M);
-            wgrad_conv(c, st, R.c[1].col, 9 * w, c->rn_bb, (int)M, 9 * w, w, R.c[1].w_off);
-            launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
-            launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
+            if (sb && rn_c1_direct(R)) {
+                int ns = 0;
+                launch_conv64_wgrad_sb(st, R.y0, c->rn_bb, c->wgrad_slab, &ns, B, S, R.Wout);
+                launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
+                launch_conv64_fwd_sb(st, c->rn_bb, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, R.Wout);
+            } else {
+                wgrad_conv(c, st, R.c[1].col, 9 * w, c->rn_bb, (int)M, 9 * w, w, R.c[1].w_off);
+                launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
+                launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
+            }
             // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
             rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, c->rn_bb, M);
             wgrad_conv(c, st, X, ldx, c->rn_bb, (int)M, R.Cin, w, R.c[0].w_off);

@@ -94,7 +94,7 @@ int launch_conv_first_msparse(hipStream_t st, const float* x, const float* p, co
                               const float* scale, float* slab, int* n_slab, int B, int H, int Cin);
 int launch_conv_first_assemble(hipStream_t st, const float* G, const float* M, const float* W, const float* bias, const float* coef,
                                float* dW, float* db, int Cin);
-// split-bf16 form with transposed LDS reads (conv_wgrad_sb.hip): W = 16 or 4; same slab layout as launch_conv64_wgrad
+// split-bf16 form with transposed LDS reads (conv_wgrad_sb.hip): W = 16, 8 or 4; same slab layout as launch_conv64_wgrad
 int conv64_wgrad_sb_usable(int W);
 int launch_conv64_wgrad_sb(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab, int B, int H, int W);
 int launch_conv64_wgrad(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab,

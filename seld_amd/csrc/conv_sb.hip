@@ -679,6 +679,7 @@ int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* w
                          float* stat_partial, int* n_partial, int B, int H, int W) {
     if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 8 waves, 156 KB
     if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 6 waves
+    if (W == 8 && g_conv64_dbuf) return launch_sbd<3, 32>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves (resnet50_block stage 1)
     if (W == 16) return launch_sbr<4, 16, true>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves, 153 KB
     if (W == 4) return launch_sbr<2, 48, false>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 6 waves (halo columns: no room for 8)
     const int npix = B * H * W;

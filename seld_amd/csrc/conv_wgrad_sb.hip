@@ -6,7 +6,7 @@
 // (what the global loads deliver, written with 8-byte stores) and ds_read_b64_tr_b16 hands lane i the channel-i column of
 // a 4-pixel x 16-channel block, i.e. 4 consecutive k of row i; two of them make a fragment.
 //
-// Chunk = 64 pixels of one image (4 rows at W = 16, 16 rows at W = 4) plus the halo: 108 pixels of x and 64 of dz, three
+// Chunk = 64 pixels of one image (4 rows at W = 16, 8 at W = 8, 16 at W = 4) plus the halo: up to 108 pixels of x and 64 of dz, three
 // bf16 planes each, 66 KB of LDS -> two workgroups per CU.  Wave (cih, coh) owns the 32 ci x 32 co tile of all 9 taps
 // (144 accumulator registers), exactly as conv64_wgrad_kernel; a k-step is 16 pixels: 6 transposed reads for the dz
 // fragments, 6 per tap for x, 54 MFMAs.
@@ -23,7 +23,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define WGSB_MAX_BLOCKS 512
 #define WGSB_SLAB (9 * 4096 + 64)
 #define WGSB_PXC 64            // pixels per chunk
-#define WGSB_HALO 108          // (R + 2) * (W + 2) for both W = 16 (6 x 18) and W = 4 (18 x 6)
+#define WGSB_HALO 108          // (R + 2) * (W + 2) for W = 16 (6 x 18) and W = 4 (18 x 6); W = 8 uses 100 (10 x 10) of it
 
 __device__ __forceinline__ void wgsb_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
@@ -49,8 +49,8 @@ template <int WLOG2>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                  float* __restrict__ slab, int B, int H) {
     constexpr int W = 1 << WLOG2, R = WGSB_PXC / W, RW = W + 2, RR = R + 2;
-    static_assert(RR * RW == WGSB_HALO, "halo size");
-    static_assert(W == 16 || W == 4, "k-step geometry below is written for these two widths");
+    static_assert(RR * RW <= WGSB_HALO, "halo size");
+    static_assert(W == 16 || W == 8 || W == 4, "k-step geometry below is written for these widths");
     constexpr int XPL = WGSB_HALO * 128, DPL = WGSB_PXC * 128;        // plane sizes in bytes
     extern __shared__ __attribute__((aligned(16))) char wgsb_smem[];
     char* xl = wgsb_smem;                 // [3][108 px][128 B]
@@ -62,20 +62,22 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
     const int chunks_per_img = (H + R - 1) / R;
     const int nchunks = B * chunks_per_img;
     // ---- per-lane read offsets.  Pixel P of an image lives at P*128 + (chb ^ 64*((P>>1)&1)).  A read's pixel is
-    // P0 + q with P0 = (compile-time part) + (kg part): the kg part is a multiple of 4 pixels, so the swizzle bit is that
-    // of ((P0c & 3) + q) and the lane keeps one offset per value of P0c & 3.
-    constexpr int KGPIX = W == 16 ? 8 : 2 * RW;           // pixels between the kg = 0 and kg = 1 halves of a k-step (x image)
+    // P0 + q with P0 = (compile-time part) + (kg part): bit 1 of a sum depends on the addends mod 4 only, so the swizzle bit is that
+    // of ((P0c & 3) + kg part + q) and the lane keeps one offset per value of P0c & 3.
+    // A k-step is 16 pixels: W = 16 one image row (kg = its halves), W = 8 two rows (kg = the row), W = 4 four rows (kg = the row pair).
+    constexpr int KGPIX = W == 16 ? 8 : W == 8 ? RW : 2 * RW;           // pixels between the kg = 0 and kg = 1 halves of a k-step (x image)
     const int chbA = 64 * cih + 32 * g1 + 8 * p, chbB = 64 * coh + 32 * g1 + 8 * p;
     int offA[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) offA[m] = (kg * KGPIX + q) * 128 + (chbA ^ (64 * (((m + q) >> 1) & 1)));
+    for (int m = 0; m < 4; ++m) offA[m] = (kg * KGPIX + q) * 128 + (chbA ^ (64 * (((m + q + kg * KGPIX) >> 1) & 1)));
     const int offB = (8 * kg + q) * 128 + (chbB ^ (64 * ((q >> 1) & 1)));
     f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16(), acc3 = zero16(), acc4 = zero16(), acc5 = zero16(), acc6 = zero16(),
            acc7 = zero16(), acc8 = zero16();
     float4 brun = make_float4(0.f, 0.f, 0.f, 0.f);     // this thread's 4 channels (tid & 15) of the bias gradient
 #define WGSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
     // compile-time pixel offset of the x block of k-step s, half h (pixels 8 kg + 4 h ...), tap (dy, dx), kg part excluded
-#define WGSB_P0(s_, h_, dy_, dx_) (W == 16 ? ((s_) + (dy_)) * RW + 4 * (h_) + (dx_) : (4 * (s_) + (h_) + (dy_)) * RW + (dx_))
+#define WGSB_P0(s_, h_, dy_, dx_) (W == 16 ? ((s_) + (dy_)) * RW + 4 * (h_) + (dx_) : W == 8 ? (2 * (s_) + (dy_)) * RW + 4 * (h_) + (dx_) \
+                                           : (4 * (s_) + (h_) + (dy_)) * RW + (dx_))
 #define WGSB_AADDR(s_, h_, dy_, dx_, pl_) (xl + (pl_) * XPL + WGSB_P0(s_, h_, dy_, dx_) * 128 + offA[WGSB_P0(s_, h_, dy_, dx_) & 3])
     // One (k-step, tap) = 6 MFMAs on that tap's accumulator.  Operands are pipelined one step ahead in named registers and
     // the order is pinned with sched_barrier: left alone, the scheduler hoists a whole k-step of transposed reads (108
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
             const int g = idx & 15, P = idx >> 4;                                                                     \
             const int rr = P / RW, cc = P - rr * RW;                                                                  \
             const int t = t0_ - 1 + rr, f = cc - 1;                                                                   \
-            const bool ok = P < WGSB_HALO && t >= 0 && t < H && f >= 0 && f < W;                                      \
+            const bool ok = P < RR * RW && t >= 0 && t < H && f >= 0 && f < W;                                      \
             const float4 v = *reinterpret_cast<const float4*>(ok ? x + ((size_t)(b_ * H + t) * W + f) * 64 + g * 4 : x); \
             const unsigned k_ = ok ? 0xffffffffu : 0u;                                                                \
             xv[u] = make_float4(__uint_as_float(__float_as_uint(v.x) & k_), __uint_as_float(__float_as_uint(v.y) & k_), \
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
     }
 }
 
-int conv64_wgrad_sb_usable(int W) { return W == 16 || W == 4; }
+int conv64_wgrad_sb_usable(int W) { return W == 16 || W == 8 || W == 4; }
 
 int launch_conv64_wgrad_sb(hipStream_t st, const float* x, const float* dz, float* slab, int* n_slab, int B, int H, int W) {
     if (!conv64_wgrad_sb_usable(W) || B <= 0 || H <= 0) return -2;
@@ -218,7 +220,7 @@ int launch_conv64_wgrad_sb(hipStream_t st, const float* x, const float* dz, floa
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                           \
         hipLaunchKernelGGL(conv64_wgrad_sb_kernel<L>, dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);    \
     }
-    if (W == 16) WGSB_GO(4) else WGSB_GO(2)
+    if (W == 16) WGSB_GO(4) else if (W == 8) WGSB_GO(3) else WGSB_GO(2)
 #undef WGSB_GO
     *n_slab = grid;
     return 0;

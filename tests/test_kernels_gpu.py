@@ -19,7 +19,8 @@ def _conv_ref(x, w, b):
     return F.conv2d(xt, wt, torch.as_tensor(b, dtype=torch.float64), padding=1).permute(0, 2, 3, 1).numpy()
 
 
-@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64)])
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64), (2, 45, 8, 64),
+                                       (3, 70, 8, 64)])
 def test_conv_fwd(seld_lib, B, H, W, Cin):
     rng = np.random.default_rng(1)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -39,7 +40,7 @@ def test_conv_fwd(seld_lib, B, H, W, Cin):
     seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16), (4, 100, 16)])
+@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16), (4, 100, 16), (3, 70, 8)])
 def test_conv_dgrad(seld_lib, B, H, W):
     rng = np.random.default_rng(2)
     dz = rng.standard_normal((B, H, W, 64)).astype(np.float32)
@@ -58,7 +59,7 @@ def test_conv_dgrad(seld_lib, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64),
-                                       (1, 3, 4, 64), (2, 33, 4, 64), (4, 600, 16, 64), (4, 600, 4, 64)])
+                                       (1, 3, 4, 64), (2, 33, 4, 64), (4, 600, 16, 64), (4, 600, 4, 64), (2, 33, 8, 64), (1, 5, 8, 64), (4, 600, 8, 64)])
 def test_conv_wgrad(seld_lib, B, H, W, Cin):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
