@@ -82,7 +82,12 @@ struct seld_ctx {
     float *xc_g[3] = {};                     // gradient ping-pong buffers [B,S,16,64]
     // resnet50_block (arch.first_kind == SELD_FIRST_RESNET50): conv[0] is the entry block, then the bottleneck blocks
     std::vector<RnBlock> rn;
-    float *rn_part = nullptr, *rn_gx[2] = {}, *rn_bz = nullptr, *rn_ba = nullptr, *rn_bb = nullptr, *rn_bcol = nullptr;
+    float *rn_part = nullptr, *rn_gx[2] = {}, *rn_bz[2] = {}, *rn_ba = nullptr, *rn_bb[3] = {}, *rn_bcol = nullptr;
+    // resnet50_block backward: the kernel gradients run on the side stream beside the input-gradient chain; the dz buffers rotate
+    // (ev_rn_free[slot]: the side stream's product that read the slot is done; slots 0-1 = rn_bz, 2-4 = rn_bb)
+    hipEvent_t ev_rn_ready = nullptr, ev_rn_free[5] = {};
+    float* rn_w9_slab = nullptr;           // slabs of the stage-1 3x3 kernel gradients (wgrad_slab belongs to the main stream's first block)
+    int rn_wgrad_side = 1;
     int rn_feat = 0;                         // features per label frame into the first GRU layer (2 x 32 rn_filters)
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
@@ -408,7 +413,13 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             }
         ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
         ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
-        ALLOC(c->rn_bz, mx_out); ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bb, mx_w); ALLOC(c->rn_bcol, mx_col);
+        for (auto& b_ : c->rn_bz) ALLOC(b_, mx_out);
+        for (auto& b_ : c->rn_bb) ALLOC(b_, mx_w);
+        ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bcol, mx_col);
+        ALLOC(c->rn_w9_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+        bool ok_ = hipEventCreateWithFlags(&c->ev_rn_ready, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+        for (auto& e_ : c->ev_rn_free) ok_ = ok_ && hipEventCreateWithFlags(&e_, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+        if (!ok_) { seld_destroy(c); return fail(nullptr, SELD_ERR_HIP, "event creation failed"); }
     }
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
@@ -497,6 +508,8 @@ void seld_destroy(seld_ctx* c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_gram) hipEventDestroy(c->ev_gram);
+    if (c->ev_rn_ready) hipEventDestroy(c->ev_rn_ready);
+    for (auto e_ : c->ev_rn_free) if (e_) hipEventDestroy(e_);
     for (auto e : c->ev_bucket) if (e) hipEventDestroy(e);
     if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
@@ -522,6 +535,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -1013,10 +1027,6 @@ static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A
 }
 
 // dW[K1,N] = A^T B for a bias-free convolution of a FIRST block (xception / resnet50), as many short splits as the slab buffer holds
-static void wgrad_conv(seld_ctx* c, hipStream_t st, const float* A, int lda, const float* Bm, int M, int K1, int N, int64_t w_off) {
-    launch_rn_product_wgrad(st, A, lda, Bm, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + w_off, M, K1, N,
-                            c->rn_split_bf16);
-}
 
 
 // BatchNormalization of a resnet50_block convolution: statistics (training) or moving statistics -> cv.coef
@@ -1166,6 +1176,26 @@ static int backward_impl(seld_ctx* c, const float* x) {
         // ---- resnet50_block backward, blocks last to first; g = gradient w.r.t. the block's output
         PROF(c, "rn_stages_bwd");
         const bool sb = c->rn_split_bf16 != 0;
+        // The kernel gradients (a third of the block's products) go to the side stream: one product of these shapes leaves the card
+        // part-filled (e.g. 300 row tiles on 256 CUs), and an independent stream fills what the input-gradient chain leaves idle.
+        // A dz buffer is handed over by ev_rn_ready and comes back by ev_rn_free[slot] before its next writer starts.
+        const bool aside = c->rn_wgrad_side != 0;
+        hipStream_t ws = aside ? c->side : st;
+        bool busy[5] = {};
+        int zi = 1, bbi = 4;        // last slot taken of rn_bz (0-1) / rn_bb (2-4)
+        auto take = [&](int first, int n, int& cur) {
+            cur = first + (cur - first + 1) % n;
+            if (busy[cur]) { hipStreamWaitEvent(st, c->ev_rn_free[cur], 0); busy[cur] = false; }
+            return cur < 2 ? c->rn_bz[cur] : c->rn_bb[cur - 2];
+        };
+        auto fork = [&](int) { if (aside) { hipEventRecord(c->ev_rn_ready, st); hipStreamWaitEvent(c->side, c->ev_rn_ready, 0); } };
+        auto done = [&](int slot) { if (aside) { hipEventRecord(c->ev_rn_free[slot], c->side); busy[slot] = true; } };
+        auto wgrad = [&](int slot, const float* A, int lda, const float* dz, int M_, int K1, int N, int64_t w_off) {
+            fork(slot);
+            launch_rn_product_wgrad(ws, A, lda, dz, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + w_off, M_, K1, N,
+                                    c->rn_split_bf16);
+            done(slot);
+        };
         const float* g = dout;
         int flip = 0;
         for (int bi = (int)c->rn.size() - 1; bi >= 0; --bi) {
@@ -1176,31 +1206,37 @@ static int backward_impl(seld_ctx* c, const float* x) {
             float* dX = bi == 0 ? c->conv[0].dp : c->rn_gx[flip];
             const int ldx = R.Cin * R.stride_f;
             // main branch: BN2 (behind the block's ReLU: mask = out), 1x1 expand
-            rn_bn_bwd(c, st, R.c[2], g, R.out, c->rn_bz, M);
-            wgrad_conv(c, st, R.y1, w, c->rn_bz, (int)M, w, 4 * w, R.c[2].w_off);
-            launch_rn_product_dgrad(st, c->rn_bz, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
-            // BN1 (mask = y1), 3x3 through im2col / col2im
-            rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, c->rn_bb, M);
+            float* dz2 = take(0, 2, zi);
+            rn_bn_bwd(c, st, R.c[2], g, R.out, dz2, M);
+            wgrad(zi, R.y1, w, dz2, (int)M, w, 4 * w, R.c[2].w_off);
+            launch_rn_product_dgrad(st, dz2, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
+            // BN1 (mask = y1), 3x3: stage 1 on the conv blocks' kernels, the other widths through im2col / col2im
+            float* dz1 = take(2, 3, bbi);
+            rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, dz1, M);
             if (sb && rn_c1_direct(R)) {
+                fork(bbi);
                 int ns = 0;
-                launch_conv64_wgrad_sb(st, R.y0, c->rn_bb, c->wgrad_slab, &ns, B, S, R.Wout);
-                launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
-                launch_conv64_fwd_sb(st, c->rn_bb, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, R.Wout);
+                launch_conv64_wgrad_sb(ws, R.y0, dz1, c->rn_w9_slab, &ns, B, S, R.Wout);
+                launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
+                done(bbi);
+                launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, R.Wout);
             } else {
-                wgrad_conv(c, st, R.c[1].col, 9 * w, c->rn_bb, (int)M, 9 * w, w, R.c[1].w_off);
-                launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
+                wgrad(bbi, R.c[1].col, 9 * w, dz1, (int)M, 9 * w, w, R.c[1].w_off);
+                launch_rn_product_dgrad(st, dz1, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
                 launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
             }
             // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
-            rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, c->rn_bb, M);
-            wgrad_conv(c, st, X, ldx, c->rn_bb, (int)M, R.Cin, w, R.c[0].w_off);
+            float* dz0 = take(2, 3, bbi);
+            rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, dz0, M);
+            wgrad(bbi, X, ldx, dz0, (int)M, R.Cin, w, R.c[0].w_off);
             if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
-            launch_rn_product_dgrad(st, c->rn_bb, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0);
+            launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0);
             // shortcut
             if (R.proj) {
-                rn_bn_bwd(c, st, R.sc, g, R.out, c->rn_bz, M);
-                wgrad_conv(c, st, X, ldx, c->rn_bz, (int)M, R.Cin, 4 * w, R.sc.w_off);
-                launch_rn_product_dgrad(st, c->rn_bz, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1);
+                float* dzs = take(0, 2, zi);
+                rn_bn_bwd(c, st, R.sc, g, R.out, dzs, M);
+                wgrad(zi, X, ldx, dzs, (int)M, R.Cin, 4 * w, R.sc.w_off);
+                launch_rn_product_dgrad(st, dzs, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1);
             } else {
                 launch_rn_add_masked(st, dX, g, R.out, M * 4 * w);
             }

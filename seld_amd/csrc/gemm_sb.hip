@@ -396,6 +396,8 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
 #define G16_GO(NG_) hipLaunchKernelGGL(gemm_sb16_kernel<NG_>, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum)
         if (g_gsb_dbg & 16) G16_GO(0);
         else if (ng == 24) G16_GO(24);       // the GRU input gradients: K = 2 x 384
+        else if (ng == 36) G16_GO(36);       // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
+        else if (ng == 16) G16_GO(16);       // ... its 1x1 products with K = 512
         else if (ng == 12) G16_GO(12);
         else if (ng == 8) G16_GO(8);
         else if (ng == 4) G16_GO(4);
