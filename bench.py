@@ -33,7 +33,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32
 # gemm_sb): the ceiling for the fp32-equivalent FLOP count is a sixth of the bf16 peak
 PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 SPLIT_BF16_GROUPS = {"conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "conv3_fwd", "conv3_dgrad", "conv3_wgrad",
-                     "gru_inproj_gemm", "gru_bwd_gemms"}   # with the default options (seld_set_option)
+                     "gru_inproj_gemm", "gru_bwd_gemms",
+                     # resnet50_block: 87 % of the stages' FLOP (stages 2-3, the 128-column products of stages 0-1, stage 1's 3x3) run on
+                     # the split-bf16 kernels, the 32- / 64-column rest on the f32 MFMA: the whole group is priced against the split peak
+                     "rn_stages_fwd", "rn_stages_bwd"}   # with the default options (seld_set_option)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 # GRU recurrence (gru.hip): S dependent steps per launch; the floor of a step is the VALU issue time of its two waves per
 # SIMD — per wave 48 v_pk_fma_f32 + ~23 (forward) / ~37 (BPTT) other VALU + 6 (0) transcendental instructions at the
@@ -81,8 +84,9 @@ def kernel_work(name, B, T, F=64, C=7):
         "xc_pointwise_bwd": ("mfma", 2 * 2 * px2 * 64 * 64), "xc_depthwise_bwd": ("hbm", 4 * 5 * px2 * 64),
     }
     if name in ("rn_stages_fwd", "rn_stages_bwd"):
-        # resnet50_block (spec/RESNET50_BLOCK.md): the products of every bottleneck (1x1 reduce, 3x3, 1x1 expand, projection shortcut)
-        # on the f32-input MFMA GEMM; the backward pass runs each twice (kernel gradient + input gradient)
+        # resnet50_block (spec/RESNET50_BLOCK.md): the products of every bottleneck (1x1 reduce, 3x3, 1x1 expand, projection shortcut);
+        # the backward pass runs each twice (kernel gradient + input gradient).  The group's time also holds the BatchNorm passes,
+        # im2col and (backward) whatever the side stream's kernel gradients make the main stream wait for
         mac, cin, wbins = 0, 64, 16
         for s_, nb in enumerate(RESNET_BLOCKS):
             w = 32 * 2 ** s_
