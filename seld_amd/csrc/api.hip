@@ -881,8 +881,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             if (R.proj) {
                 launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
                 rn_bn(c, st, R.sc, M, training);
-                launch_rn_bn_apply(st, R.sc.z, R.sc.coef, nullptr, R.out, M, 4 * w, 0);
-                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, R.out, R.out, M, 4 * w, 1);
+                launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w);
             } else {
                 launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1);
             }
@@ -1046,9 +1045,11 @@ static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int traini
     launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
 }
 // backward of the same: dz = BN'(dy [mask > 0]) into `dz`, dgamma / dbeta into the gradient buffer
+// mask == nullptr: the BatchNorm feeds a ReLU directly (no residual) and the gate is recomputed from z
 static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, const float* mask, float* dz, int64_t M) {
     int nbx = 0;
-    launch_rn_bn_bwd_reduce(st, cv.z, dy, mask, cv.coef, c->rn_part, &nbx, M, cv.Cout);
+    const int gate_z = mask == nullptr;
+    launch_rn_bn_bwd_reduce(st, cv.z, dy, mask, cv.coef, c->rn_part, &nbx, M, cv.Cout, gate_z);
     if (c->sync_fn) {
         const int nd = (cv.Cout + 63) / 64 * 128;
         launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 1);
@@ -1056,7 +1057,7 @@ static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, 
         launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M * c->sync_world, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 2);
     } else
         launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout);
-    launch_rn_bn_bwd_dz(st, cv.z, dy, mask, cv.coef, dz, M, cv.Cout);
+    launch_rn_bn_bwd_dz(st, cv.z, dy, mask, cv.coef, dz, M, cv.Cout, gate_z);
 }
 
 // weight gradients of the fused linear heads, on the side stream (the caller has forked): F = feat^T dy and colsum(dy) in one TN
@@ -1212,7 +1213,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_rn_product_dgrad(st, dz2, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
             // BN1 (mask = y1), 3x3: stage 1 on the conv blocks' kernels, the other widths through im2col / col2im
             float* dz1 = take(2, 3, bbi);
-            rn_bn_bwd(c, st, R.c[1], c->rn_ba, R.y1, dz1, M);
+            rn_bn_bwd(c, st, R.c[1], c->rn_ba, nullptr, dz1, M);
             if (sb && rn_c1_direct(R)) {
                 fork(bbi);
                 int ns = 0;
@@ -1227,7 +1228,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             }
             // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
             float* dz0 = take(2, 3, bbi);
-            rn_bn_bwd(c, st, R.c[0], c->rn_ba, R.y0, dz0, M);
+            rn_bn_bwd(c, st, R.c[0], c->rn_ba, nullptr, dz0, M);
             wgrad(bbi, X, ldx, dz0, (int)M, R.Cin, w, R.c[0].w_off);
             if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
             launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0);

@@ -464,6 +464,18 @@ int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nsla
     return 0;
 }
 
+// this thread's share of out[i] = sum_z slab[z][i]: slabs g, g + 8, ... with 4 independent loads in flight
+__device__ __forceinline__ double slab_group_sum(const float* __restrict__ slab, int nslab, int64_t stride, int64_t i, int g) {
+    double s = 0.0;
+    int z = g;
+    for (; z + 24 < nslab; z += 32) {
+        const float v0 = slab[(size_t)z * stride + i], v1 = slab[(size_t)(z + 8) * stride + i];
+        const float v2 = slab[(size_t)(z + 16) * stride + i], v3 = slab[(size_t)(z + 24) * stride + i];
+        s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; z < nslab; z += 8) s += (double)slab[(size_t)z * stride + i];
+    return s;
+}
 // out[i] (+)= sum_z slab[z][i].  Block = 32 outputs x 8 slab groups: thread (o = tid & 31, g = tid >> 5) adds
 // slabs g, g+8, ... (independent, coalesced 128-B rows), the 8 group sums are combined through LDS in a
 // fixed order -> bit-reproducible and 8x the memory parallelism of one thread per output.
@@ -473,16 +485,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     __shared__ double red[256];
     const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + o;
-    double s = 0.0;
-    if (i < n) {
-        int z = g;
-        for (; z + 24 < nslab; z += 32) {   // 4 independent loads in flight
-            const float v0 = slab[(size_t)z * stride + i], v1 = slab[(size_t)(z + 8) * stride + i];
-            const float v2 = slab[(size_t)(z + 16) * stride + i], v3 = slab[(size_t)(z + 24) * stride + i];
-            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-        }
-        for (; z < nslab; z += 8) s += (double)slab[(size_t)z * stride + i];
-    }
+    const double s = i < n ? slab_group_sum(slab, nslab, stride, i, g) : 0.0;
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < n) {
@@ -503,9 +506,7 @@ __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* __restr
     const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + o;
     const int64_t n = n_w + n_b;
-    double s = 0.0;
-    if (i < n)
-        for (int z = g; z < nslab; z += 8) s += (double)slab[(size_t)z * stride + i];
+    const double s = i < n ? slab_group_sum(slab, nslab, stride, i, g) : 0.0;
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < n) {
@@ -525,9 +526,7 @@ __global__ __launch_bounds__(256) void reduce_slabs2_batch_kernel(const float* _
     const int64_t i = (int64_t)blockIdx.x * 32 + o;
     const int64_t n = n_w + n_b;
     const float* src = slab + (size_t)blockIdx.y * nslab * stride;
-    double s = 0.0;
-    if (i < n)
-        for (int z = g; z < nslab; z += 8) s += (double)src[(size_t)z * stride + i];
+    const double s = i < n ? slab_group_sum(src, nslab, stride, i, g) : 0.0;
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < n) {

@@ -55,7 +55,7 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
         if (K[i] % GSB_KC) return -2;
         j.src[i] = src[i]; j.dst[i] = dst[i]; j.ldb[i] = ldb[i]; j.transb[i] = transb[i]; j.K[i] = K[i]; j.N[i] = N[i];
     }
-    hipLaunchKernelGGL(gemm_split_b_kernel, dim3(48, njobs), dim3(256), 0, st, j);
+    hipLaunchKernelGGL(gemm_split_b_kernel, dim3(144, njobs), dim3(256), 0, st, j);
     return 0;
 }
 

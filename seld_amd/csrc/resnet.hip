@@ -66,20 +66,26 @@ int launch_col2im3x3(hipStream_t st, const float* dcol, float* dy, int B, int H,
 
 // grid (blocks_x, C / 64): workgroup (x, y) reduces the pixels x, x + gridDim.x, ... of channels [64 y, 64 y + 64).
 // partial[(y * gridDim.x + x)][128]
-template <bool BWD>
+// GATEZ (backward, no residual behind the BatchNorm): the ReLU's gate is recomputed from z — fma(z, scale, shift) > 0 is bit for bit
+// what rn_bn_apply wrote through its max(., 0) — instead of read from the stored output
+template <bool BWD, bool GATEZ = false>
 __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
                                                         const float* __restrict__ coef, float* __restrict__ partial, int64_t npix, int C) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
     const int c0 = blockIdx.y * 64 + 4 * g;
     const bool gok = c0 < C;                 // C = 32: half of the chunk's groups have no channels
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1, gsc = s1, gsh = s1;
     if (BWD && gok) { mu = *reinterpret_cast<const float4*>(coef + c0); is = *reinterpret_cast<const float4*>(coef + C + c0); }
+    if (GATEZ && gok) { gsc = *reinterpret_cast<const float4*>(coef + 2 * C + c0); gsh = *reinterpret_cast<const float4*>(coef + 3 * C + c0); }
     for (int64_t p = (int64_t)blockIdx.x * 16 + slot; gok && p < npix; p += (int64_t)gridDim.x * 16) {
         const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c0);
         if (BWD) {
             float4 d = *reinterpret_cast<const float4*>(dy + p * C + c0);
-            if (mask) {
+            if (GATEZ) {
+                const float4 m = rn_fma4(zv, gsc, gsh);
+                d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+            } else if (mask) {
                 const float4 m = *reinterpret_cast<const float4*>(mask + p * C + c0);
                 d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
             }
@@ -108,14 +114,15 @@ static int rn_blocks_x(int64_t npix) {
 int launch_rn_bn_stats(hipStream_t st, const float* z, float* partial, int* nbx, int64_t npix, int C) {
     if (C % 32) return -2;
     *nbx = rn_blocks_x(npix);
-    hipLaunchKernelGGL(rn_reduce_kernel<false>, dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix, C);
+    hipLaunchKernelGGL((rn_reduce_kernel<false, false>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix, C);
     return 0;
 }
 int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* partial, int* nbx,
-                            int64_t npix, int C) {
+                            int64_t npix, int C, int gate_z) {
     if (C % 32) return -2;
     *nbx = rn_blocks_x(npix);
-    hipLaunchKernelGGL(rn_reduce_kernel<true>, dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
+    if (gate_z) hipLaunchKernelGGL((rn_reduce_kernel<true, true>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, nullptr, coef, partial, npix, C);
+    else hipLaunchKernelGGL((rn_reduce_kernel<true, false>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
     return 0;
 }
 
@@ -237,6 +244,25 @@ __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float* __restric
     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     reinterpret_cast<float4*>(out)[gid] = o;
 }
+// out = relu(BN(z) + BN_r(zr)): the block output of a projection bottleneck in one pass (both BatchNorms applied on load)
+__global__ __launch_bounds__(256) void rn_bn_apply2_kernel(const float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ zr,
+                                                           const float* __restrict__ coef_r, float* __restrict__ out, int64_t n4, int G) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n4) return;
+    const int g = (int)(gid % G), C = 4 * G;
+    // the shortcut's value is rounded to fp32 before the add, exactly as when it was written to memory first
+    const float4 r = rn_fma4(reinterpret_cast<const float4*>(zr)[gid], reinterpret_cast<const float4*>(coef_r + 2 * C)[g],
+                             reinterpret_cast<const float4*>(coef_r + 3 * C)[g]);
+    float4 o = rn_fma4(reinterpret_cast<const float4*>(z)[gid], reinterpret_cast<const float4*>(coef + 2 * C)[g],
+                       reinterpret_cast<const float4*>(coef + 3 * C)[g]);
+    o = make_float4(fmaxf(o.x + r.x, 0.f), fmaxf(o.y + r.y, 0.f), fmaxf(o.z + r.z, 0.f), fmaxf(o.w + r.w, 0.f));
+    reinterpret_cast<float4*>(out)[gid] = o;
+}
+int launch_rn_bn_apply2(hipStream_t st, const float* z, const float* coef, const float* zr, const float* coef_r, float* out, int64_t npix, int C) {
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(rn_bn_apply2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, zr, coef_r, out, n4, C / 4);
+    return 0;
+}
 int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu) {
     const int64_t n4 = npix * (C / 4);
     hipLaunchKernelGGL(rn_bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, res, out, n4, C / 4, relu);
@@ -244,6 +270,7 @@ int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const 
 }
 
 // dz = scale (dy' - c1 - xhat c2), dy' = dy [mask > 0]
+template <bool GATEZ>
 __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
                                                            const float* __restrict__ coef, float* __restrict__ dz, int64_t n4, int G) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -251,12 +278,15 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restri
     const int g = (int)(gid % G), C = 4 * G;
     const float4 zv = reinterpret_cast<const float4*>(z)[gid];
     float4 d = reinterpret_cast<const float4*>(dy)[gid];
-    if (mask) {
+    const float4 mu = reinterpret_cast<const float4*>(coef)[g], is = reinterpret_cast<const float4*>(coef + C)[g];
+    const float4 sc = reinterpret_cast<const float4*>(coef + 2 * C)[g], c1 = reinterpret_cast<const float4*>(coef + 4 * C)[g];
+    if (GATEZ) {
+        const float4 m = rn_fma4(zv, sc, reinterpret_cast<const float4*>(coef + 3 * C)[g]);
+        d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+    } else if (mask) {
         const float4 m = reinterpret_cast<const float4*>(mask)[gid];
         d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
     }
-    const float4 mu = reinterpret_cast<const float4*>(coef)[g], is = reinterpret_cast<const float4*>(coef + C)[g];
-    const float4 sc = reinterpret_cast<const float4*>(coef + 2 * C)[g], c1 = reinterpret_cast<const float4*>(coef + 4 * C)[g];
     const float4 c2 = reinterpret_cast<const float4*>(coef + 5 * C)[g];
     float4 o;
     o.x = sc.x * (d.x - c1.x - (zv.x - mu.x) * is.x * c2.x);
@@ -265,9 +295,11 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restri
     o.w = sc.w * (d.w - c1.w - (zv.w - mu.w) * is.w * c2.w);
     reinterpret_cast<float4*>(dz)[gid] = o;
 }
-int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C) {
+int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C,
+                        int gate_z) {
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(rn_bn_bwd_dz_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
+    if (gate_z) hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, nullptr, coef, dz, n4, C / 4);
+    else hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
     return 0;
 }
 
