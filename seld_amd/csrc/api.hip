@@ -79,7 +79,8 @@ struct seld_ctx {
     std::vector<XcUnit> xc;
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
-    float *xc_g[3] = {};                     // gradient ping-pong buffers [B,S,16,64]
+    float *xc_g[4] = {}, *xc_dz2 = nullptr;  // gradient ping-pong buffers [B,S,16,64] (X, F1, F2, second F1); second dz buffer
+    int xc_wgrad_side = 1;                   // xception_block backward: kernel gradients on the side stream (as rn_wgrad_side)
     // resnet50_block (arch.first_kind == SELD_FIRST_RESNET50): conv[0] is the entry block, then the bottleneck blocks
     std::vector<RnBlock> rn;
     float *rn_part = nullptr, *rn_gx[2] = {}, *rn_bz[2] = {}, *rn_ba = nullptr, *rn_bb[3] = {}, *rn_bcol = nullptr;
@@ -387,7 +388,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         c->xc_x.resize(a->xc_blocks + 1);
         c->xc_x[0] = c->conv[0].p;
         for (int b = 1; b <= a->xc_blocks; ++b) ALLOC(c->xc_x[b], npx);
-        for (int k = 0; k < 3; ++k) ALLOC(c->xc_g[k], npx);
+        for (int k = 0; k < 4; ++k) ALLOC(c->xc_g[k], npx);
+        ALLOC(c->xc_dz2, npx);
         ALLOC(c->xc_feat, (size_t)B * S * 128);
         ALLOC(c->xc_part, (size_t)xc_partial_capacity() * 128);
         ALLOC(c->xc_slab, (size_t)xc_partial_capacity() * 576);
@@ -417,6 +419,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         for (auto& b_ : c->rn_bb) ALLOC(b_, mx_w);
         ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bcol, mx_col);
         ALLOC(c->rn_w9_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+    }
+    if (resn || a->first_kind == SELD_FIRST_XCEPTION) {
         bool ok_ = hipEventCreateWithFlags(&c->ev_rn_ready, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
         for (auto& e_ : c->ev_rn_free) ok_ = ok_ && hipEventCreateWithFlags(&e_, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
         if (!ok_) { seld_destroy(c); return fail(nullptr, SELD_ERR_HIP, "event creation failed"); }
@@ -536,6 +540,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -1259,6 +1264,22 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const float* id = c->xc_ident;       // mean 0 | invstd 1 | scale 1 | shift 0 | c1 0 | c2 0
             launch_bn_pool_bwd_dz(st, c->xc_x.back(), dout, id, id + 64, id + 128, id + 192, id + 256, X, B, S, 16, 64, 1, 8);
         }
+        // The two kernel gradients of a unit (pointwise: dwo^T dz, depthwise: from the unit's input and F1) are off the input-gradient
+        // chain: they run on the side stream; dz and F1 alternate between two buffers each, handed over by ev_rn_ready and taken back
+        // by ev_rn_free[slot] (slots 0-1 dz, 2-3 F1) before the buffer's next writer starts.
+        const bool aside = c->xc_wgrad_side != 0;
+        hipStream_t ws = aside ? c->side : st;
+        float* dzb[2] = {c->dzbuf, c->xc_dz2};
+        float* f1b[2] = {F1, c->xc_g[3]};
+        bool busy[4] = {};
+        int di = 1, fi = 1;
+        auto take = [&](int first, int& cur) {
+            cur ^= 1;
+            if (busy[first + cur]) { hipStreamWaitEvent(st, c->ev_rn_free[first + cur], 0); busy[first + cur] = false; }
+            return first + cur;
+        };
+        auto fork = [&]() { if (aside) { hipEventRecord(c->ev_rn_ready, st); hipStreamWaitEvent(c->side, c->ev_rn_ready, 0); } };
+        auto done = [&](int slot) { if (aside) { hipEventRecord(c->ev_rn_free[slot], c->side); busy[slot] = true; } };
         for (int b = (int)c->arch.xc_blocks - 1; b >= 0; --b) {
             const float* gY = X;
             for (int u = 2; u >= 0; --u) {
@@ -1267,6 +1288,8 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 const float* uin = u == 0 ? c->xc_x[b] : (fold ? c->xc[(size_t)b * 3 + u - 1].z : c->xc[(size_t)b * 3 + u - 1].a);
                 const float* aff = fold ? c->xc[(size_t)b * 3 + u - 1].scale : nullptr;
                 int np = 0, ns = 0;
+                const int sd = take(0, di);
+                float* dz = dzb[di];
                 {
                     PROF2(c, "xc_bn_bwd");
                     launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
@@ -1277,25 +1300,34 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         launch_bn_bwd_c1c2(st, c->sync_buf, (double)npix * c->sync_world, U.c1c2);
                     } else
                         launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
-                    launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, c->dzbuf, npix);
+                    launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, dz, npix);
                 }
+                const int sf = take(2, fi);
+                float* F1c = f1b[fi];
                 {
                     PROF2(c, "xc_pointwise_bwd");
                     // dW = dwo^T dz (TN product over the pixels, many short splits: the slab is only 64 x 64), d(dwo) = dz W^T
-                    launch_gemm_tn(st, U.dwo, 64, c->dzbuf, 64, c->tn_slab, &ns, (int)npix, 64, 64, 0, 0, 0, 512);
-                    launch_reduce_slabs2(st, c->tn_slab, ns, 64 * 64 + 64, c->grads + U.pw_off, 64 * 64, nullptr, 0);
-                    launch_gemm(st, c->dzbuf, 64, c->params + U.pw_off, 64, nullptr, F1, 64, (int)npix, 64, 64, 1, 0, 0);
+                    fork();
+                    launch_gemm_tn(ws, U.dwo, 64, dz, 64, c->tn_slab, &ns, (int)npix, 64, 64, 0, 0, 0, 512);
+                    launch_reduce_slabs2(ws, c->tn_slab, ns, 64 * 64 + 64, c->grads + U.pw_off, 64 * 64, nullptr, 0);
+                    done(sd);
+                    launch_gemm(st, dz, 64, c->params + U.pw_off, 64, nullptr, F1c, 64, (int)npix, 64, 64, 1, 0, 0);
                 }
                 PROF2(c, "xc_depthwise_bwd");
-                launch_dw3x3_bwd_w(st, uin, F1, c->xc_slab, &ns, B, S, 16, aff);
-                launch_reduce_slabs(st, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
+                fork();
+                launch_dw3x3_bwd_w(ws, uin, F1c, c->xc_slab, &ns, B, S, 16, aff);
+                launch_reduce_slabs(ws, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
+                done(sf);
                 // gradient w.r.t. the unit's input, through its ReLU; the module's first unit adds the residual branch's X
                 float* gin = (u == 0 && b == 0) ? c->conv[0].dp : F2;
-                launch_dw3x3_bwd_data(st, F1, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16, aff);
+                launch_dw3x3_bwd_data(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16, aff);
                 gY = gin;
             }
             if (b > 0) { float* t_ = X; X = F2; F2 = t_; }      // the module's input gradient is the next module's output gradient
         }
+        // the first block's backward (main stream) writes dzbuf: not before the side stream's last reader of it is done
+        for (int k = 0; k < 4; ++k)
+            if (busy[k]) hipStreamWaitEvent(st, c->ev_rn_free[k], 0);
         dp = c->conv[0].dp;
     }
     for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
