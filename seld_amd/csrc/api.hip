@@ -83,7 +83,7 @@ struct seld_ctx {
     int xc_wgrad_side = 1;                   // xception_block backward: kernel gradients on the side stream (as rn_wgrad_side)
     // resnet50_block (arch.first_kind == SELD_FIRST_RESNET50): conv[0] is the entry block, then the bottleneck blocks
     std::vector<RnBlock> rn;
-    float *rn_part = nullptr, *rn_gx[2] = {}, *rn_bz[2] = {}, *rn_ba = nullptr, *rn_bb[3] = {}, *rn_bcol = nullptr;
+    float *rn_part = nullptr, *rn_part_side = nullptr, *rn_gx[2] = {}, *rn_bz[2] = {}, *rn_ba = nullptr, *rn_bb[3] = {}, *rn_bcol = nullptr;
     // resnet50_block backward: the kernel gradients run on the side stream beside the input-gradient chain; the dz buffers rotate
     // (ev_rn_free[slot]: the side stream's product that read the slot is done; slots 0-1 = rn_bz, 2-4 = rn_bb)
     hipEvent_t ev_rn_ready = nullptr, ev_rn_free[5] = {};
@@ -414,6 +414,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
                 if (cv->k == 3 && cv->Cin == 64 && N == 64) { ALLOC(cv->wsp9, (size_t)9 * 3 * 4096); ALLOC(cv->wsp9_flip, (size_t)9 * 3 * 4096); }
             }
         ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
+        ALLOC(c->rn_part_side, (size_t)rn_partial_capacity() * 16 * 128);
         ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
         for (auto& b_ : c->rn_bz) ALLOC(b_, mx_out);
         for (auto& b_ : c->rn_bb) ALLOC(b_, mx_w);
@@ -663,7 +664,7 @@ static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orien
     return flush();
 }
 
-static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have = 0);
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have = 0, float* part = nullptr);
 // the 3x3 convolution of a stage-1 bottleneck (64 -> 64 channels on a width conv_sb.hip / conv_wgrad_sb.hip have kernels for)
 static bool rn_c1_direct(const RnBlock& R) { return R.c[1].wsp9 && (R.Wout == 16 || R.Wout == 8 || R.Wout == 4); }
 
@@ -864,6 +865,14 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         for (auto& R : c->rn) {
             const int64_t M = (int64_t)B * S * R.Wout;
             const int w = R.w;
+            // the projection shortcut (first block of a stage) depends on the block input only: side stream, joined before the add
+            const bool sc_side = R.proj && c->rn_wgrad_side && !c->sync_fn;
+            if (sc_side) {
+                hipEventRecord(c->ev_rn_ready, st); hipStreamWaitEvent(c->side, c->ev_rn_ready, 0);
+                launch_rn_product_fwd(c->side, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
+                rn_bn(c, c->side, R.sc, M, training, 0, c->rn_part_side);
+                hipEventRecord(c->ev_rn_free[0], c->side);
+            }
             // 1x1 (frequency stride = doubled row stride of the operand), BN, ReLU
             launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w);
             rn_bn(c, st, R.c[0], M, training);
@@ -884,8 +893,11 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w);
             rn_bn(c, st, R.c[2], M, training);
             if (R.proj) {
-                launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
-                rn_bn(c, st, R.sc, M, training);
+                if (sc_side) hipStreamWaitEvent(st, c->ev_rn_free[0], 0);
+                else {
+                    launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
+                    rn_bn(c, st, R.sc, M, training);
+                }
                 launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w);
             } else {
                 launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1);
@@ -1035,19 +1047,21 @@ static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A
 
 // BatchNormalization of a resnet50_block convolution: statistics (training) or moving statistics -> cv.coef
 // nbx_have > 0: the convolution's epilogue already left that many [sum | sum of squares] partials in rn_part (Cout = 64)
-static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have) {
+// part: the partial-sum scratch (default rn_part; the side stream's projection shortcut has its own)
+static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have, float* part) {
     int nbx = nbx_have;
-    if (training && !nbx_have) launch_rn_bn_stats(st, cv.z, c->rn_part, &nbx, M, cv.Cout);
+    if (!part) part = c->rn_part;
+    if (training && !nbx_have) launch_rn_bn_stats(st, cv.z, part, &nbx, M, cv.Cout);
     float *g = c->params + cv.g_off, *be = c->params + cv.be_off, *mm = c->state + cv.mm_off, *mv = c->state + cv.mv_off;
     if (training && c->sync_fn) {
         // synchronised BatchNorm: this rank's per-chunk sums -> the host's all-reduce -> coefficients of the GLOBAL batch
         const int nd = (cv.Cout + 63) / 64 * 128;
-        launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 1);
+        launch_rn_bn_finalize(st, part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 1);
         if (c->sync_fn(c->sync_user, c->sync_buf, nd, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
-        launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M * c->sync_world, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 2);
+        launch_rn_bn_finalize(st, part, nbx, (double)M * c->sync_world, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 2);
         return;
     }
-    launch_rn_bn_finalize(st, c->rn_part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
+    launch_rn_bn_finalize(st, part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
 }
 // backward of the same: dz = BN'(dy [mask > 0]) into `dz`, dgamma / dbeta into the gradient buffer
 // mask == nullptr: the BatchNorm feeds a ReLU directly (no residual) and the gate is recomputed from z
