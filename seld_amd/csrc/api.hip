@@ -80,6 +80,7 @@ struct seld_ctx {
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
     float *xc_g[4] = {}, *xc_dz2 = nullptr;  // gradient ping-pong buffers [B,S,16,64] (X, F1, F2, second F1); second dz buffer
+    int xc_fused_pw_bwd = 1;                 // a unit's BatchNorm' + pointwise input / kernel gradients in one kernel (xc_pw_bwd)
     int xc_wgrad_side = 1;                   // xception_block backward: kernel gradients on the side stream (as rn_wgrad_side)
     // resnet50_block (arch.first_kind == SELD_FIRST_RESNET50): conv[0] is the entry block, then the bottleneck blocks
     std::vector<RnBlock> rn;
@@ -542,6 +543,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -1302,8 +1304,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 const float* uin = u == 0 ? c->xc_x[b] : (fold ? c->xc[(size_t)b * 3 + u - 1].z : c->xc[(size_t)b * 3 + u - 1].a);
                 const float* aff = fold ? c->xc[(size_t)b * 3 + u - 1].scale : nullptr;
                 int np = 0, ns = 0;
-                const int sd = take(0, di);
-                float* dz = dzb[di];
+                const bool fpw = c->xc_fused_pw_bwd != 0;
+                int sd = -1;
+                float* dz = nullptr;
+                if (!fpw) { sd = take(0, di); dz = dzb[di]; }
                 {
                     PROF2(c, "xc_bn_bwd");
                     launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
@@ -1314,11 +1318,19 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         launch_bn_bwd_c1c2(st, c->sync_buf, (double)npix * c->sync_world, U.c1c2);
                     } else
                         launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
-                    launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, dz, npix);
+                    if (!fpw) launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, dz, npix);
                 }
                 const int sf = take(2, fi);
                 float* F1c = f1b[fi];
-                {
+                if (fpw) {
+                    PROF2(c, "xc_pointwise_bwd");
+                    // dz formed on load; F1 = dz W^T and the slabs of dW = dwo^T dz from one pass (xc_pw_bwd); the combine goes to the side stream
+                    if (busy[0]) { hipStreamWaitEvent(st, c->ev_rn_free[0], 0); busy[0] = false; }      // slot 0 = the slab buffer here
+                    launch_xc_pw_bwd(st, U.z, gY, U.dwo, c->params + U.pw_off, U.mean, U.invstd, U.scale, U.c1c2, F1c, c->tn_slab, &ns, npix);
+                    fork();
+                    launch_reduce_slabs(ws, c->tn_slab, ns, 4096, c->grads + U.pw_off, 4096, 0);
+                    done(0);
+                } else {
                     PROF2(c, "xc_pointwise_bwd");
                     // dW = dwo^T dz (TN product over the pixels, many short splits: the slab is only 64 x 64), d(dwo) = dz W^T
                     fork();

@@ -165,6 +165,10 @@ int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npar
 int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
                             int* npartial, int64_t npix);
 int launch_xc_bn_apply(hipStream_t st, const float* z, const float* scale, const float* shift, const float* res, float* out, int64_t npix);
+// BatchNorm' + both pointwise products of a unit's backward in one pass (xception.hip): f1 = dz W^T, slab[nslab][4096] = partial dwo^T dz
+int xc_pw_bwd_slabs();
+int launch_xc_pw_bwd(hipStream_t st, const float* z, const float* gy, const float* dwo, const float* wpw, const float* mean, const float* invstd,
+                     const float* scale, const float* c1c2, float* f1, float* slab, int* nslab, int64_t npix);
 int launch_xc_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, const float* scale,
                         const float* c1c2, float* dz, int64_t npix);
 int launch_xc_ident(hipStream_t st, float* ident);

@@ -249,6 +249,111 @@ int launch_xc_unit_fwd(hipStream_t st, const float* x, const float* kdw, const f
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The pointwise half of a unit's backward in ONE pass:  dz = BatchNorm'(gY) formed on load (never stored), F1 = dz W^T (gradient
+// w.r.t. the depthwise output) and the kernel gradient dW = dwo^T dz, both on the fp32 MFMA.  As three kernels (xc_bn_bwd_dz, gemm_tn +
+// combine, gemm_f32) the step moved 7 tensor passes per unit; this way 4 (z, gY, dwo in, F1 out).
+// Tile = 128 pixels, 4 waves.  LDS: dz [128][65] (row stride 65: a lane per PIXEL reading channel k is conflict-free, and so is a lane
+// per CHANNEL reading pixel k) and dwo [128][64].  F1: wave w = pixels 32 w .., two 32-channel tiles, W^T in 64 registers per lane.
+// dW: wave (a, c) owns the 32 x 32 tile (input channels 32 a .., output channels 32 c ..) over ALL pixels the workgroup visits
+// (persistent, two per CU); one slab of 4 096 floats per workgroup, combined in a fixed order by reduce_slabs.
+#define XPB_MAX_BLOCKS 512
+__global__ __launch_bounds__(256, 2) void xc_pw_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gy, const float* __restrict__ dwo,
+                                                           const float* __restrict__ wpw, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ c1c2, float* __restrict__ f1, float* __restrict__ slab,
+                                                           int64_t npix) {
+    extern __shared__ __attribute__((aligned(16))) float xpb_smem[];
+    float* Dw = xpb_smem;                 // [128][64]
+    float* Dz = xpb_smem + 128 * 64;      // [128][65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kk = lane >> 5;
+    const int g = tid & 15;
+    const int wa = wave >> 1, wc = wave & 1;
+    float wreg[2][32];                           // B operand of F1 = dz W^T: B[k = o][n = i] = W[i][o], k = 2 s + kk, n = 32 c + li
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s_ = 0; s_ < 32; ++s_) wreg[c][s_] = wpw[(32 * c + li) * 64 + 2 * s_ + kk];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[g], c1 = reinterpret_cast<const float4*>(c1c2)[g];
+    const float4 c2 = reinterpret_cast<const float4*>(c1c2 + 64)[g];
+    f32x16 dw = zero16();
+    const int64_t ntiles = (npix + 127) / 128;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 128;
+        // ---- stage: thread = (pixel slot tid >> 4, channels 4 g ..), 8 pixels each
+        float4 zv[8], dv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t p = p0 + 16 * u + (tid >> 4);
+            const bool ok = p < npix;
+            const size_t o_ = (size_t)(ok ? p : 0) * 16 + g;
+            zv[u] = reinterpret_cast<const float4*>(z)[o_];
+            dv[u] = reinterpret_cast<const float4*>(gy)[o_];
+            wv[u] = reinterpret_cast<const float4*>(dwo)[o_];
+            if (!ok) { dv[u] = make_float4(0.f, 0.f, 0.f, 0.f); wv[u] = dv[u]; zv[u] = mu; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pl = 16 * u + (tid >> 4);
+            const bool ok = p0 + pl < npix;
+            // the expression of xc_bn_bwd_dz_kernel, bit for bit
+            float4 o;
+            o.x = sc.x * (dv[u].x - c1.x - (zv[u].x - mu.x) * is.x * c2.x);
+            o.y = sc.y * (dv[u].y - c1.y - (zv[u].y - mu.y) * is.y * c2.y);
+            o.z = sc.z * (dv[u].z - c1.z - (zv[u].z - mu.z) * is.z * c2.z);
+            o.w = sc.w * (dv[u].w - c1.w - (zv[u].w - mu.w) * is.w * c2.w);
+            if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);       // pixels past the end add nothing to dW
+            float* d = Dz + pl * 65 + 4 * g;
+            d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.w;
+            *reinterpret_cast<float4*>(Dw + pl * 64 + 4 * g) = wv[u];
+        }
+        __syncthreads();
+        // ---- F1 tile of this wave's 32 pixels
+        f32x16 acc[2] = {zero16(), zero16()};
+        const float* arow = Dz + (32 * wave + li) * 65 + kk;
+#pragma unroll
+        for (int s_ = 0; s_ < 32; ++s_) {
+            const float a = arow[2 * s_];
+            acc[0] = MFMA_F32_32x32x2(a, wreg[0][s_], acc[0]);
+            acc[1] = MFMA_F32_32x32x2(a, wreg[1][s_], acc[1]);
+        }
+        // ---- dW tile (wa, wc) over the 128 pixels: A[i][k = pixel] = dwo[pixel][32 wa + i], B[k = pixel][o] = dz[pixel][32 wc + o]
+        const float* ap = Dw + kk * 64 + 32 * wa + li;
+        const float* bp = Dz + kk * 65 + 32 * wc + li;
+#pragma unroll 16
+        for (int s_ = 0; s_ < 64; ++s_) dw = MFMA_F32_32x32x2(ap[2 * s_ * 64], bp[2 * s_ * 65], dw);
+        // ---- store F1: accumulator row = pixel, column = input channel
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = quad_transpose4(acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3], li);
+                const int64_t p = p0 + 32 * wave + 8 * q + 4 * kk + (li & 3);
+                if (p < npix) *reinterpret_cast<float4*>(f1 + (size_t)p * 64 + 32 * c + (li & ~3)) = o;
+            }
+        __syncthreads();        // the tile's LDS images are free
+    }
+    // this workgroup's share of dW [64 in][64 out]: rows 32 wa + (accumulator row), columns 32 wc + li
+    float* out = slab + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(out + (size_t)(32 * wa + 8 * q + 4 * kk + (li & 3)) * 64 + 32 * wc + (li & ~3)) =
+            quad_transpose4(dw[4 * q], dw[4 * q + 1], dw[4 * q + 2], dw[4 * q + 3], li);
+}
+int xc_pw_bwd_slabs() { return XPB_MAX_BLOCKS; }
+int launch_xc_pw_bwd(hipStream_t st, const float* z, const float* gy, const float* dwo, const float* wpw, const float* mean, const float* invstd,
+                     const float* scale, const float* c1c2, float* f1, float* slab, int* nslab, int64_t npix) {
+    const int64_t ntiles = (npix + 127) / 128;
+    const int grid = (int)(ntiles < XPB_MAX_BLOCKS ? ntiles : XPB_MAX_BLOCKS);
+    const size_t smem = (size_t)(128 * 64 + 128 * 65) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(xc_pw_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(xc_pw_bwd_kernel, dim3(grid), dim3(256), smem, st, z, gy, dwo, wpw, mean, invstd, scale, c1c2, f1, slab, npix);
+    *nslab = grid;
+    return 0;
+}
+
 // per-workgroup [sum a | sum a b] over the pixels, 64 channels: STATS: a = b = z (sum z, sum z^2);
 // BWD: a = dy, b = xhat = (z - mean) invstd (sum dy, sum dy xhat).  partial[blockIdx][128]
 template <bool BWD>

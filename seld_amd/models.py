@@ -157,7 +157,7 @@ class SeldNet:
 
     def set_option(self, key: str, value: int) -> None:
         """Kernel-selection knobs of the C library (`seld_set_option`): "conv64_split_bf16", "gemm_split_bf16", "conv1_split_bf16",
-        "conv1_pool_fused", "conv1_gram", "conv64_dbuf", "gru_wgrad_batch", "xc_fused_fwd", "rn_split_bf16"."""
+        "conv1_pool_fused", "conv1_gram", "conv64_dbuf", "gru_wgrad_batch", "xc_fused_fwd", "xc_fused_pw_bwd", "xc_wgrad_side", "rn_split_bf16", "rn_wgrad_side"."""
         _lib.check(self.lib.seld_set_option(self.ctx, key.encode(), int(value)), self.ctx)
 
     def get_grads(self) -> np.ndarray:

@@ -674,7 +674,8 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
 
 
 
-@pytest.mark.parametrize("B,T,blocks,doa_loss,fused", [(2, 50, 8, "MSE", 1), (3, 100, 2, "MMSE", 1), (1, 35, 1, "MSE", 1), (2, 50, 2, "MSE", 0)])
+@pytest.mark.parametrize("B,T,blocks,doa_loss,fused", [(2, 50, 8, "MSE", 1), (3, 100, 2, "MMSE", 1), (1, 35, 1, "MSE", 1), (2, 50, 2, "MSE", 0),
+                                                          (3, 45, 2, "MSE", 2)])
 def test_xception_gru_train_step(xception_config, B, T, blocks, doa_loss, fused):
     """BASELINE config 4 (model_config/xception_gru.json): FIRST = xception_block as published in spec/XCEPTION_BLOCK.md (the
     reference snapshot does not define the block: parity is against OUR spec, restated by the oracle) — one train step and one
@@ -688,7 +689,12 @@ def test_xception_gru_train_step(xception_config, B, T, blocks, doa_loss, fused)
     w, st = O.random_weights(spec, 5)
     x, ys, yd = O.synthetic_batch(B, T, seed=17)
     model = models.seldnet((B, T, 64, 7), cfg)
-    model.set_option("xc_fused_fwd", fused)      # 1 (default): a unit's depthwise + pointwise + statistics in one kernel, BN applied on the next load
+    # 1 (default): a unit's forward in one kernel (BN applied on the next load), its BatchNorm' + pointwise gradients in one kernel, kernel
+    # gradients on the side stream; 0: the separate forward kernels; 2: the separate backward kernels on one stream
+    model.set_option("xc_fused_fwd", 1 if fused else 0)
+    if fused == 2:
+        model.set_option("xc_fused_pw_bwd", 0)
+        model.set_option("xc_wgrad_side", 0)
     tr, nt = O.variable_specs(spec)
     assert [(n, s) for n, _, s in model.variables] == tr and [(n, s) for n, _, s in model.state_variables] == nt
     if blocks == 8:
