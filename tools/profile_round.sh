@@ -40,6 +40,13 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/xc_stats" -o xc -- \
     python3 "$root/bench.py" --model xception_gru --steps 5 --warmup 2 --no-cpu-baseline --no-features --no-kernel-timing > /dev/null 2> "$out/rocprof_xc.log"
 find "$out/xc_stats" -name '*kernel_trace.csv' -delete
+# BASELINE config 5 (resnet50_gru.json; FIRST block per spec/RESNET50_BLOCK.md, 16 clips): bench line + kernel stats
+cd "$root"
+timeout -k 10 200 python3 bench.py --model resnet50_gru --steps 10 --warmup 3 --no-cpu-baseline --no-features > "$out/bench_resnet50_gru.json" 2>> "$out/bench.err"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/rn_stats" -o rn -- \
+    python3 "$root/bench.py" --model resnet50_gru --steps 5 --warmup 2 --no-cpu-baseline --no-features --no-kernel-timing > /dev/null 2> "$out/rocprof_rn.log"
+find "$out/rn_stats" -name '*kernel_trace.csv' -delete
 rm -rf "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"   # raw per-dispatch counters are large; the per-kernel summary stays
 find "$out/stats" -name '*kernel_trace.csv' -delete
 cat "$out/bench.json"
