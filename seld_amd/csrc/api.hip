@@ -90,6 +90,7 @@ struct seld_ctx {
     hipEvent_t ev_rn_ready = nullptr, ev_rn_free[5] = {};
     float* rn_w9_slab = nullptr;           // slabs of the stage-1 3x3 kernel gradients (wgrad_slab belongs to the main stream's first block)
     int rn_wgrad_side = 1;
+    int rn_implicit3x3 = 1;                // stages 2-3: the 3x3 products read im2col rows formed on load (0: materialised im2col / col2im)
     int rn_feat = 0;                         // features per label frame into the first GRU layer (2 x 32 rn_filters)
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
@@ -542,6 +543,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "rn_implicit3x3")) { c->rn_implicit3x3 = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
@@ -668,6 +670,8 @@ static int prepare_gemm_splits(seld_ctx* c, hipStream_t st, bool with_grad_orien
 
 static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int training, int nbx_have = 0, float* part = nullptr);
 // the 3x3 convolution of a stage-1 bottleneck (64 -> 64 channels on a width conv_sb.hip / conv_wgrad_sb.hip have kernels for)
+// ... of a stage-2 / 3 bottleneck: split-bf16 products on im2col rows formed on load (no col tensor)
+static bool rn_c1_implicit(const seld_ctx* c, const RnBlock& R) { return c->rn_implicit3x3 && R.c[1].wsp && R.c[1].wsp_t && rn_conv3_sb_ok(R.w, R.w); }
 static bool rn_c1_direct(const RnBlock& R) { return R.c[1].wsp9 && (R.Wout == 16 || R.Wout == 8 || R.Wout == 4); }
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
@@ -850,7 +854,10 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 for (RnConv* cv : {&R.c[0], &R.c[1], &R.c[2], &R.sc}) {
                     const int K = cv->k * cv->k * cv->Cin, N = cv->Cout;
                     if (cv->wsp) add(c->params + cv->w_off, cv->wsp, N, 0, K, N);
-                    if (cv->wsp_t && save) add(c->params + cv->w_off, cv->wsp_t, N, 1, N, K);
+                    if (cv->wsp_t && save) {
+                        if (cv == &R.c[1] && rn_c1_implicit(c, R)) add(c->params + cv->w_off, cv->wsp_t, N, 2, 9 * N, cv->Cin);    // flipped taps
+                        else add(c->params + cv->w_off, cv->wsp_t, N, 1, N, K);
+                    }
                 }
             if (n) launch_gemm_split_b(st, n, src, dst, ldb, tb, Ks, Ns);
             const float* w9[8]; unsigned short* d9[8]; int f9[8];
@@ -885,6 +892,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 int npart = 0;
                 launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout);
                 rn_bn(c, st, R.c[1], M, training, npart);
+            } else if (sb && rn_c1_implicit(c, R)) {
+                launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w);
+                rn_bn(c, st, R.c[1], M, training);
             } else {
                 launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
                 launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
@@ -1242,6 +1252,12 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
                 done(bbi);
                 launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, R.Wout);
+            } else if (sb && rn_c1_implicit(c, R)) {
+                fork(bbi);
+                launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + R.c[1].w_off, B, S,
+                                      R.Wout, w, w);
+                done(bbi);
+                launch_rn_conv3_dgrad(st, dz1, R.c[1].wsp_t, c->rn_ba, B, S, R.Wout, w, w);
             } else {
                 wgrad(bbi, R.c[1].col, 9 * w, dz1, (int)M, 9 * w, w, R.c[1].w_off);
                 launch_rn_product_dgrad(st, dz1, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);

@@ -153,6 +153,12 @@ int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, con
                             int accumulate);
 int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float* dz, float* slab, int64_t slab_cap, float* dw, int M, int K, int N,
                             int split_bf16);
+// 3x3 'same' convolution [B*H*W][C] -> [B*H*W][N] with the im2col rows formed on load (C, N powers of two >= 128: rn_conv3_sb_ok);
+// wsp = split of w [9 C][N] (transb 0), wsp_flip = split with transb 2 (K = 9 N, N = C): the input-gradient convolution's matrix
+int rn_conv3_sb_ok(int C, int N);
+int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N);
+int launch_rn_conv3_dgrad(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dimg, int B, int H, int W, int C, int N);
+int launch_rn_conv3_wgrad(hipStream_t st, const float* img, const float* dz, float* slab, int64_t slab_cap, float* dw, int B, int H, int W, int C, int N);
 // xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
 int launch_xc_unit_fwd(hipStream_t st, const float* x, const float* kdw, const float* wpw, float* dwo, float* z, float* partial, int* npartial,
                        int B, int H, int W, const float* aff = nullptr);
@@ -209,7 +215,9 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
                         const int* transb, const int* K, const int* N);
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
                    const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
-                   int accum = 0);      // accum: C += (the shortcut's input gradient lands on the reduce convolution's)
+                   int accum = 0,       // accum: C += (the shortcut's input gradient lands on the reduce convolution's)
+                   int conv_C = 0, int conv_H = 0, int conv_W = 0);   // conv_C > 0: A0 = NHWC image [M px][C], the product is its 3x3 'same'
+                                                                       // convolution (K = 9 C, im2col rows formed on load, never stored)
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
@@ -231,7 +239,7 @@ int launch_gemm_tn_sb(hipStream_t st, const float* A, int lda, const float* Bm, 
                       int shift, int want_bias);
 // one product with K1 % 128 == 0 (resnet50_block's kernel gradients): slabs of K1 * N floats, `slab_cap` floats available
 int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int64_t slab_cap, int* nslab,
-                            int M, int K1, int N);
+                            int M, int K1, int N, int conv_C = 0, int conv_H = 0, int conv_W = 0);   // conv_C > 0: A = NHWC image, implicit im2col (K1 = 9 C)
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b);
 int gemm_tn_max_splits();

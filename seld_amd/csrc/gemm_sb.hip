@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
 // M = 19200): K = 2 x 384, N = 128: 37 us against 52 us; K = 128, N = 2 x 384: 38 us against 35 us — the launcher
 // picks by the number of column groups.  (Prefetching three chunks ahead and placing the next chunk's split / LDS stores
 // in the MFMA gaps with sched_group_barrier were both measured slower than this plain form.)
-template <int NG>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
+template <int NG, bool CONV = false>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
 __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
-                                                         int K, int act, int mode, int accum) {
+                                                         int K, int act, int mode, int accum, int cvs, int cvH, int cvW) {
     __shared__ __attribute__((aligned(16))) unsigned short Al[2][3 * 128 * GSB_KC];      // 2 x 24 KB
     __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,7 +251,11 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     const int nck = K / GSB_KC, ng = mode == 2 ? 2 * nck : nck;
     // staging role: row srow, floats [4 sk, 4 sk + 4) of the chunk
     const int srow = tid >> 3, sk = tid & 7;
-    const size_t aoff = (size_t)min(m0 + srow, M - 1) * lda + 4 * sk;
+    const int srowg = min(m0 + srow, M - 1);
+    const size_t aoff = (size_t)srowg * lda + 4 * sk;
+    // CONV (cvs = log2 C): A0 is the NHWC image [M pixels][C], row m of the virtual im2col matrix [M][9 C] is the 3 x 3 neighbourhood of
+    // pixel m (zeros outside the H x W image); a 32-k chunk lies inside one tap because C % 32 == 0
+    const int cvt = CONV ? (srowg / cvW) % cvH : 0, cvf = CONV ? srowg % cvW : 0;
     const int a_dst = srow * GSB_KC + ((((sk >> 1) ^ (srow >> 2)) & 3) << 3) + 4 * (sk & 1);   // bf16 index inside a plane
     const size_t bplane = (size_t)N * GSB_KC / 8;   // plane stride of the pre-split B, in 16-B units
     float4 na;
@@ -259,6 +263,13 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
 #define G16_ISSUE(g_)                                                                                           \
     {                                                                                                           \
         const int h_ = (g_) >= nck ? 1 : 0, gc_ = (g_) - h_ * nck;                                              \
+        if (CONV) {                                                                                             \
+            const int k0_ = gc_ * GSB_KC, tap_ = k0_ >> cvs, dy_ = tap_ / 3 - 1, dx_ = tap_ - 3 * (tap_ / 3) - 1;  \
+            const bool ok_ = (unsigned)(cvt + dy_) < (unsigned)cvH && (unsigned)(cvf + dx_) < (unsigned)cvW;     \
+            const float4 t_ = *reinterpret_cast<const float4*>(                                                 \
+                A0 + (ok_ ? (((size_t)(srowg + dy_ * cvW + dx_)) << cvs) + (k0_ - (tap_ << cvs)) + 4 * sk : 0));    \
+            na = ok_ ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+        } else                                                                                                  \
         na = *reinterpret_cast<const float4*>((h_ ? A1 : A0) + aoff + (size_t)gc_ * GSB_KC);                    \
         const u32x4* bp_ = reinterpret_cast<const u32x4*>((h_ ? Bs1 : Bs0) + ((size_t)gc_ * 3 * N + n0) * GSB_KC); \
         nb0 = bp_[(tid >> 9) * bplane + (tid & 511)];            /* planes 0 and 1 */                           \
@@ -378,30 +389,38 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
 int g_gsb_dbg = 0;
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
                    const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
-                   int accum) {
+                   int accum, int conv_C, int conv_H, int conv_W) {
+    int cvs = 0;
+    if (conv_C) {      // implicit 3x3: K = 9 C, C a power of two >= 32, M = B * H * W pixels, one product
+        while ((1 << cvs) < conv_C) ++cvs;
+        if ((1 << cvs) != conv_C || conv_C < 32 || K != 9 * conv_C || mode != 0 || conv_H <= 0 || conv_W <= 0 || M % (conv_H * conv_W)) return -1;
+        lda = conv_C;
+    }
     if (M <= 0 || N <= 0 || K <= 0 || !gemm_sb_usable(A0, lda, N, K)) return -1;
     if (mode == 2 && !gemm_sb_usable(A1, lda, N, K)) return -1;
     dim3 grid(N / GSB_BN * (mode == 1 ? 2 : 1), (M + 127) / 128);
     // few column groups: not enough row tiles to give every SIMD more than one wave -> the 16-wave form
     const bool wide = grid.x >= 2;
-    if ((g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide)
-        if (K == 128 && mode != 2 && !(g_gsb_dbg & 32))
-            hipLaunchKernelGGL(gemm_sb_kernel<4>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
-                               mode, g_gsb_dbg & 3, accum);
-        else
-            hipLaunchKernelGGL(gemm_sb_kernel<0>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act,
-                               mode, g_gsb_dbg & 3, accum);
-    else {
+    // (an implicit convolution always takes the 16-wave form: its per-chunk address work is shared by 4 column waves there — K = 9 x 256,
+    // N = 256: 198 us against 264 for the 4-wave form)
+    if (cvs ? false : (g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide) {
+#define GSB_GO(NG_) hipLaunchKernelGGL(gemm_sb_kernel<NG_>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
+                                       mode, g_gsb_dbg & 3, accum)
+        if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4);
+        else GSB_GO(0);
+#undef GSB_GO
+    } else {
         const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
-#define G16_GO(NG_) hipLaunchKernelGGL(gemm_sb16_kernel<NG_>, grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum)
-        if (g_gsb_dbg & 16) G16_GO(0);
-        else if (ng == 24) G16_GO(24);       // the GRU input gradients: K = 2 x 384
-        else if (ng == 36) G16_GO(36);       // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
-        else if (ng == 16) G16_GO(16);       // ... its 1x1 products with K = 512
-        else if (ng == 12) G16_GO(12);
-        else if (ng == 8) G16_GO(8);
-        else if (ng == 4) G16_GO(4);
-        else G16_GO(0);
+#define G16_GO(NG_, CV_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
+        if (cvs) { if (ng == 36) G16_GO(36, true); else if (ng == 72) G16_GO(72, true); else G16_GO(0, true); }      // implicit 3x3: K = 9 x 128 / 9 x 256 unrolled
+        else if (g_gsb_dbg & 16) G16_GO(0, false);
+        else if (ng == 36) G16_GO(36, false);       // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
+        else if (ng == 24) G16_GO(24, false);       // the GRU input gradients: K = 2 x 384
+        else if (ng == 16) G16_GO(16, false);       // ... its 1x1 products with K = 512
+        else if (ng == 12) G16_GO(12, false);
+        else if (ng == 8) G16_GO(8, false);
+        else if (ng == 4) G16_GO(4, false);
+        else G16_GO(0, false);
 #undef G16_GO
     }
     return 0;

@@ -37,12 +37,17 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 // follow job j-1's (gridDim.z slabs each)
 // tile_stride > 0 (the convolution kernel gradients of resnet50_block, K1 = a multiple of 128): ONE product, blockIdx.y = the
 // 128-row tile of C (columns 128 y .. of A); a split's slab is the whole [K1][N] matrix, tile_stride floats apart
+// cvs = log2 C > 0 (tile mode only): A is an NHWC image [M pixels][C] and the product's A matrix its virtual im2col [M][9 C] (3 x 3
+// 'same', zeros outside the H x W image): tile y covers columns 128 y .. of it, i.e. ONE tap (C % 128 == 0) at channel offset
+// (128 y) % C — the row of the image is the pixel shifted by the tap, masked at the image border.
 __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
-                                                            int S, int want_bias, long long tile_stride) {
+                                                            int S, int want_bias, long long tile_stride, int cvs, int cvH, int cvW) {
     const int job = tile_stride ? 0 : blockIdx.y;
-    const float* __restrict__ A = jobs.A[job] + (tile_stride ? 128 * blockIdx.y : 0);
+    const int cv_tap = cvs ? (128 * (int)blockIdx.y) >> cvs : 0;
+    const int cv_dy = cv_tap / 3 - 1, cv_dx = cv_tap - 3 * (cv_tap / 3) - 1;
+    const float* __restrict__ A = jobs.A[job] + (cvs ? 128 * (int)blockIdx.y - (cv_tap << cvs) : tile_stride ? 128 * blockIdx.y : 0);
     const float* __restrict__ Bm = jobs.B[job];
-    const int lda = jobs.lda[job], shift = jobs.shift[job];
+    const int lda = cvs ? 1 << cvs : jobs.lda[job], shift = jobs.shift[job];
     __shared__ __attribute__((aligned(16))) char Al[3 * TNSB_PL];
     __shared__ __attribute__((aligned(16))) char Bl[3 * TNSB_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,6 +74,11 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
             const int t = gm % S;                                                                            \
             oka = inb && (t + shift >= 0) && (t + shift < S);                                                \
             am = gm + shift;                                                                                 \
+        }                                                                                                    \
+        if (cvs) {          /* A row = the pixel shifted by this tile's tap */                               \
+            const int pr_ = gm / cvW, f_ = gm - pr_ * cvW, t_ = pr_ % cvH;                                   \
+            oka = inb && (unsigned)(t_ + cv_dy) < (unsigned)cvH && (unsigned)(f_ + cv_dx) < (unsigned)cvW;   \
+            am = gm + cv_dy * cvW + cv_dx;                                                                   \
         }                                                                                                    \
         const float4 ta = *reinterpret_cast<const float4*>(A + (size_t)(oka ? am : 0) * lda + 4 * c4);       \
         const float4 tb = *reinterpret_cast<const float4*>(Bm + (size_t)(inb ? gm : 0) * ldb + n0 + 4 * c4); \
@@ -167,14 +177,20 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL);
+    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
     *nslab = splits;
     return 0;
 }
 // C[K1][N] = A^T B with K1 % 128 == 0: one launch, (K1/128) x (N/128) tiles x splits blocks; slabs of K1 * N floats each (no bias part).
 // The split count fills the card about once (768 resident blocks) within the slab buffer's capacity.
 int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int64_t slab_cap, int* nslab,
-                            int M, int K1, int N) {
+                            int M, int K1, int N, int conv_C, int conv_H, int conv_W) {
+    int cvs = 0;
+    if (conv_C) {      // A = NHWC image, K1 = 9 C, C a power of two and a multiple of 128
+        while ((1 << cvs) < conv_C) ++cvs;
+        if ((1 << cvs) != conv_C || (conv_C % 128) || K1 != 9 * conv_C || conv_H <= 0 || conv_W <= 0 || M % (conv_H * conv_W)) return -1;
+        lda = conv_C;
+    }
     if (M <= 0 || K1 <= 0 || (K1 % 128) || !gemm_tn_sb_usable(A, lda, Bm, ldb, 128, N)) return -1;
     const int tiles = (K1 / 128) * (N / 128);
     int64_t splits = (768 + tiles - 1) / tiles;
@@ -188,7 +204,7 @@ int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float
     TnJobs jobs = {};
     jobs.A[0] = A; jobs.B[0] = Bm; jobs.lda[0] = lda; jobs.shift[0] = 0;
     hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
-                       (long long)K1 * N);
+                       (long long)K1 * N, cvs, conv_H, conv_W);
     *nslab = (int)splits;
     return 0;
 }

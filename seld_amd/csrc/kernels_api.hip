@@ -363,12 +363,13 @@ int seld_k_valu_clock_mhz(int blocks, double* mhz) {
 
 // ---- resnet50_block pieces (resnet.hip + the fp32 GEMMs), as api.hip composes them
 // split `w` ([K,N]; transposed: the planes of w^T) into scratch planes when the split-bf16 product takes the shape, as the model does per step
+// transposed == 2: the matrix of a 3x3 kernel's input-gradient convolution (K = 9 Cin: flipped taps, channels swapped)
 static unsigned short* rn_k_split(Scratch& s, const float* w, int K, int N, int transposed) {
     if (!g_rn_split_bf16 || !(transposed ? rn_sb_dgrad_ok(K, N) : rn_sb_fwd_ok(K, N))) return nullptr;
     unsigned short* d = reinterpret_cast<unsigned short*>(s.get((gemm_sb_split_elems(K, N) + 1) / 2));
     if (!d) return nullptr;
     const float* src[1] = {w}; unsigned short* dst[1] = {d};
-    const int ldb[1] = {N}, tb[1] = {transposed}, Ks[1] = {transposed ? N : K}, Ns[1] = {transposed ? K : N};
+    const int ldb[1] = {N}, tb[1] = {transposed}, Ks[1] = {transposed == 2 ? 9 * N : transposed ? N : K}, Ns[1] = {transposed == 2 ? K / 9 : transposed ? K : N};
     return launch_gemm_split_b(0, 1, src, dst, ldb, tb, Ks, Ns) ? nullptr : d;
 }
 
@@ -381,6 +382,10 @@ int seld_k_rn_conv(const float* x, const float* w, float* z, int B, int H, int W
     const unsigned short* wsp = rn_k_split(s, w, K, Cout, 0);
     if (ksize == 1) {
         if (launch_rn_product_fwd(0, x, Cin * stride_f, w, wsp, z, M, K, Cout)) return SELD_ERR_INVALID;
+        return done();
+    }
+    if (wsp && rn_conv3_sb_ok(Cin, Cout)) {      // im2col rows formed on load
+        if (launch_rn_conv3_fwd(0, x, wsp, z, B, H, W, Cin, Cout)) return SELD_ERR_INVALID;
         return done();
     }
     float* col = s.get((size_t)M * 9 * Cin);
@@ -398,9 +403,17 @@ int seld_k_rn_conv_bwd(const float* x, const float* w, const float* dz, float* d
     Scratch s;
     const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384);     // the model's slab buffer
     float* slab = s.get((size_t)cap);
+    if (!slab) return SELD_ERR_NOMEM;
+    if (ksize == 3 && g_rn_split_bf16 && rn_conv3_sb_ok(Cin, Cout)) {      // both gradients with the im2col rows formed on load
+        const unsigned short* wsp_f = rn_k_split(s, w, K1, Cout, 2);
+        if (!wsp_f) return SELD_ERR_NOMEM;
+        if (launch_rn_conv3_wgrad(0, x, dz, slab, cap, dw, B, H, W, Cin, Cout)) return SELD_ERR_INVALID;
+        if (launch_rn_conv3_dgrad(0, dz, wsp_f, dx, B, H, W, Cin, Cout)) return SELD_ERR_INVALID;
+        return done();
+    }
     float* col = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
     float* dcol = ksize == 3 ? s.get((size_t)M * 9 * Cin) : nullptr;
-    if (!slab || (ksize == 3 && (!col || !dcol))) return SELD_ERR_NOMEM;
+    if (ksize == 3 && (!col || !dcol)) return SELD_ERR_NOMEM;
     const unsigned short* wsp_t = rn_k_split(s, w, K1, Cout, 1);
     if (ksize == 3) {
         launch_im2col3x3(0, x, col, B, H, W, Cin);

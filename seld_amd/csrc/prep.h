@@ -4,7 +4,9 @@
 #pragma once
 #include "common.h"
 
-// B fp32 ([K,N] if !transb, [N,K] if transb) -> planes [chunk c = k/32][plane][n][piece'][8] bf16, piece' = piece ^ ((n >> 2) & 3)
+// B fp32 ([K,N] if !transb, [N,K] if transb) -> planes [chunk c = k/32][plane][n][piece'][8] bf16, piece' = piece ^ ((n >> 2) & 3).
+// transb == 2: src is a 3x3 kernel [9][N = Cin][ldb = Cout] (HWIO) and B the matrix of its INPUT-GRADIENT convolution,
+// B[(tap', co)][ci] = src[8 - tap'][ci][co] (taps flipped, channels swapped), K = 9 Cout
 __device__ __forceinline__ void gemm_split_b_body(const GemmSplitJobs& jobs, int job, int bx, int nbx) {
     const int K = jobs.K[job], N = jobs.N[job], ldb = jobs.ldb[job], transb = jobs.transb[job];
     const float* __restrict__ src = jobs.src[job];
@@ -12,7 +14,12 @@ __device__ __forceinline__ void gemm_split_b_body(const GemmSplitJobs& jobs, int
     for (int idx = bx * 256 + threadIdx.x; idx < K * N; idx += nbx * 256) {
         // the fast index follows the contiguous axis of the source
         const int k = transb ? idx % K : idx / N, n = transb ? idx / K : idx % N;
-        const float x = transb ? src[(size_t)n * ldb + k] : src[(size_t)k * ldb + n];
+        float x;
+        if (transb == 2) {
+            const int co_n = K / 9, tap = k / co_n, co = k - tap * co_n;
+            x = src[((size_t)(8 - tap) * N + n) * ldb + co];
+        } else
+            x = transb ? src[(size_t)n * ldb + k] : src[(size_t)k * ldb + n];
         const unsigned u = __float_as_uint(x);
         const float r = x - __uint_as_float(u & 0xffff0000u);
         const unsigned v = __float_as_uint(r);

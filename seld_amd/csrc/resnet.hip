@@ -349,3 +349,20 @@ int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float
     if (launch_gemm_tn(st, A, lda, dz, N, slab, &ns, M, K, N, 0, 0, 0, splits)) return -1;
     return launch_reduce_slabs2(st, slab, ns, per, dw, (int64_t)K * N, nullptr, 0);
 }
+
+// ---- 3x3 'same' convolution of an NHWC image [B*H*W][C] -> [B*H*W][N] as split-bf16 products whose im2col rows are formed on load
+// (gemm_sb.hip / gemm_tn_sb.hip: conv_C): no col / dcol tensors, no col2im.  C and N powers of two, multiples of 128 (stages 2-3).
+int rn_conv3_sb_ok(int C, int N) { return C >= 128 && N >= 128 && (C & (C - 1)) == 0 && (N & (N - 1)) == 0; }
+// wsp: launch_gemm_split_b(w [9 C][N], transb 0)
+int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N) {
+    return launch_gemm_sb(st, img, nullptr, C, wsp, nullptr, nullptr, nullptr, z, nullptr, N, B * H * W, N, 9 * C, 0, 0, 0, C, H, W);
+}
+// input gradient = the convolution of dz [.][N] with the flipped, channel-swapped kernel; wsp_flip: launch_gemm_split_b(w, ldb N, transb 2, K 9 N, N C)
+int launch_rn_conv3_dgrad(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dimg, int B, int H, int W, int C, int N) {
+    return launch_gemm_sb(st, dz, nullptr, N, wsp_flip, nullptr, nullptr, nullptr, dimg, nullptr, C, B * H * W, C, 9 * N, 0, 0, 0, N, H, W);
+}
+int launch_rn_conv3_wgrad(hipStream_t st, const float* img, const float* dz, float* slab, int64_t slab_cap, float* dw, int B, int H, int W, int C, int N) {
+    int ns = 0;
+    if (launch_gemm_tn_sb_tiles(st, img, C, dz, N, slab, slab_cap, &ns, B * H * W, 9 * C, N, C, H, W)) return -1;
+    return launch_reduce_slabs2(st, slab, ns, (int64_t)9 * C * N, dw, (int64_t)9 * C * N, nullptr, 0);
+}

@@ -556,7 +556,7 @@ def test_conv1_train_without_pre_bn_tensor(seld_lib, B, H, CIN):
 # ---- resnet50_block pieces (spec/RESNET50_BLOCK.md) at the shapes its stages run them at: B*S*W pixels with W = 16, 8, 4, 2
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,stride_f", [(2, 30, 16, 64, 32, 1, 1), (2, 30, 16, 32, 32, 3, 1), (2, 30, 16, 128, 64, 1, 2),
                                                            (4, 60, 2, 256, 256, 3, 1), (4, 60, 2, 256, 1024, 1, 1), (4, 60, 4, 512, 1024, 1, 2),
-                                                           (3, 7, 4, 128, 128, 3, 1), (2, 30, 16, 32, 128, 1, 1), (2, 61, 4, 128, 512, 1, 1)])
+                                                           (3, 7, 4, 128, 128, 3, 1), (2, 30, 16, 32, 128, 1, 1), (2, 61, 4, 128, 512, 1, 1), (2, 21, 4, 128, 256, 3, 1), (5, 9, 2, 256, 128, 3, 1)])
 @pytest.mark.parametrize("split", [1, 0])
 def test_rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f, split):
     """A resnet50_block convolution as its three products (forward, input gradient, kernel gradient) against float64 autograd: on the

@@ -19,6 +19,8 @@ if sys.argv[1] == "run":
     import ctypes as C, torch
     from seld_amd import _lib
     lib = _lib.load()
+    if os.environ.get("SELD_GSB_DBG"):
+        assert lib.seld_k_set_option(b"gsb_dbg", int(os.environ["SELD_GSB_DBG"])) == 0      # 8: force the 16-wave form, 4: the 4-wave form
     p = lambda t: C.c_void_p(t.data_ptr())
     for tag, W, Cin, Cout, k, st in SHAPES:
         x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
