@@ -328,7 +328,9 @@ int seld_debug_relu_output(seld_ctx* ctx, int block, int which, float* dst, int6
 int seld_k_valu_clock_mhz(int blocks, double* mhz);
 /* resnet50_block pieces (spec/RESNET50_BLOCK.md; model_config/resnet50_gru.json:2-11), as the train / predict entry points compose them.
  *   seld_k_rn_conv      z [B,H,W/stride_f,Cout] = Conv2D(Cout, ksize in {1,3}, 'same', strides (1,stride_f), use_bias=False)(x [B,H,W,Cin]);
- *                       w HWIO.  ksize 3: im2col + fp32 MFMA GEMM; ksize 1: the GEMM on rows of stride Cin*stride_f.
+ *                       w HWIO.  ksize 1: a product on rows of stride Cin*stride_f; ksize 3: a product on im2col rows (formed on load by the
+ *                       split-bf16 kernels when Cin and Cout are powers of two >= 128, else materialised); split-bf16 kernels wherever the
+ *                       shape allows unless seld_k_set_option("rn_split_bf16", 0), else the fp32 MFMA GEMM.
  *   seld_k_rn_conv_bwd  dw (HWIO) and dx from dz
  *   seld_k_rn_bn        out = [relu](BatchNormalization(training)(z) [+ res]) over npix x C (C % 32 == 0); mean / invstd optional outputs
  *   seld_k_rn_bn_bwd    dz, dgamma, dbeta from dy gated by (mask > 0) (mask may be NULL) */

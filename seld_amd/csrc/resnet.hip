@@ -1,14 +1,16 @@
 // resnet.hip — channel-count-generic layer kernels for `resnet50_block` (spec/RESNET50_BLOCK.md; model_config/resnet50_gru.json:2-11
-// names the block, the reference snapshot does not define it).  Correctness-first: every convolution is a product on the fp32 MFMA
-// GEMM of gemm.hip — a 1x1 convolution directly (a frequency stride of 2 is a doubled row stride of the operand), a 3x3 convolution
-// through an explicit im2col —, kernel gradients are the TN product of gemm.hip, and BatchNormalization / ReLU / residual adds are
-// streaming kernels over [pixels][C] with float4 over the channels, C any multiple of 32.
+// names the block, the reference snapshot does not define it).  Every convolution is a product — a 1x1 convolution directly (a
+// frequency stride of 2 is a doubled row stride of the operand), a 3x3 convolution on im2col rows that the split-bf16 kernels form on
+// load (stages 2-3), the conv blocks' implicit-GEMM kernels (stage 1) or an explicit im2col (stage 0) —, dispatched by shape at the end
+// of this file (launch_rn_product_* / launch_rn_conv3_*: split-bf16 kernels where the shape allows, else the fp32 MFMA GEMM / TN
+// product of gemm.hip); BatchNormalization / ReLU / residual adds are streaming kernels over [pixels][C] with float4 over the
+// channels, C any multiple of 32.
 //
 //   im2col3x3 / col2im3x3     col[p][tap C + c] = y[p + tap][c] ('same' padding)  /  dy[p][c] = sum_taps dcol[p - tap][tap C + c]
 //   rn_reduce<BWD>            per-workgroup, per 64-channel chunk [sum z | sum z^2]  resp.  [sum dy' | sum dy' xhat], dy' = dy [mask > 0]
 //   rn_bn_finalize / rn_bn_bwd_finalize   the per-channel finalisation of bn_pool.hip for any C (one workgroup per 64 channels)
-//   rn_bn_apply               out = [relu](z scale + shift [+ res])
-//   rn_bn_bwd_dz              dz = scale (dy' - c1 - xhat c2)
+//   rn_bn_apply / rn_bn_apply2   out = [relu](z scale + shift [+ res])  /  relu(BN(z) + BN_r(z_r)) for a projection block
+//   rn_bn_bwd_dz              dz = scale (dy' - c1 - xhat c2)   (GATEZ forms of both backward kernels: the gate recomputed from z)
 //   rn_add_masked             dst += dy [mask > 0]
 #include "common.h"
 #include <algorithm>
