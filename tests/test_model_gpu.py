@@ -715,7 +715,8 @@ def test_xception_gru_train_step(xception_config, B, T, blocks, doa_loss, fused)
 
 
 
-@pytest.mark.parametrize("B,T,blocks,doa_loss,split", [(4, 300, [1, 1, 1, 1], "MSE", 1), (4, 300, [1, 1, 1, 1], "MSE", 0), (3, 300, [2, 1, 1, 1], "MMSE", 1),
+@pytest.mark.parametrize("B,T,blocks,doa_loss,split", [(4, 300, [1, 1, 1, 1], "MSE", 1), (4, 300, [1, 1, 1, 1], "MSE", 0), (4, 300, [1, 1, 1, 1], "MSE", 2),
+                                                         (3, 300, [2, 1, 1, 1], "MMSE", 1),
                                                          (2, 300, [3, 4, 6, 3], "MSE", 1)])
 def test_resnet50_gru_train_step(resnet50_config, B, T, blocks, doa_loss, split):
     """BASELINE config 5's model (model_config/resnet50_gru.json): FIRST = resnet50_block as published in spec/RESNET50_BLOCK.md (the
@@ -741,7 +742,13 @@ def test_resnet50_gru_train_step(resnet50_config, B, T, blocks, doa_loss, split)
     w, st = O.random_weights(spec, 7)
     x, ys, yd = O.synthetic_batch(B, T, seed=19)
     model = models.seldnet((B, T, 64, 7), cfg)
-    model.set_option("rn_split_bf16", split)      # 1 (default): stages 2-3 and the 128-column products of stages 0-1 on the split-bf16 kernels
+    # 1 (default): stages 2-3 and the 128-column products of stages 0-1 on the split-bf16 kernels (3x3: im2col rows formed on load), kernel
+    # gradients and projection shortcuts on the side stream; 0: every product on the fp32 MFMA GEMM; 2: split-bf16 products on a
+    # materialised im2col, one stream
+    model.set_option("rn_split_bf16", 1 if split else 0)
+    if split == 2:
+        model.set_option("rn_implicit3x3", 0)
+        model.set_option("rn_wgrad_side", 0)
     tr, nt = O.variable_specs(spec)
     assert [(n, s) for n, _, s in model.variables] == tr and [(n, s) for n, _, s in model.state_variables] == nt
     if blocks == [3, 4, 6, 3]:
