@@ -47,6 +47,7 @@ struct RnBlock {
     bool proj;
     RnConv c[3], sc;
     float *y0 = nullptr, *y1 = nullptr, *out = nullptr;      // ReLU(BN(c0)), ReLU(BN(c1)) [M, w]; block output [M, 4w]
+    unsigned char* gate = nullptr;                          // [M, w]: bit j of byte q = (out[4 q + j] > 0), written by the forward's last pass
 };
 
 // one  ReLU -> SeparableConv2D(64, 3, use_bias=False) -> BatchNormalization  unit of xception_block's middle flow (spec/XCEPTION_BLOCK.md)
@@ -403,7 +404,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             for (int i = 0; i < 3; ++i) { ALLOC(R.c[i].z, M * R.c[i].Cout); ALLOC(R.c[i].coef, (size_t)6 * R.c[i].Cout); }
             ALLOC(R.c[1].col, M * 9 * R.w);
             if (R.proj) { ALLOC(R.sc.z, M * 4 * R.w); ALLOC(R.sc.coef, (size_t)6 * 4 * R.w); }
-            ALLOC(R.y0, M * R.w); ALLOC(R.y1, M * R.w); ALLOC(R.out, M * 4 * R.w);
+            ALLOC(R.y0, M * R.w); ALLOC(R.y1, M * R.w); ALLOC(R.out, M * 4 * R.w); ALLOC(R.gate, M * R.w);
             mx_out = std::max(mx_out, M * 4 * R.w); mx_w = std::max(mx_w, M * R.w); mx_col = std::max(mx_col, M * 9 * R.w);
             mx_in = std::max(mx_in, (size_t)B * S * R.Win * R.Cin);
         }
@@ -910,9 +911,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                     launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
                     rn_bn(c, st, R.sc, M, training);
                 }
-                launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w);
+                launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w, save ? R.gate : nullptr);
             } else {
-                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1);
+                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1, save ? R.gate : nullptr);
             }
             X = R.out;
         }
@@ -1076,10 +1077,11 @@ static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int traini
     launch_rn_bn_finalize(st, part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
 }
 // backward of the same: dz = BN'(dy [mask > 0]) into `dz`, dgamma / dbeta into the gradient buffer
-// mask == nullptr: the BatchNorm feeds a ReLU directly (no residual) and the gate is recomputed from z
-static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, const float* mask, float* dz, int64_t M) {
+// gate4 == nullptr: the BatchNorm feeds a ReLU directly (no residual) and the gate is recomputed from z; else the block output's gate bytes
+static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, const unsigned char* gate4, float* dz, int64_t M) {
     int nbx = 0;
-    const int gate_z = mask == nullptr;
+    const int gate_z = gate4 ? 2 : 1;
+    const float* mask = reinterpret_cast<const float*>(gate4);
     launch_rn_bn_bwd_reduce(st, cv.z, dy, mask, cv.coef, c->rn_part, &nbx, M, cv.Cout, gate_z);
     if (c->sync_fn) {
         const int nd = (cv.Cout + 63) / 64 * 128;
@@ -1239,7 +1241,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const int ldx = R.Cin * R.stride_f;
             // main branch: BN2 (behind the block's ReLU: mask = out), 1x1 expand
             float* dz2 = take(0, 2, zi);
-            rn_bn_bwd(c, st, R.c[2], g, R.out, dz2, M);
+            rn_bn_bwd(c, st, R.c[2], g, R.gate, dz2, M);
             wgrad(zi, R.y1, w, dz2, (int)M, w, 4 * w, R.c[2].w_off);
             launch_rn_product_dgrad(st, dz2, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
             // BN1 (mask = y1), 3x3: stage 1 on the conv blocks' kernels, the other widths through im2col / col2im
@@ -1272,11 +1274,11 @@ static int backward_impl(seld_ctx* c, const float* x) {
             // shortcut
             if (R.proj) {
                 float* dzs = take(0, 2, zi);
-                rn_bn_bwd(c, st, R.sc, g, R.out, dzs, M);
+                rn_bn_bwd(c, st, R.sc, g, R.gate, dzs, M);
                 wgrad(zi, X, ldx, dzs, (int)M, R.Cin, 4 * w, R.sc.w_off);
                 launch_rn_product_dgrad(st, dzs, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1);
             } else {
-                launch_rn_add_masked(st, dX, g, R.out, M * 4 * w);
+                launch_rn_add_gated(st, dX, g, R.gate, M * 4 * w);
             }
             g = dX;
             flip ^= 1;

@@ -137,11 +137,16 @@ int launch_rn_bn_finalize(hipStream_t st, const float* partial, int nbx, double 
                           float* mov_var, float* coef, int C, int training, double* sums = nullptr, int phase = 0);
 int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, double count, float* dgamma, float* dbeta, float* coef, int C,
                               double* sums = nullptr, int phase = 0);
-int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu);
-// gate_z: the ReLU gate recomputed from z and the coefficients (a BatchNorm without residual) instead of read from `mask`
+// gate4 (optional): one byte per 4 channels, bit j = (out channel j > 0) — what the backward's three readers of the block output's gate take
+int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu,
+                       unsigned char* gate4 = nullptr);
+int launch_rn_add_gated(hipStream_t st, float* dst, const float* dy, const unsigned char* gate4, int64_t n);
+// gate_z: 1 = the ReLU gate recomputed from z and the coefficients (a BatchNorm without residual) instead of read from `mask`;
+// 2 = `mask` points to gate bytes (launch_rn_bn_apply's gate4)
 int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C,
                         int gate_z = 0);
-int launch_rn_bn_apply2(hipStream_t st, const float* z, const float* coef, const float* zr, const float* coef_r, float* out, int64_t npix, int C);
+int launch_rn_bn_apply2(hipStream_t st, const float* z, const float* coef, const float* zr, const float* coef_r, float* out, int64_t npix, int C,
+                        unsigned char* gate4 = nullptr);
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n);
 // the three products of a convolution ([M,K] rows x [K,N] kernel): split-bf16 kernels when the shape allows and pre-split planes are
 // given (wsp: launch_gemm_split_b of w, wsp_t: of w^T), else the fp32 MFMA GEMM

@@ -68,9 +68,11 @@ int launch_col2im3x3(hipStream_t st, const float* dcol, float* dy, int B, int H,
 
 // grid (blocks_x, C / 64): workgroup (x, y) reduces the pixels x, x + gridDim.x, ... of channels [64 y, 64 y + 64).
 // partial[(y * gridDim.x + x)][128]
-// GATEZ (backward, no residual behind the BatchNorm): the ReLU's gate is recomputed from z — fma(z, scale, shift) > 0 is bit for bit
-// what rn_bn_apply wrote through its max(., 0) — instead of read from the stored output
-template <bool BWD, bool GATEZ = false>
+// The backward's gate dy' = dy [y > 0], by MASKM: 0 = read from the float tensor `mask` (or none); 1 (no residual behind the
+// BatchNorm) = recomputed from z — fma(z, scale, shift) > 0 is bit for bit what rn_bn_apply wrote through its max(., 0); 2 = read
+// from the gate bytes rn_bn_apply left beside the block output (one byte per 4 channels, bit j = channel j's output > 0: a
+// sixteenth of the float tensor's traffic, and the block output's gate is read three times in the backward)
+template <bool BWD, int MASKM = 0>
 __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
                                                         const float* __restrict__ coef, float* __restrict__ partial, int64_t npix, int C) {
     __shared__ float red[256 * 8];
@@ -79,14 +81,17 @@ __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict_
     const bool gok = c0 < C;                 // C = 32: half of the chunk's groups have no channels
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1, gsc = s1, gsh = s1;
     if (BWD && gok) { mu = *reinterpret_cast<const float4*>(coef + c0); is = *reinterpret_cast<const float4*>(coef + C + c0); }
-    if (GATEZ && gok) { gsc = *reinterpret_cast<const float4*>(coef + 2 * C + c0); gsh = *reinterpret_cast<const float4*>(coef + 3 * C + c0); }
+    if (MASKM == 1 && gok) { gsc = *reinterpret_cast<const float4*>(coef + 2 * C + c0); gsh = *reinterpret_cast<const float4*>(coef + 3 * C + c0); }
     for (int64_t p = (int64_t)blockIdx.x * 16 + slot; gok && p < npix; p += (int64_t)gridDim.x * 16) {
         const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c0);
         if (BWD) {
             float4 d = *reinterpret_cast<const float4*>(dy + p * C + c0);
-            if (GATEZ) {
+            if (MASKM == 1) {
                 const float4 m = rn_fma4(zv, gsc, gsh);
                 d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+            } else if (MASKM == 2) {
+                const unsigned m = reinterpret_cast<const unsigned char*>(mask)[(p * C + c0) >> 2];
+                d = make_float4((m & 1) ? d.x : 0.f, (m & 2) ? d.y : 0.f, (m & 4) ? d.z : 0.f, (m & 8) ? d.w : 0.f);
             } else if (mask) {
                 const float4 m = *reinterpret_cast<const float4*>(mask + p * C + c0);
                 d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
@@ -116,15 +121,16 @@ static int rn_blocks_x(int64_t npix) {
 int launch_rn_bn_stats(hipStream_t st, const float* z, float* partial, int* nbx, int64_t npix, int C) {
     if (C % 32) return -2;
     *nbx = rn_blocks_x(npix);
-    hipLaunchKernelGGL((rn_reduce_kernel<false, false>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix, C);
+    hipLaunchKernelGGL((rn_reduce_kernel<false, 0>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, nullptr, nullptr, nullptr, partial, npix, C);
     return 0;
 }
 int launch_rn_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* partial, int* nbx,
                             int64_t npix, int C, int gate_z) {
     if (C % 32) return -2;
     *nbx = rn_blocks_x(npix);
-    if (gate_z) hipLaunchKernelGGL((rn_reduce_kernel<true, true>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, nullptr, coef, partial, npix, C);
-    else hipLaunchKernelGGL((rn_reduce_kernel<true, false>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
+    if (gate_z == 1) hipLaunchKernelGGL((rn_reduce_kernel<true, 1>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, nullptr, coef, partial, npix, C);
+    else if (gate_z == 2) hipLaunchKernelGGL((rn_reduce_kernel<true, 2>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
+    else hipLaunchKernelGGL((rn_reduce_kernel<true, 0>), dim3(*nbx, (C + 63) / 64), dim3(256), 0, st, z, dy, mask, coef, partial, npix, C);
     return 0;
 }
 
@@ -233,7 +239,7 @@ int launch_rn_bn_bwd_finalize(hipStream_t st, const float* partial, int nbx, dou
 
 // out = [relu](z scale + shift [+ res]); G = C / 4
 __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ res,
-                                                          float* __restrict__ out, int64_t n4, int G, int relu) {
+                                                          float* __restrict__ out, int64_t n4, int G, int relu, unsigned char* __restrict__ gate4) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= n4) return;
     const int g = (int)(gid % G), C = 4 * G;
@@ -245,10 +251,12 @@ __global__ __launch_bounds__(256) void rn_bn_apply_kernel(const float* __restric
     }
     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     reinterpret_cast<float4*>(out)[gid] = o;
+    if (gate4) gate4[gid] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
 }
 // out = relu(BN(z) + BN_r(zr)): the block output of a projection bottleneck in one pass (both BatchNorms applied on load)
 __global__ __launch_bounds__(256) void rn_bn_apply2_kernel(const float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ zr,
-                                                           const float* __restrict__ coef_r, float* __restrict__ out, int64_t n4, int G) {
+                                                           const float* __restrict__ coef_r, float* __restrict__ out, int64_t n4, int G,
+                                                           unsigned char* __restrict__ gate4) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= n4) return;
     const int g = (int)(gid % G), C = 4 * G;
@@ -259,20 +267,23 @@ __global__ __launch_bounds__(256) void rn_bn_apply2_kernel(const float* __restri
                        reinterpret_cast<const float4*>(coef + 3 * C)[g]);
     o = make_float4(fmaxf(o.x + r.x, 0.f), fmaxf(o.y + r.y, 0.f), fmaxf(o.z + r.z, 0.f), fmaxf(o.w + r.w, 0.f));
     reinterpret_cast<float4*>(out)[gid] = o;
+    if (gate4) gate4[gid] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
 }
-int launch_rn_bn_apply2(hipStream_t st, const float* z, const float* coef, const float* zr, const float* coef_r, float* out, int64_t npix, int C) {
+int launch_rn_bn_apply2(hipStream_t st, const float* z, const float* coef, const float* zr, const float* coef_r, float* out, int64_t npix, int C,
+                        unsigned char* gate4) {
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(rn_bn_apply2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, zr, coef_r, out, n4, C / 4);
+    hipLaunchKernelGGL(rn_bn_apply2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, zr, coef_r, out, n4, C / 4, gate4);
     return 0;
 }
-int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu) {
+int launch_rn_bn_apply(hipStream_t st, const float* z, const float* coef, const float* res, float* out, int64_t npix, int C, int relu,
+                       unsigned char* gate4) {
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(rn_bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, res, out, n4, C / 4, relu);
+    hipLaunchKernelGGL(rn_bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, coef, res, out, n4, C / 4, relu, gate4);
     return 0;
 }
 
 // dz = scale (dy' - c1 - xhat c2), dy' = dy [mask > 0]
-template <bool GATEZ>
+template <int MASKM>
 __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ mask,
                                                            const float* __restrict__ coef, float* __restrict__ dz, int64_t n4, int G) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -282,9 +293,12 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restri
     float4 d = reinterpret_cast<const float4*>(dy)[gid];
     const float4 mu = reinterpret_cast<const float4*>(coef)[g], is = reinterpret_cast<const float4*>(coef + C)[g];
     const float4 sc = reinterpret_cast<const float4*>(coef + 2 * C)[g], c1 = reinterpret_cast<const float4*>(coef + 4 * C)[g];
-    if (GATEZ) {
+    if (MASKM == 1) {
         const float4 m = rn_fma4(zv, sc, reinterpret_cast<const float4*>(coef + 3 * C)[g]);
         d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+    } else if (MASKM == 2) {
+        const unsigned m = reinterpret_cast<const unsigned char*>(mask)[gid];
+        d = make_float4((m & 1) ? d.x : 0.f, (m & 2) ? d.y : 0.f, (m & 4) ? d.z : 0.f, (m & 8) ? d.w : 0.f);
     } else if (mask) {
         const float4 m = reinterpret_cast<const float4*>(mask)[gid];
         d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
@@ -300,8 +314,9 @@ __global__ __launch_bounds__(256) void rn_bn_bwd_dz_kernel(const float* __restri
 int launch_rn_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mask, const float* coef, float* dz, int64_t npix, int C,
                         int gate_z) {
     const int64_t n4 = npix * (C / 4);
-    if (gate_z) hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, nullptr, coef, dz, n4, C / 4);
-    else hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
+    if (gate_z == 1) hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, nullptr, coef, dz, n4, C / 4);
+    else if (gate_z == 2) hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<2>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
+    else hipLaunchKernelGGL(rn_bn_bwd_dz_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, z, dy, mask, coef, dz, n4, C / 4);
     return 0;
 }
 
@@ -313,6 +328,20 @@ __global__ __launch_bounds__(256) void rn_add_masked_kernel(float* __restrict__ 
     float4 o = reinterpret_cast<float4*>(dst)[gid];
     o = make_float4(o.x + (m.x > 0.f ? d.x : 0.f), o.y + (m.y > 0.f ? d.y : 0.f), o.z + (m.z > 0.f ? d.z : 0.f), o.w + (m.w > 0.f ? d.w : 0.f));
     reinterpret_cast<float4*>(dst)[gid] = o;
+}
+__global__ __launch_bounds__(256) void rn_add_gated_kernel(float* __restrict__ dst, const float* __restrict__ dy, const unsigned char* __restrict__ gate4,
+                                                           int64_t n4) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n4) return;
+    const float4 d = reinterpret_cast<const float4*>(dy)[gid];
+    const unsigned m = gate4[gid];
+    float4 o = reinterpret_cast<float4*>(dst)[gid];
+    o = make_float4(o.x + ((m & 1) ? d.x : 0.f), o.y + ((m & 2) ? d.y : 0.f), o.z + ((m & 4) ? d.z : 0.f), o.w + ((m & 8) ? d.w : 0.f));
+    reinterpret_cast<float4*>(dst)[gid] = o;
+}
+int launch_rn_add_gated(hipStream_t st, float* dst, const float* dy, const unsigned char* gate4, int64_t n) {
+    hipLaunchKernelGGL(rn_add_gated_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, dy, gate4, n / 4);
+    return 0;
 }
 int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const float* mask, int64_t n) {
     hipLaunchKernelGGL(rn_add_masked_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, dy, mask, n / 4);
