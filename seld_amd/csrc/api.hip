@@ -41,6 +41,7 @@ struct RnConv {
     float *col = nullptr, *z = nullptr, *coef = nullptr;     // im2col of the input (k = 3), pre-BN output, [mean|invstd|scale|shift|c1|c2] x Cout
     unsigned short *wsp = nullptr, *wsp_t = nullptr;         // pre-split bf16 planes of the kernel / its transpose (shapes the split-bf16 GEMM takes)
     unsigned short *wsp9 = nullptr, *wsp9_flip = nullptr;    // 3x3, 64 -> 64 (stage 1): tap planes for the implicit-GEMM kernels of conv_sb.hip
+    float *w2 = nullptr, *dw2 = nullptr;                     // 3x3, 32 -> 32 (stage 0): the kernel embedded as 64 -> 64 over pairs of bins, its gradient
 };
 struct RnBlock {
     int Cin, w, stride_f, Win, Wout;
@@ -414,7 +415,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
                 if (!N) continue;
                 if (rn_sb_fwd_ok(K, N)) ALLOC(cv->wsp, gemm_sb_split_elems(K, N));
                 if (rn_sb_dgrad_ok(K, N)) ALLOC(cv->wsp_t, gemm_sb_split_elems(K, N));
-                if (cv->k == 3 && cv->Cin == 64 && N == 64) { ALLOC(cv->wsp9, (size_t)9 * 3 * 4096); ALLOC(cv->wsp9_flip, (size_t)9 * 3 * 4096); }
+                if (cv->k == 3 && ((cv->Cin == 64 && N == 64) || (cv->Cin == 32 && N == 32))) {
+                    ALLOC(cv->wsp9, (size_t)9 * 3 * 4096); ALLOC(cv->wsp9_flip, (size_t)9 * 3 * 4096);
+                    if (N == 32) { ALLOC(cv->w2, (size_t)9 * 4096); ALLOC(cv->dw2, (size_t)9 * 4096); }
+                }
             }
         ALLOC(c->rn_part, (size_t)rn_partial_capacity() * 16 * 128);
         ALLOC(c->rn_part_side, (size_t)rn_partial_capacity() * 16 * 128);
@@ -673,7 +677,12 @@ static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int traini
 // the 3x3 convolution of a stage-1 bottleneck (64 -> 64 channels on a width conv_sb.hip / conv_wgrad_sb.hip have kernels for)
 // ... of a stage-2 / 3 bottleneck: split-bf16 products on im2col rows formed on load (no col tensor)
 static bool rn_c1_implicit(const seld_ctx* c, const RnBlock& R) { return c->rn_implicit3x3 && R.c[1].wsp && R.c[1].wsp_t && rn_conv3_sb_ok(R.w, R.w); }
-static bool rn_c1_direct(const RnBlock& R) { return R.c[1].wsp9 && (R.Wout == 16 || R.Wout == 8 || R.Wout == 4); }
+// (stage 0: 32 -> 32 channels as 64 -> 64 over pairs of bins, rn_c1_width = the width the kernels see)
+static int rn_c1_width(const RnBlock& R) { return R.c[1].w2 ? R.Wout / 2 : R.Wout; }
+static bool rn_c1_direct(const RnBlock& R) {
+    const int W = rn_c1_width(R);
+    return R.c[1].wsp9 && (!R.c[1].w2 || (R.Wout & 1) == 0) && (W == 16 || W == 8 || W == 4);
+}
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     hipStream_t st = c->stream;
@@ -865,8 +874,10 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             n = 0;
             for (auto& R : c->rn) {
                 if (!rn_c1_direct(R)) continue;
-                w9[n] = c->params + R.c[1].w_off; d9[n] = R.c[1].wsp9; f9[n++] = 0;
-                if (save) { w9[n] = c->params + R.c[1].w_off; d9[n] = R.c[1].wsp9_flip; f9[n++] = 1; }
+                const float* wsrc = c->params + R.c[1].w_off;
+                if (R.c[1].w2) { launch_rn_w32_embed(st, wsrc, R.c[1].w2); wsrc = R.c[1].w2; }
+                w9[n] = wsrc; d9[n] = R.c[1].wsp9; f9[n++] = 0;
+                if (save) { w9[n] = wsrc; d9[n] = R.c[1].wsp9_flip; f9[n++] = 1; }
                 if (n >= 7) { launch_split_weights_batch(st, n, w9, d9, f9); n = 0; }
             }
             if (n) launch_split_weights_batch(st, n, w9, d9, f9);
@@ -891,8 +902,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             // the other widths as a product on im2col rows
             if (sb && rn_c1_direct(R)) {
                 int npart = 0;
-                launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout);
-                rn_bn(c, st, R.c[1], M, training, npart);
+                if (R.c[1].w2) {      // stage 0: the epilogue's sums are per (bin parity, channel): the statistics pass instead
+                    launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, nullptr, nullptr, B, S, rn_c1_width(R));
+                    rn_bn(c, st, R.c[1], M, training);
+                } else {
+                    launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout);
+                    rn_bn(c, st, R.c[1], M, training, npart);
+                }
             } else if (sb && rn_c1_implicit(c, R)) {
                 launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w);
                 rn_bn(c, st, R.c[1], M, training);
@@ -1250,10 +1266,14 @@ static int backward_impl(seld_ctx* c, const float* x) {
             if (sb && rn_c1_direct(R)) {
                 fork(bbi);
                 int ns = 0;
-                launch_conv64_wgrad_sb(ws, R.y0, dz1, c->rn_w9_slab, &ns, B, S, R.Wout);
-                launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
+                launch_conv64_wgrad_sb(ws, R.y0, dz1, c->rn_w9_slab, &ns, B, S, rn_c1_width(R));
+                if (R.c[1].w2) {
+                    launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, R.c[1].dw2, 9 * 4096, 0);
+                    launch_rn_w32_extract(ws, R.c[1].dw2, c->grads + R.c[1].w_off);
+                } else
+                    launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
                 done(bbi);
-                launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, R.Wout);
+                launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, rn_c1_width(R));
             } else if (sb && rn_c1_implicit(c, R)) {
                 fork(bbi);
                 launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + R.c[1].w_off, B, S,

@@ -160,6 +160,9 @@ int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float
                             int split_bf16);
 // 3x3 'same' convolution [B*H*W][C] -> [B*H*W][N] with the im2col rows formed on load (C, N powers of two >= 128: rn_conv3_sb_ok);
 // wsp = split of w [9 C][N] (transb 0), wsp_flip = split with transb 2 (K = 9 N, N = C): the input-gradient convolution's matrix
+// stage 0's 32 -> 32 3x3 as a 64 -> 64 3x3 over pairs of bins (resnet.hip): w [9][32][32] -> W2 [9][64][64]; dW2 -> dw
+int launch_rn_w32_embed(hipStream_t st, const float* w, float* w2);
+int launch_rn_w32_extract(hipStream_t st, const float* dw2, float* dw);
 int rn_conv3_sb_ok(int C, int N);
 int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N);
 int launch_rn_conv3_dgrad(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dimg, int B, int H, int W, int C, int N);
@@ -226,7 +229,7 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
 // C[K1,N] = sum_m A[rowmap(m),K1]^T B[m,N]; rows are (b,t) with t in [0,S): A row uses t+shift (zero if outside)
 // slab layout per split: [K1*N main | N column sums of B (valid if want_bias)]
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits = 0);
+                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits = 0, int chunk_rows = 32);
 // split-bf16 form with transposed LDS reads (gemm_tn_sb.hip): K1 = 128, N % 128 == 0; same slabs as launch_gemm_tn
 int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N);
 // several products of one shape in one launch (+ one combine launch): job j's slabs follow job j-1's (nslab each)

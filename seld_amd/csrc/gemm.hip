@@ -313,12 +313,15 @@ int launch_gemm_dual_k(hipStream_t st, const float* A0, const float* A1, int lda
 #define TN_MAX_SPLITS 128
 int gemm_tn_max_splits() { return TN_MAX_SPLITS; }
 
+// CR = rows per chunk: 32, or 64 for the long skinny products of resnet50_block's first stages (M = 10^5 rows, a 64 x 64 output): the
+// loop prefetches one chunk ahead, so a chunk costs a load round trip, and twice the rows per trip halve the trips
+template <int CR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ Bm, int ldb,
                                                       float* __restrict__ slab, int M, int K1, int N,
                                                       int rows_per_split, int S, int shift, int want_bias) {
-    __shared__ __attribute__((aligned(16))) float As[32 * 64];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * 64];
+    __shared__ __attribute__((aligned(16))) float As[CR * 64];
+    __shared__ __attribute__((aligned(16))) float Bs[CR * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, li = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
@@ -330,9 +333,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     f32x16 acc = zero16(), acc1 = zero16();
     float bsum = 0.f;  // tid < 64 of the k1-tile-0 blocks: column sum of B (bias gradient)
     const bool do_bias = want_bias && blockIdx.y == 0 && tid < 64;
-    float va[2][4], vb[2][4];
+    constexpr int NU = CR / 16;       // float4 per thread and operand per chunk
+    float va[NU][4], vb[NU][4];
 #define TN_LOAD(mm0_)                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                     \
         const int idx = tid + 256 * u;                                                                   \
         const int r = idx >> 4, c4 = (idx & 15) * 4;                                                     \
         const int gm = (mm0_) + r;                                                                       \
@@ -365,20 +369,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }                                                                                                \
     }
 #define TN_COMMIT()                                                                                      \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                      \
         const int idx = tid + 256 * u;                                                                   \
         const int r = idx >> 4, c4 = (idx & 15) * 4;                                                     \
         *reinterpret_cast<float4*>(&As[r * 64 + c4]) = make_float4(va[u][0], va[u][1], va[u][2], va[u][3]); \
         *reinterpret_cast<float4*>(&Bs[r * 64 + c4]) = make_float4(vb[u][0], vb[u][1], vb[u][2], vb[u][3]); \
     }
     TN_LOAD(mbeg)
-    for (int mm0 = mbeg; mm0 < mend; mm0 += 32) {
+    for (int mm0 = mbeg; mm0 < mend; mm0 += CR) {
         TN_COMMIT()
         lds_barrier();
-        if (mm0 + 32 < mend) TN_LOAD(mm0 + 32)
+        if (mm0 + CR < mend) TN_LOAD(mm0 + CR)
         if (do_bias) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) bsum += Bs[r * 64 + tid];
+            for (int r = 0; r < CR; ++r) bsum += Bs[r * 64 + tid];
         }
         {
             float ra[4], rb[4];
@@ -388,12 +392,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 rb[u] = Bs[(2 * u + hi) * 64 + wc * 32 + li];
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < CR / 2; ++s) {
                 const int u = s & 3;
                 __builtin_amdgcn_sched_barrier(0);
                 if (s & 1) acc1 = MFMA_F32_32x32x2(ra[u], rb[u], acc1);
                 else acc = MFMA_F32_32x32x2(ra[u], rb[u], acc);
-                if (s + 4 < 16) {
+                if (s + 4 < CR / 2) {
                     ra[u] = As[(2 * (s + 4) + hi) * 64 + wr * 32 + li];
                     rb[u] = Bs[(2 * (s + 4) + hi) * 64 + wc * 32 + li];
                 }
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int* nslab,
-                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits) {
+                   int M, int K1, int N, int S, int shift, int want_bias, int max_splits, int chunk_rows) {
     if (M <= 0 || K1 <= 0 || N <= 0) return -1;
     if (max_splits <= 0) max_splits = TN_MAX_SPLITS;       // callers with small K1 x N slabs may ask for more (the slab buffer permitting)
     // Rows per split: the loop prefetches one 32-row chunk ahead, i.e. every chunk costs a load round trip (~2 us) unless other
@@ -434,10 +438,12 @@ int launch_gemm_tn(hipStream_t st, const float* A, int lda, const float* Bm, int
     int splits = (M + 159) / 160;
     if (splits > max_splits) splits = max_splits;
     int rps = (M + splits - 1) / splits;
-    rps = (rps + 31) / 32 * 32;
+    const int cr = chunk_rows == 64 ? 64 : 32;
+    rps = (rps + cr - 1) / cr * cr;
     splits = (M + rps - 1) / rps;
     dim3 grid((N + 63) / 64, (K1 + 63) / 64, splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, Bm, ldb, slab, M, K1, N, rps, S > 0 ? S : M, shift, want_bias);
+    if (cr == 64) hipLaunchKernelGGL(gemm_tn_kernel<64>, grid, dim3(256), 0, st, A, lda, Bm, ldb, slab, M, K1, N, rps, S > 0 ? S : M, shift, want_bias);
+    else hipLaunchKernelGGL(gemm_tn_kernel<32>, grid, dim3(256), 0, st, A, lda, Bm, ldb, slab, M, K1, N, rps, S > 0 ? S : M, shift, want_bias);
     *nslab = splits;
     return 0;
 }

@@ -377,7 +377,7 @@ int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float
         return launch_reduce_slabs2(st, slab, ns, (int64_t)K * N, dw, (int64_t)K * N, nullptr, 0);
     const int64_t per = (int64_t)K * N + N;
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, slab_cap / per));
-    if (launch_gemm_tn(st, A, lda, dz, N, slab, &ns, M, K, N, 0, 0, 0, splits)) return -1;
+    if (launch_gemm_tn(st, A, lda, dz, N, slab, &ns, M, K, N, 0, 0, 0, splits, 64)) return -1;
     return launch_reduce_slabs2(st, slab, ns, per, dw, (int64_t)K * N, nullptr, 0);
 }
 
@@ -396,4 +396,43 @@ int launch_rn_conv3_wgrad(hipStream_t st, const float* img, const float* dz, flo
     int ns = 0;
     if (launch_gemm_tn_sb_tiles(st, img, C, dz, N, slab, slab_cap, &ns, B * H * W, 9 * C, N, C, H, W)) return -1;
     return launch_reduce_slabs2(st, slab, ns, (int64_t)9 * C * N, dw, (int64_t)9 * C * N, nullptr, 0);
+}
+
+// ---- stage 0's 3x3 convolution (32 -> 32 channels on 16 frequency bins) on the 64-channel kernels of the conv blocks -------------
+// Two neighbouring bins of 32 channels ARE one "super-pixel" of 64 channels in memory ([.., 16, 32] = [.., 8, 64]), and the 3x3
+// convolution over pixels is a 3x3 convolution over super-pixels with the kernel
+//     W2[dy][DX][32 h' + ci][32 h + co] = w[dy][dx = 2 DX + h' - h][ci][co]   (0 where dx is outside -1..1)
+// (input pixel 2 (J + DX) + h' feeds output pixel 2 J + h): half of W2 is zero, i.e. twice the FLOP — on kernels that run five times
+// the rate of the fp32 MFMA product on a materialised im2col, and with no im2col / col2im.  The kernel gradient of w is the sum of the
+// (two) entries of dW2 that hold each w[dy][dx].
+__global__ __launch_bounds__(256) void rn_w32_embed_kernel(const float* __restrict__ w, float* __restrict__ w2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 9 * 4096) return;
+    const int tap = idx >> 12, cp = (idx >> 6) & 63, op = idx & 63;
+    const int dyi = tap / 3, DX = tap - 3 * dyi - 1, hp = cp >> 5, ci = cp & 31, h = op >> 5, co = op & 31;
+    const int dx = 2 * DX + hp - h;
+    w2[idx] = (dx >= -1 && dx <= 1) ? w[((dyi * 3 + dx + 1) * 32 + ci) * 32 + co] : 0.f;
+}
+__global__ __launch_bounds__(256) void rn_w32_extract_kernel(const float* __restrict__ dw2, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 9 * 1024) return;
+    const int tap = idx >> 10, ci = (idx >> 5) & 31, co = idx & 31;
+    const int dyi = tap / 3, dx = tap - 3 * dyi - 1;
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int t = dx + h - hp;
+            if ((t & 1) == 0 && t >= -2 && t <= 2) s += dw2[((dyi * 3 + t / 2 + 1) * 64 + hp * 32 + ci) * 64 + h * 32 + co];
+        }
+    dw[idx] = s;
+}
+int launch_rn_w32_embed(hipStream_t st, const float* w, float* w2) {
+    hipLaunchKernelGGL(rn_w32_embed_kernel, dim3(9 * 4096 / 256), dim3(256), 0, st, w, w2);
+    return 0;
+}
+int launch_rn_w32_extract(hipStream_t st, const float* dw2, float* dw) {
+    hipLaunchKernelGGL(rn_w32_extract_kernel, dim3(9 * 1024 / 256), dim3(256), 0, st, dw2, dw);
+    return 0;
 }
