@@ -1,5 +1,6 @@
 """Every distinct convolution of resnet50_gru.json at 16 clips (spec/RESNET50_BLOCK.md; M = 16 * 600 * W rows) through the kernel entry points,
-each called twice (the second launch is the warm one).  Run under `rocprofv3 --kernel-trace --output-format csv` and feed the trace to this
+each called twice (the second launch is the warm one).  (The model runs the 3x3 of stages 0 and 1 on the conv blocks' implicit-GEMM kernels
+instead — api.hip: rn_c1_direct —, so the s0.c1 / s1.c1 rows here show the product path those stages no longer take by default.)  Run under `rocprofv3 --kernel-trace --output-format csv` and feed the trace to this
 script's `report` mode for per-shape kernel times:
     rocprofv3 --kernel-trace --output-format csv -d OUT -o rn -- python3 tools/tune_rn_products.py run
     python3 tools/tune_rn_products.py report OUT/.../rn_kernel_trace.csv"""
