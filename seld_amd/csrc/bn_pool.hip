@@ -97,10 +97,13 @@ __device__ __forceinline__ float4 fma4(float4 z, float4 a, float4 b) {
     return make_float4(fmaf(z.x, a.x, b.x), fmaf(z.y, a.y, b.y), fmaf(z.z, a.z, b.z), fmaf(z.w, a.w, b.w));
 }
 
-// one thread per (pooled pixel, channel group of 4); C == 64 -> 16 groups
+// one thread per (pooled pixel, channel group of 4); C == 64 -> 16 groups.  CPT x CPF > 0: the window known at compile time (the model's
+// (1,4), (1,2) and xception_block's (1,8)): its loads are all issued before the first use instead of one per trip of a runtime loop
+template <int CPT, int CPF>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ p,
-                                                               int64_t npool, int H, int W, int PT, int PF) {
+                                                               int64_t npool, int H, int W, int PT_, int PF_) {
+    const int PT = CPT ? CPT : PT_, PF = CPF ? CPF : PF_;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= npool * 16) return;
     const int g = (int)(gid & 15);
@@ -112,8 +115,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
     const float4 sc = reinterpret_cast<const float4*>(scale)[g];
     const float4 sh = reinterpret_cast<const float4*>(shift)[g];
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu floor
+#pragma unroll
     for (int i = 0; i < PT; ++i) {
         const float* row = z + (((size_t)b * H + (size_t)tp * PT + i) * W + (size_t)fp * PF) * 64 + g * 4;
+#pragma unroll
         for (int j = 0; j < PF; ++j) {
             const float4 y = fma4(*reinterpret_cast<const float4*>(row + (size_t)j * 64), sc, sh);
             m.x = fmaxf(m.x, y.x); m.y = fmaxf(m.y, y.y); m.z = fmaxf(m.z, y.z); m.w = fmaxf(m.w, y.w);
@@ -127,8 +132,13 @@ int launch_bn_relu_pool_fwd(hipStream_t st, const float* z, const float* scale, 
     if (C != 64 || H % pt || W % pf) return -2;
     const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
     const int64_t nthr = npool * 16;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, scale, shift, p,
-                       npool, H, W, pt, pf);
+#define POOL_FWD_GO(T_, F_) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<T_, F_>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, scale, shift, p, \
+                                              npool, H, W, pt, pf)
+    if (pt == 1 && pf == 4) POOL_FWD_GO(1, 4);
+    else if (pt == 1 && pf == 2) POOL_FWD_GO(1, 2);
+    else if (pt == 1 && pf == 8) POOL_FWD_GO(1, 8);
+    else POOL_FWD_GO(0, 0);
+#undef POOL_FWD_GO
     return 0;
 }
 
@@ -244,11 +254,15 @@ int launch_bn_bwd_finalize(hipStream_t st, const float* partial, int npartial, d
     return 0;
 }
 
+template <int CPT, int CPF>      // as bn_relu_pool_fwd_kernel; with a compile-time window its z values also stay in registers for the second sweep
 __global__ __launch_bounds__(256) void bn_pool_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ dp,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ c1c2, float* __restrict__ dz,
-                                                             int64_t npool, int H, int W, int PT, int PF) {
+                                                             int64_t npool, int H, int W, int PT_, int PF_) {
+    const int PT = CPT ? CPT : PT_, PF = CPF ? CPF : PF_;
+    constexpr int NWIN = CPT * CPF > 0 ? CPT * CPF : 1;
+    float4 zreg[NWIN];
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= npool * 16) return;
     const int g = (int)(gid & 15);
@@ -269,9 +283,15 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_dz_kernel(const float* __rest
     float ym[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int am[4] = {0, 0, 0, 0};
     const size_t base = (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + g * 4;
+    if (CPT * CPF > 0) {
+#pragma unroll
+        for (int q = 0; q < NWIN; ++q) zreg[q] = *reinterpret_cast<const float4*>(z + base + ((size_t)(q / (CPF ? CPF : 1)) * W + q % (CPF ? CPF : 1)) * 64);
+    }
+#pragma unroll
     for (int i = 0; i < PT; ++i)
+#pragma unroll
         for (int j = 0; j < PF; ++j) {
-            const float4 zv = *reinterpret_cast<const float4*>(z + base + ((size_t)i * W + j) * 64);
+            const float4 zv = CPT * CPF > 0 ? zreg[(i * PF + j) % NWIN] : *reinterpret_cast<const float4*>(z + base + ((size_t)i * W + j) * 64);
             const float4 y = fma4(zv, sc4, sh4);
             const int pos = i * PF + j;
             if (y.x > ym[0]) { ym[0] = y.x; am[0] = pos; }
@@ -284,10 +304,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_dz_kernel(const float* __rest
     float gsel[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) gsel[c] = ym[c] > 0.f ? dv[c] : 0.f;
+#pragma unroll
     for (int i = 0; i < PT; ++i)
+#pragma unroll
         for (int j = 0; j < PF; ++j) {
             const size_t a = base + ((size_t)i * W + j) * 64;
-            const float4 zv = *reinterpret_cast<const float4*>(z + a);
+            const float4 zv = CPT * CPF > 0 ? zreg[(i * PF + j) % NWIN] : *reinterpret_cast<const float4*>(z + a);
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
             const int pos = i * PF + j;
             float o[4];
@@ -307,8 +329,13 @@ int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const
     if (C != 64 || H % pt || W % pf) return -2;
     const int64_t npool = (int64_t)B * (H / pt) * (W / pf);
     const int64_t nthr = npool * 16;
-    hipLaunchKernelGGL(bn_pool_bwd_dz_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, dp, mean, invstd,
-                       scale, shift, c1c2, dz, npool, H, W, pt, pf);
+#define POOL_DZ_GO(T_, F_) hipLaunchKernelGGL((bn_pool_bwd_dz_kernel<T_, F_>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, z, dp, mean, invstd, \
+                                             scale, shift, c1c2, dz, npool, H, W, pt, pf)
+    if (pt == 1 && pf == 4) POOL_DZ_GO(1, 4);
+    else if (pt == 1 && pf == 2) POOL_DZ_GO(1, 2);
+    else if (pt == 1 && pf == 8) POOL_DZ_GO(1, 8);
+    else POOL_DZ_GO(0, 0);
+#undef POOL_DZ_GO
     return 0;
 }
 
