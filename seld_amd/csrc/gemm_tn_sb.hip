@@ -40,14 +40,15 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 // cvs = log2 C > 0 (tile mode only): A is an NHWC image [M pixels][C] and the product's A matrix its virtual im2col [M][9 C] (3 x 3
 // 'same', zeros outside the H x W image): tile y covers columns 128 y .. of it, i.e. ONE tap (C % 128 == 0) at channel offset
 // (128 y) % C — the row of the image is the pixel shifted by the tap, masked at the image border.
+template <bool CONV>      // a template parameter: the GRU's instantiation (the headline step's side stream) must not carry the convolution's index work
 __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
                                                             int S, int want_bias, long long tile_stride, int cvs, int cvH, int cvW) {
     const int job = tile_stride ? 0 : blockIdx.y;
-    const int cv_tap = cvs ? (128 * (int)blockIdx.y) >> cvs : 0;
+    const int cv_tap = CONV ? (128 * (int)blockIdx.y) >> cvs : 0;
     const int cv_dy = cv_tap / 3 - 1, cv_dx = cv_tap - 3 * (cv_tap / 3) - 1;
-    const float* __restrict__ A = jobs.A[job] + (cvs ? 128 * (int)blockIdx.y - (cv_tap << cvs) : tile_stride ? 128 * blockIdx.y : 0);
+    const float* __restrict__ A = jobs.A[job] + (CONV ? 128 * (int)blockIdx.y - (cv_tap << cvs) : tile_stride ? 128 * blockIdx.y : 0);
     const float* __restrict__ Bm = jobs.B[job];
-    const int lda = cvs ? 1 << cvs : jobs.lda[job], shift = jobs.shift[job];
+    const int lda = CONV ? 1 << cvs : jobs.lda[job], shift = jobs.shift[job];
     __shared__ __attribute__((aligned(16))) char Al[3 * TNSB_PL];
     __shared__ __attribute__((aligned(16))) char Bl[3 * TNSB_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
             oka = inb && (t + shift >= 0) && (t + shift < S);                                                \
             am = gm + shift;                                                                                 \
         }                                                                                                    \
-        if (cvs) {          /* A row = the pixel shifted by this tile's tap */                               \
+        if (CONV) {         /* A row = the pixel shifted by this tile's tap */                               \
             const int pr_ = gm / cvW, f_ = gm - pr_ * cvW, t_ = pr_ % cvH;                                   \
             oka = inb && (unsigned)(t_ + cv_dy) < (unsigned)cvH && (unsigned)(f_ + cv_dx) < (unsigned)cvW;   \
             am = gm + cv_dy * cvW + cv_dx;                                                                   \
@@ -177,7 +178,7 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    hipLaunchKernelGGL(gemm_tn_sb_kernel<false>, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
     *nslab = splits;
     return 0;
 }
@@ -203,8 +204,10 @@ int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float
     splits = (M + rps - 1) / rps;
     TnJobs jobs = {};
     jobs.A[0] = A; jobs.B[0] = Bm; jobs.lda[0] = lda; jobs.shift[0] = 0;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
-                       (long long)K1 * N, cvs, conv_H, conv_W);
+    if (cvs) hipLaunchKernelGGL(gemm_tn_sb_kernel<true>, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+                                (long long)K1 * N, cvs, conv_H, conv_W);
+    else hipLaunchKernelGGL(gemm_tn_sb_kernel<false>, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+                            (long long)K1 * N, 0, 0, 0);
     *nslab = (int)splits;
     return 0;
 }
