@@ -92,6 +92,7 @@ struct seld_ctx {
     hipEvent_t ev_rn_ready = nullptr, ev_rn_free[5] = {};
     float* rn_w9_slab = nullptr;           // slabs of the stage-1 3x3 kernel gradients (wgrad_slab belongs to the main stream's first block)
     int rn_wgrad_side = 1;
+    size_t rn_col_elems = 0;
     int rn_implicit3x3 = 1;                // stages 2-3: the 3x3 products read im2col rows formed on load (0: materialised im2col / col2im)
     int rn_feat = 0;                         // features per label frame into the first GRU layer (2 x 32 rn_filters)
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
@@ -403,7 +404,6 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         for (auto& R : c->rn) {
             const size_t M = (size_t)B * S * R.Wout;
             for (int i = 0; i < 3; ++i) { ALLOC(R.c[i].z, M * R.c[i].Cout); ALLOC(R.c[i].coef, (size_t)6 * R.c[i].Cout); }
-            ALLOC(R.c[1].col, M * 9 * R.w);
             if (R.proj) { ALLOC(R.sc.z, M * 4 * R.w); ALLOC(R.sc.coef, (size_t)6 * 4 * R.w); }
             ALLOC(R.y0, M * R.w); ALLOC(R.y1, M * R.w); ALLOC(R.out, M * 4 * R.w); ALLOC(R.gate, M * R.w);
             mx_out = std::max(mx_out, M * 4 * R.w); mx_w = std::max(mx_w, M * R.w); mx_col = std::max(mx_col, M * 9 * R.w);
@@ -425,7 +425,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(c->rn_gx[0], mx_in); ALLOC(c->rn_gx[1], mx_in);
         for (auto& b_ : c->rn_bz) ALLOC(b_, mx_out);
         for (auto& b_ : c->rn_bb) ALLOC(b_, mx_w);
-        ALLOC(c->rn_ba, mx_w); ALLOC(c->rn_bcol, mx_col);
+        ALLOC(c->rn_ba, mx_w);
+        c->rn_col_elems = mx_col;      // the im2col tensors (a block's col, the shared dcol) are allocated on first use: no default path needs them
         ALLOC(c->rn_w9_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
     }
     if (resn || a->first_kind == SELD_FIRST_XCEPTION) {
@@ -913,6 +914,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w);
                 rn_bn(c, st, R.c[1], M, training);
             } else {
+                // (only with rn_split_bf16 / rn_implicit3x3 off, or a width no direct kernel takes: the col tensor is allocated here, once)
+                if (!R.c[1].col && dalloc(c, &R.c[1].col, (size_t)M * 9 * w)) return fail(c, SELD_ERR_NOMEM, "im2col tensor");
                 launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
                 launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
                 rn_bn(c, st, R.c[1], M, training);
@@ -1281,6 +1284,8 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 done(bbi);
                 launch_rn_conv3_dgrad(st, dz1, R.c[1].wsp_t, c->rn_ba, B, S, R.Wout, w, w);
             } else {
+                if (!R.c[1].col) return fail(c, SELD_ERR_INVALID, "resnet50_block: the options changed between forward and backward");
+                if (!c->rn_bcol && dalloc(c, &c->rn_bcol, c->rn_col_elems)) return fail(c, SELD_ERR_NOMEM, "col2im tensor");
                 wgrad(bbi, R.c[1].col, 9 * w, dz1, (int)M, 9 * w, w, R.c[1].w_off);
                 launch_rn_product_dgrad(st, dz1, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
                 launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
