@@ -437,7 +437,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
     ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
-    ALLOC(c->tn_slab, (size_t)gemm_tn_max_splits() * (384 * 384 + 384));
+    ALLOC(c->tn_slab, (size_t)tn_slab_capacity());
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
     ALLOC(c->wsplit, (size_t)2 * c->conv.size() * 9 * 3 * 4096);
@@ -1068,7 +1068,7 @@ static void wgrad_dense(seld_ctx* c, hipStream_t st, float* slab, const float* A
                         int K1, int N, int64_t w_off, int64_t b_off, int S, int shift) {
     int ns = 0;
     // both slab buffers hold gemm_tn_max_splits() slabs of 384 x 384 + 384 floats: larger products (a 2048-feature GRU input) take fewer splits
-    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384) / ((int64_t)K1 * N + N);
+    const int64_t cap = tn_slab_capacity() / ((int64_t)K1 * N + N);
     if (c->gemm_split_bf16 && gemm_tn_sb_usable(A, lda, Bm, ldb, K1, N)) launch_gemm_tn_sb(st, A, lda, Bm, ldb, slab, &ns, M, N, S, shift, 1);
     else launch_gemm_tn(st, A, lda, Bm, ldb, slab, &ns, M, K1, N, S, shift, 1, (int)std::min<int64_t>(cap, gemm_tn_max_splits()));
     launch_reduce_slabs2(st, slab, ns, (int64_t)K1 * N + N, c->grads + w_off, (int64_t)K1 * N, c->grads + b_off, N);
@@ -1245,7 +1245,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
         auto done = [&](int slot) { if (aside) { hipEventRecord(c->ev_rn_free[slot], c->side); busy[slot] = true; } };
         auto wgrad = [&](int slot, const float* A, int lda, const float* dz, int M_, int K1, int N, int64_t w_off) {
             fork(slot);
-            launch_rn_product_wgrad(ws, A, lda, dz, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + w_off, M_, K1, N,
+            launch_rn_product_wgrad(ws, A, lda, dz, c->tn_slab, tn_slab_capacity(), c->grads + w_off, M_, K1, N,
                                     c->rn_split_bf16);
             done(slot);
         };
@@ -1279,7 +1279,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, rn_c1_width(R));
             } else if (sb && rn_c1_implicit(c, R)) {
                 fork(bbi);
-                launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, (int64_t)gemm_tn_max_splits() * (384 * 384 + 384), c->grads + R.c[1].w_off, B, S,
+                launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, tn_slab_capacity(), c->grads + R.c[1].w_off, B, S,
                                       R.Wout, w, w);
                 done(bbi);
                 launch_rn_conv3_dgrad(st, dz1, R.c[1].wsp_t, c->rn_ba, B, S, R.Wout, w, w);

@@ -251,6 +251,8 @@ int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float
 int launch_reduce_slabs2(hipStream_t st, const float* slab, int nslab, int64_t stride, float* out_w, int64_t n_w,
                          float* out_b, int64_t n_b);
 int gemm_tn_max_splits();
+// floats of the kernel-gradient slab buffer a model context holds (the GRU's largest product, gemm_tn_max_splits() slabs of it)
+inline int64_t tn_slab_capacity() { return (int64_t)gemm_tn_max_splits() * (384 * 384 + 384); }
 int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nslab, int M, int N);
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,

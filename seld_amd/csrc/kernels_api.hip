@@ -401,7 +401,7 @@ int seld_k_rn_conv_bwd(const float* x, const float* w, const float* dz, float* d
     if ((ksize != 1 && ksize != 3) || (ksize == 3 && stride_f != 1) || stride_f < 1 || W % stride_f || Cin % 4) return SELD_ERR_UNSUPPORTED;
     const int Wo = W / stride_f, M = B * H * Wo, K1 = ksize * ksize * Cin;
     Scratch s;
-    const int64_t cap = (int64_t)gemm_tn_max_splits() * (384 * 384 + 384);     // the model's slab buffer
+    const int64_t cap = tn_slab_capacity();     // the model's slab buffer
     float* slab = s.get((size_t)cap);
     if (!slab) return SELD_ERR_NOMEM;
     if (ksize == 3 && g_rn_split_bf16 && rn_conv3_sb_ok(Cin, Cout)) {      // both gradients with the im2col rows formed on load
