@@ -171,21 +171,37 @@ __global__ __launch_bounds__(256, 2) void xc_unit_fwd_kernel(const float* __rest
     const int tiles_per_img = (H + XU_ROWS - 1) / XU_ROWS, ntiles = B * tiles_per_img;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The input rows of a tile are requested one tile ahead (10 float4 per thread: row u of the region, this thread's column slot), so
+    // that a tile's first phase does not start with a round trip to memory; BatchNorm-on-load / ReLU are applied at the commit.
+    constexpr int NPRE = XU_ROWS + 2;
+    float4 pre[NPRE];
+    float4 asc = make_float4(1.f, 1.f, 1.f, 1.f), ash = zero4;
+    if (aff) { asc = reinterpret_cast<const float4*>(aff)[tid & 15]; ash = reinterpret_cast<const float4*>(aff + 64)[tid & 15]; }
+#define XU_ISSUE(tile_)                                                                                            \
+    {                                                                                                              \
+        const int b_ = (tile_) / tiles_per_img, t0_ = ((tile_) - b_ * tiles_per_img) * XU_ROWS;                    \
+        _Pragma("unroll") for (int u = 0; u < NPRE; ++u) {                                                         \
+            const int t_ = t0_ - 1 + u;                                                                            \
+            const bool ok_ = t_ >= 0 && t_ < H;                                                                    \
+            pre[u] = reinterpret_cast<const float4*>(x + ((size_t)(b_ * H + (ok_ ? t_ : 0)) * W) * 64)[tid];       \
+        }                                                                                                          \
+    }
+    if ((int)blockIdx.x < ntiles) XU_ISSUE((int)blockIdx.x)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img, t0 = (tile - b * tiles_per_img) * XU_ROWS;
-        // ---- input rows t0 - 1 .. t0 + XU_ROWS (zeros outside the image), ReLU on the way in
-        for (int i = tid; i < (XU_ROWS + 2) * W * 16; i += 256) {
-            const int rr = i / (W * 16), rem = i - rr * (W * 16);
-            const int t = t0 - 1 + rr;
+        // ---- commit input rows t0 - 1 .. t0 + XU_ROWS (zeros outside the image), BatchNorm of the previous unit and ReLU on the way in
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int t = t0 - 1 + u;
             float4 v = zero4;
-            if (t >= 0 && t < H) {
-                v = reinterpret_cast<const float4*>(x + ((size_t)(b * H + t) * W) * 64)[rem];
-                if (aff) v = fma4v(v, reinterpret_cast<const float4*>(aff)[rem & 15], reinterpret_cast<const float4*>(aff + 64)[rem & 15]);
-                v = relu4(v);
-            }
-            reinterpret_cast<float4*>(R)[i] = v;
+            if (t >= 0 && t < H) v = relu4(aff ? fma4v(pre[u], asc, ash) : pre[u]);
+            reinterpret_cast<float4*>(R)[tid + 256 * u] = v;
         }
         __syncthreads();
+        {   // next tile's rows: in flight under this tile's depthwise and pointwise phases (the last tile re-reads itself)
+            const int nxt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+            XU_ISSUE(nxt)
+        }
         // ---- depthwise: pixel p = 16 it + pslot (row p >> 4, column p & 15), channels 4 g ..
 #pragma unroll
         for (int it = 0; it < TP / 16; ++it) {
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void xc_unit_fwd_kernel(const float* __rest
             }
         __syncthreads();        // At and R are free for the next tile
     }
+#undef XU_ISSUE
     if (want_stats) {
         float* red = R;          // [4][128]
 #pragma unroll
