@@ -183,6 +183,14 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
 /* (x - mean)/max(std, eps) per (freq, chan), rows trimmed / zero-padded (before normalising, as the reference does) to T_out */
 int seld_feat_normalize(const float* feat, const float* mean, const float* stdv, float* out, int64_t T_in, int64_t T_out,
                         int FC, float eps, void* stream);
+/* calculate_statistics (feature_extractor.py:218-224): per-(freq, chan) mean and population std over ALL frames of a list of feature
+ * tensors.  `acc` = 2*FC + 1 doubles on the device (sum | sum of squares | row count; zero it to start), folded once per tensor
+ * feat [rows][FC] (any number of calls, any row counts: a file, or a batch [n][T][FC] as n*T rows); `scratch` =
+ * seld_feat_stats_scratch_doubles(FC) doubles (device).  Fixed-order double sums: bit-reproducible for a given call sequence.
+ * seld_feat_stats_finalize writes float mean / std [FC] (the reference's [1, freq, chan] arrays). */
+int64_t seld_feat_stats_scratch_doubles(int FC);
+int seld_feat_stats_accumulate(const float* feat, int64_t rows, int FC, double* acc, double* scratch, void* stream);
+int seld_feat_stats_finalize(const double* acc, int FC, float* mean, float* stdv, void* stream);
 
 /* ---- sliding-window inference: the two tensor ops around model() in evaluator.ensemble_outputs
  * (evaluator.py:16-50, trainv2.py:158-192).
@@ -295,7 +303,7 @@ int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const floa
 int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N);
 /* Bidirectional(GRU(128, reset_after=True), merge_mode='mul') recurrence (modules.py:311-316).
  * gx_* [B,S,384] = x*kernel + bias[0]; U_* [128,384]; brec_* = bias[1]; h_* [B,S,128]; out = h_f*h_b.
- * saved_* [B,S,4,128] (z, r, hh, h*U_h+b) may be NULL. */
+ * saved_* [B,S,128,4] (per unit: z, r, hh, h*U_h+b) may be NULL. */
 int seld_k_gru_fwd(const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b,
                    float* saved_f, float* saved_b, float* out, int B, int S, int units);

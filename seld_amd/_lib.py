@@ -95,6 +95,9 @@ SIGNATURES = {
     "seld_feat_extract": (_I, [_P, _P, _I, _L, _P, _P]),
     "seld_feat_extract_batch": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "seld_feat_normalize": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
+    "seld_feat_stats_scratch_doubles": (_L, [_I]),
+    "seld_feat_stats_accumulate": (_I, [_P, _L, _I, _P, _P, _P]),
+    "seld_feat_stats_finalize": (_I, [_P, _I, _P, _P, _P]),
     "seld_frame_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "seld_overlap_average": (_I, [_P, _P, _I, _I, _I, _P]),
     "seld_aug_mask": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -19,7 +19,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define CPSB_MAX_PERSISTENT 512
-int g_cpsb_stagger = 2;     // which half of the workgroups starts late (0: none, 1: odd, 2: upper half, 3: odd pairs)
 int conv_pool_sb_stat_capacity() { return CPSB_MAX_PERSISTENT; }
 
 // exact 3-way truncation split of two floats, packed as bf16 pairs (element 0 in the low half) — as conv_sb.hip
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ gamma, float* __restrict__ zext,
                                                                         unsigned char* __restrict__ amax,
-                                                                        float* __restrict__ stat_partial, int B, int H, int stagger) {
+                                                                        float* __restrict__ stat_partial, int B, int H) {
     using G = PoolSbGeom<CIN>;
     constexpr int CP = G::CP, NS = G::NS, KW = G::KW, PLANE = G::PLANE, WPLANE = G::WPLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned short cpsb_smem[];
@@ -123,14 +122,6 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
     if (tile < ntiles) {
         CPSB_ISSUE(tile)
         CPSB_COMMIT()
-    }
-    // Two workgroups share a CU, hence two waves a SIMD: started together they stay IN PHASE — both in their MFMA loop, then both
-    // in the VALU-only window reduction — and the matrix pipe idles through every reduction (-DCPSB_TIMING: 10.6 k + 13.8 k cycles
-    // per tile against 7.7 k of MFMA).  Half of the workgroups start half a tile late, so that one's reduction runs under the
-    // other's MFMAs.
-    if (stagger == 1 ? (blockIdx.x & 1) : (stagger == 2 ? (blockIdx.x >= gridDim.x / 2) : (stagger == 3 ? ((blockIdx.x >> 1) & 1) : 0))) {
-#pragma unroll 1
-        for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_sleep(64);      // 3 x 64 x 64 clocks
     }
     __syncthreads();
     typedef float f32x2s __attribute__((ext_vector_type(2)));
@@ -281,7 +272,7 @@ static int launch_cpsb(hipStream_t st, const float* x, const float* w, const flo
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_sb_kernel<CIN, A_>),                   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);                               \
         hipLaunchKernelGGL((conv_first_fwd_pool_sb_kernel<CIN, A_>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
-                           gamma, zext, amax, stat_partial, B, H, g_cpsb_stagger);                                   \
+                           gamma, zext, amax, stat_partial, B, H);                                                   \
     }
     if (amax) CPSB_GO(true)
     else CPSB_GO(false)

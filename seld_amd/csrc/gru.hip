@@ -39,6 +39,22 @@ __device__ unsigned long long g_gru_timing[2][512][4];    // [fwd | bwd][workgro
 #define GRU_STAMP(t_)
 #endif
 
+// -DGRU_TRACE (diagnostic build, tools/trace_gru.py): absolute s_memtime stamps of EVERY wave of workgroup 0 over recurrence steps
+// 100..107 at up to four points of a step -> a timeline of who waits for whom (read back with seld_k_gru_timing(2 | 3, ...)).
+#ifdef GRU_TRACE
+__device__ unsigned long long g_gru_trace[2][8][8][4];    // [fwd | bwd][wave][step - 100][stamp]
+#define GRU_TR(w_, k_)                                                                                   \
+    if (blockIdx.x == 0 && step >= 100 && step < 108) {                                                  \
+        unsigned long long t_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((threadIdx.x & 63) == 0) g_gru_trace[w_][threadIdx.x >> 6][step - 100][k_] = t_;             \
+    }
+#else
+#define GRU_TR(w_, k_)
+#endif
+
 #define GRU_U 128
 #define GRU_G 384
 #define GRUF_CH 16   // forward: steps per staged chunk
@@ -129,6 +145,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             unsigned long long ts0, ts1, ts2;
             GRU_STAMP(ts0)
 #endif
+            GRU_TR(0, 0)
             const int row = dir ? n - 1 - i : i;
             const int t = tlo + row;
             // lanes q = 0, 2 of a quad finish the update gate, lanes 1, 3 the reset gate: each reads only its own input term
@@ -145,6 +162,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 #ifdef GRU_TIMING
             GRU_STAMP(ts1)
 #endif
+            GRU_TR(0, 1)
             const float az = az2.x + az2.y, ar = ar2.x + ar2.y;
             float ah = ah2.x + ah2.y;
             // fold the z and r sums instead of two quad sums: with its xor-1 neighbour a lane trades the sum it does not
@@ -161,6 +179,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const float hh = tanh_(gxh + r * ghh);
             const float hn = fmaf(z, h_own - hh, hh);      // z h + (1 - z) hh
             h_own = hn;
+            GRU_TR(0, 2)
             if (q == 0) {
                 hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
                 H[(size_t)t * GRU_U + j] = hn;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 // lane q of a quad saves gate q (z | r | hh | gh).  Even lanes finished z and odd lanes r in `sg` itself, so lanes 0 / 1
                 // store sg as it is; lanes 2 / 3 pick hh / gh: two selects (seven AND/OR ops with one-hot masks before)
                 const float hi2 = q == 2 ? hh : ghh;
-                sv[((size_t)t * 4 + q) * GRU_U + j] = q < 2 ? sg : hi2;
+                sv[((size_t)t * GRU_U + j) * 4 + q] = q < 2 ? sg : hi2;      // saved gates: [t][unit][z r hh gh]
             }
 #ifdef GRU_TIMING
             GRU_STAMP(ts2)
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     }
 #endif
 }
+
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     auto pre = [&](const float* sbuf, int row) {
         const float* rp = sbuf + row * GRUB_ROW + jm;
         k_do = rp[0] * rp[128];
-        const float c_z = rp[256], c_r = rp[384], c_hh = rp[512], c_gh = rp[640], hp = rp[768];
+        const float4 sg4 = *reinterpret_cast<const float4*>(sbuf + row * GRUB_ROW + 256 + 4 * jm);   // saved gates [unit][z r hh gh]
+        const float c_z = sg4.x, c_r = sg4.y, c_hh = sg4.z, c_gh = sg4.w, hp = rp[768];
         const float kh = (1.f - c_z) * (1.f - c_hh * c_hh);
         const float kz = (hp - c_hh) * c_z * (1.f - c_z);
         const float kr = kh * c_gh * c_r * (1.f - c_r);
@@ -389,7 +410,9 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             unsigned long long tb0, tb1, tb2, tb3;
             GRU_STAMP(tb0)
 #endif
+            GRU_TR(1, 0)
             part1(i);
+            GRU_TR(1, 1)
 #ifdef GRU_TIMING
             GRU_STAMP(tb1)
 #endif
@@ -397,6 +420,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
 #ifdef GRU_TIMING
             GRU_STAMP(tb2)
 #endif
+            GRU_TR(1, 2)
             pre(sb, dir ? i + 1 : n - 2 - i);
             part2();
 #ifdef GRU_TIMING
@@ -427,14 +451,22 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S) {
     const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * GRUB_GL) * sizeof(float);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
+    auto kern = gru_bwd_kernel;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);
     return 0;
 }
 
 // per-phase cycle sums of the last gru_fwd (which = 0) / gru_bwd (1) launch: out[blocks][4]; -2 unless built with -DGRU_TIMING
 int gru_timing_read(int which, unsigned long long* out, int blocks) {
+#ifdef GRU_TRACE
+    if ((which == 2 || which == 3) && blocks == 64) {    // trace of workgroup 0: [wave][step][stamp]
+        hipDeviceSynchronize();
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gru_trace), 8 * 8 * 4 * sizeof(unsigned long long),
+                                   (size_t)(which - 2) * 8 * 8 * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    }
+#endif
 #ifdef GRU_TIMING
     if (which < 0 || which > 1 || blocks < 1 || blocks > 512) return -1;
     hipDeviceSynchronize();

@@ -97,6 +97,70 @@ class FeatureExtractor:
             pass
 
 
+class FeatureStatistics:
+    """calculate_statistics (feature_extractor.py:218-224) on the device: fold feature tensors [..., freq, chan] (any leading
+    shape: one file [T,F,C] or a batch [n,T,F,C]) into per-(freq, chan) sums, then `result()` -> (mean, std) as the reference's
+    [1, freq, chan] float arrays (device tensors; population std, numpy's ddof = 0)."""
+
+    def __init__(self, n_freq: int = 64, n_chan: int = 7, device: int | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SeldLibraryError("no HIP device visible: seld_amd has no CPU fallback")
+        self._dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.F, self.Cn = int(n_freq), int(n_chan)
+        self.FC = self.F * self.Cn
+        self.acc = torch.zeros(2 * self.FC + 1, dtype=torch.float64, device=self._dev)
+        self.scratch = torch.empty(int(self.lib.seld_feat_stats_scratch_doubles(self.FC)), dtype=torch.float64, device=self._dev)
+
+    def update(self, feat) -> "FeatureStatistics":
+        f = torch.as_tensor(np.asarray(feat) if not isinstance(feat, torch.Tensor) else feat).to(self._dev, torch.float32).contiguous()
+        if f.dim() < 3 or f.shape[-2] != self.F or f.shape[-1] != self.Cn:
+            raise ValueError(f"features must be [..., {self.F}, {self.Cn}]")
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        _lib.check(self.lib.seld_feat_stats_accumulate(f.data_ptr(), int(f.numel() // self.FC), self.FC, self.acc.data_ptr(),
+                                                       self.scratch.data_ptr(), st))
+        return self
+
+    def result(self):
+        mean = torch.empty((1, self.F, self.Cn), dtype=torch.float32, device=self._dev)
+        std = torch.empty_like(mean)
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        _lib.check(self.lib.seld_feat_stats_finalize(self.acc.data_ptr(), self.FC, mean.data_ptr(), std.data_ptr(), st))
+        return mean, std
+
+
+def calculate_statistics(feature_path: str):
+    """reference feature_extractor.calculate_statistics (feature_extractor.py:218-224): mean / std [1, freq, chan] over all frames of
+    the sorted *.npy files of a directory — file by file through the device accumulator instead of one host concatenation."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(feature_path, "*.npy")))
+    if not files:
+        raise ValueError(f"no .npy feature files under {feature_path}")
+    stats = None
+    for f in files:
+        a = np.load(f)
+        if stats is None:
+            stats = FeatureStatistics(a.shape[-2], a.shape[-1])
+        stats.update(a)
+    mean, std = stats.result()
+    return mean.cpu().numpy(), std.cpu().numpy()
+
+
+def apply_normalizer_array(feature, mean, std, eps: float = 1e-8, n_frames: int | None = None) -> torch.Tensor:
+    """apply_normalizer's arithmetic (feature_extractor.py:226-234) for one feature array [T, F, C] -> device tensor [n_frames or T, F, C]."""
+    f = torch.as_tensor(np.asarray(feature) if not isinstance(feature, torch.Tensor) else feature).to("cuda", torch.float32).contiguous()
+    T, F_, Cn = f.shape
+    lib = _lib.load()
+    m = torch.as_tensor(np.asarray(mean.cpu() if isinstance(mean, torch.Tensor) else mean, np.float32).reshape(-1)).to(f.device)
+    s = torch.as_tensor(np.asarray(std.cpu() if isinstance(std, torch.Tensor) else std, np.float32).reshape(-1)).to(f.device)
+    n_out = T if n_frames is None else int(n_frames)
+    out = torch.empty((n_out, F_, Cn), dtype=torch.float32, device=f.device)
+    st = C.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)
+    _lib.check(lib.seld_feat_normalize(f.data_ptr(), m.data_ptr(), s.data_ptr(), out.data_ptr(), int(T), n_out, F_ * Cn, float(eps), st))
+    return out
+
+
 def extract_features_device(wav, sample_rate, mode="foa", n_mels=64, **kwargs) -> torch.Tensor:
     return FeatureExtractor(sample_rate, mode, n_mels, **kwargs)(wav)
 

@@ -88,3 +88,41 @@ def test_batch_extraction_equals_clip_by_clip(seld_lib, mode):
     assert got.shape == (3, 1 + (24000 + 77) // 480, 64, 7 if mode == "foa" else 10)
     for i in range(3):
         np.testing.assert_array_equal(got[i], fx(wavs[i]).cpu().numpy())
+
+
+@pytest.mark.parametrize("mode", ["foa", "mic"])
+def test_calculate_statistics_on_device(seld_lib, tmp_path, mode):
+    """feature_extractor.calculate_statistics (feature_extractor.py:218-224): per-(freq, chan) mean / population std over ALL frames of
+    a list of files of different lengths — the device accumulator (seld_feat_stats_*) against numpy's mean / std of the host
+    concatenation (the oracle), then apply_normalizer (:226-234) with the FITTED statistics; ragged inputs: a 1-frame file, a
+    batch tensor, repeatability bit for bit."""
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    fx = FE.FeatureExtractor(24000, mode, 64, **kw)
+    feats = [fx(_wav(n, seed=s, scale=sc)).cpu().numpy() for n, s, sc in ((24000 * 3 + 11, 1, 0.1), (24000 + 500, 2, 0.01), (1000, 3, 0.3))]
+    assert feats[2].shape[0] == 3
+    feats.append(feats[0][:1])                                      # a one-frame file
+    for i, f in enumerate(feats):
+        np.save(tmp_path / f"fold1_room1_mix{i:03d}.npy", f)
+    mean, std = FE.calculate_statistics(str(tmp_path))
+    rm, rs = FO.calculate_statistics([f.astype(np.float64) for f in feats])
+    assert mean.shape == rm.shape == (1, 64, fx.channels) and mean.dtype == np.float32
+    check(f"{mode} statistics mean", mean, rm)
+    check(f"{mode} statistics std", std, rs)
+    out = FE.apply_normalizer_array(feats[1], mean, std).cpu().numpy()
+    check(f"{mode} normalised with fitted statistics", out, FO.apply_normalizer(feats[1].astype(np.float64), rm, rs))
+    # a batch [n, T, F, C] folds as n*T rows; two passes over the same list give the same bits
+    st = FE.FeatureStatistics(64, fx.channels)
+    st.update(np.stack([feats[0][:70], feats[0][70:140]])).update(feats[1])
+    m2, s2 = st.result()
+    rm2, rs2 = FO.calculate_statistics([feats[0][:140].astype(np.float64), feats[1].astype(np.float64)])
+    check(f"{mode} batch statistics mean", m2.cpu().numpy(), rm2)
+    check(f"{mode} batch statistics std", s2.cpu().numpy(), rs2)
+    mean_b, std_b = FE.calculate_statistics(str(tmp_path))
+    np.testing.assert_array_equal(mean, mean_b)
+    np.testing.assert_array_equal(std, std_b)
+    with pytest.raises(ValueError):
+        FE.calculate_statistics(str(tmp_path / "nothing_here"))
+    with pytest.raises(ValueError):
+        st.update(np.zeros((5, 64, fx.channels + 1), np.float32))

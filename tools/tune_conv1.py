@@ -47,10 +47,6 @@ while time.perf_counter() < t_end:
 unfused = lambda: lib.seld_k_conv3x3_fwd(P(x), P(w), P(b), P(z), P(st), B, H, 64, Cin, 64)
 print("conv_first_fwd (unfused)      %.4f ms" % timeit(unfused))
 print("conv_first_fwd (unfused)      %.4f ms" % timeit(unfused))
-for sg in (0, 1, 2, 3, 0, 2):
-    lib.seld_k_set_option(b"cpsb_stagger", sg)
-    print("stagger %d: conv_first_fwd_pool (z not stored) %.4f ms" % (sg, timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), None, P(ze), None, P(st), B, H, Cin))))
-lib.seld_k_set_option(b"cpsb_stagger", 2)
 for _ in range(2):
     t1 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), P(z), P(ze), P(am), P(st), B, H, Cin))
     t2 = timeit(lambda: lib.seld_k_conv_first_fwd_pool(P(x), P(w), P(b), P(gamma), None, P(ze), None, P(st), B, H, Cin))
