@@ -78,8 +78,8 @@ class FeatureExtractor:
     def normalize(self, feat: torch.Tensor, mean, std, n_frames: int = 3000, eps: float = 1e-8) -> torch.Tensor:
         """preprocess_features_labels (pad/trim to n_frames, :117-149) + apply_normalizer (:226-234)."""
         FC = feat.shape[1] * feat.shape[2]
-        m = torch.as_tensor(np.asarray(mean, np.float32).reshape(-1)).to(self._dev)
-        s = torch.as_tensor(np.asarray(std, np.float32).reshape(-1)).to(self._dev)
+        as_dev = lambda a: (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32))).to(self._dev, torch.float32).reshape(-1).contiguous()
+        m, s = as_dev(mean), as_dev(std)
         if m.numel() != FC or s.numel() != FC:
             raise ValueError("mean/std must have freq*chan elements")
         out = torch.empty((n_frames, feat.shape[1], feat.shape[2]), dtype=torch.float32, device=self._dev)
@@ -152,8 +152,8 @@ def apply_normalizer_array(feature, mean, std, eps: float = 1e-8, n_frames: int 
     f = torch.as_tensor(np.asarray(feature) if not isinstance(feature, torch.Tensor) else feature).to("cuda", torch.float32).contiguous()
     T, F_, Cn = f.shape
     lib = _lib.load()
-    m = torch.as_tensor(np.asarray(mean.cpu() if isinstance(mean, torch.Tensor) else mean, np.float32).reshape(-1)).to(f.device)
-    s = torch.as_tensor(np.asarray(std.cpu() if isinstance(std, torch.Tensor) else std, np.float32).reshape(-1)).to(f.device)
+    as_dev = lambda a: (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32))).to(f.device, torch.float32).reshape(-1).contiguous()
+    m, s = as_dev(mean), as_dev(std)
     n_out = T if n_frames is None else int(n_frames)
     out = torch.empty((n_out, F_, Cn), dtype=torch.float32, device=f.device)
     st = C.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)

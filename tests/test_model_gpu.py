@@ -747,6 +747,59 @@ def test_xception_gru_train_step(xception_config, B, T, blocks, doa_loss, fused)
 
 
 
+def _resnet_routed_grad_check(model, spec, w, st, x, ys, yd, free, kw, label):
+    """Halves (1) and (2) of test_resnet50_gru_train_step's docstring for a model that has just run its train step: every decision the
+    library took differently from the free-running fp64 oracle (`free` = its record_routing) sits on a margin fp32 cannot resolve, and
+    GIVEN the library's decisions (seld_debug_relu_output, seld_debug_pool_routing) the fp64 oracle's gradients agree with the
+    library's, variable by variable."""
+    import ctypes as C
+    from oracle import seldnet_oracle as O
+    from seld_amd import _lib
+    B, T = x.shape[0], x.shape[1]
+    g = model.get_grads()
+    # ---- the library's decisions: stem MaxPool/ReLU routing, then every bottleneck ReLU's gate
+    S = T // 5
+    routing = {}
+    pos = torch.empty((B, S, 16, 64), dtype=torch.uint8, device="cuda")
+    gate = torch.empty((B, S, 16, 64), dtype=torch.uint8, device="cuda")
+    _lib.check(model.lib.seld_debug_pool_routing(model.ctx, 0, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
+    routing[0] = (pos.cpu().to(torch.int64), gate.cpu().bool())
+    f0 = free[0]
+    both = routing[0][1] & f0["gate"]
+    arg = (routing[0][0] != f0["pos"]) & both
+    margin = (f0["top"] - f0["windows"].gather(-1, routing[0][0].unsqueeze(-1)).squeeze(-1))[arg]
+    gflip0 = routing[0][1] != f0["gate"]
+    assert (margin < 1e-5).all() and (f0["top"].abs()[gflip0] < 1e-5).all()
+    f0.pop("windows", None)
+    n_flip, n_gate, worst_pre = int(arg.sum()) + int(gflip0.sum()), 0, 0.0
+    buf = torch.empty(B * S * 16 * 128, device="cuda")
+    cnt = C.c_int64()
+    for bi, (s_, b, ci, wd, stf, proj) in enumerate(O.resnet_plan(spec)):
+        for which, nm in enumerate(("y0", "y1", "out")):
+            key = f"rn{s_}.{b}.{nm}"
+            _lib.check(model.lib.seld_debug_relu_output(model.ctx, bi, which, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), model.ctx)
+            fr = free[key]
+            assert cnt.value == fr["gate"].numel()
+            gt = (buf[:cnt.value] > 0).cpu().reshape(fr["gate"].shape)
+            routing[key] = gt
+            flip = gt != fr["gate"]
+            n_gate += gt.numel()
+            if flip.any():
+                n_flip += int(flip.sum())
+                worst_pre = max(worst_pre, float(fr["pre"].abs()[flip].max()))
+    deep = len(O.resnet_plan(spec)) > 8
+    print(f"[routing] {label}: {n_flip} of {n_gate + gate.numel()} decisions differ from the free-running fp64 oracle "
+          f"(largest fp64 |pre-activation| behind a flipped gate {worst_pre:.2e})")
+    # 16 bottlenecks deep the fp32 forward itself is 1e-4 off the fp64 one at the OUTPUTS (checked by the caller at that bar), and a
+    # gate can only be resolved to the error of its pre-activation
+    assert worst_pre < (1e-3 if deep else 1e-5) and n_flip <= 1e-5 * n_gate + 4
+    ref_r = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
+    # [3,4,6,3]: 5e-4 — fifty-three training-mode BatchNormalizations deep the fp32 forward is already 1e-4 off at the outputs
+    worst = _per_var(model, f"{label} routed grad", g, ref_r["grad"], tol=5e-4 if deep else 1e-4)
+    print(f"[routing] {label}: worst variable against the fp64 oracle WITH the library's decisions: {worst:.2e}")
+    return worst
+
+
 @pytest.mark.parametrize("B,T,blocks,doa_loss,split", [(4, 300, [1, 1, 1, 1], "MSE", 1), (4, 300, [1, 1, 1, 1], "MSE", 0), (4, 300, [1, 1, 1, 1], "MSE", 2),
                                                          (3, 300, [2, 1, 1, 1], "MMSE", 1),
                                                          (2, 300, [3, 4, 6, 3], "MSE", 1)])
@@ -799,45 +852,7 @@ def test_resnet50_gru_train_step(resnet50_config, B, T, blocks, doa_loss, split)
     check("resnet50 trainstep dloss", dl.cpu().numpy(), ref["dloss"])
     _, st1 = model.get_weights()
     check("resnet50 BN moving stats", st1, ref["new_state"])
-    g = model.get_grads()
-    # ---- the library's decisions: stem MaxPool/ReLU routing, then every bottleneck ReLU's gate
-    S = T // 5
-    routing = {}
-    pos = torch.empty((B, S, 16, 64), dtype=torch.uint8, device="cuda")
-    gate = torch.empty((B, S, 16, 64), dtype=torch.uint8, device="cuda")
-    _lib.check(model.lib.seld_debug_pool_routing(model.ctx, 0, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
-    routing[0] = (pos.cpu().to(torch.int64), gate.cpu().bool())
-    f0 = free[0]
-    both = routing[0][1] & f0["gate"]
-    arg = (routing[0][0] != f0["pos"]) & both
-    margin = (f0["top"] - f0["windows"].gather(-1, routing[0][0].unsqueeze(-1)).squeeze(-1))[arg]
-    gflip0 = routing[0][1] != f0["gate"]
-    assert (margin < 1e-5).all() and (f0["top"].abs()[gflip0] < 1e-5).all()
-    n_flip, n_gate, worst_pre = int(arg.sum()) + int(gflip0.sum()), 0, 0.0
-    buf = torch.empty(B * S * 16 * 128, device="cuda")
-    cnt = C.c_int64()
-    for bi, (s_, b, ci, wd, stf, proj) in enumerate(O.resnet_plan(spec)):
-        for which, nm in enumerate(("y0", "y1", "out")):
-            key = f"rn{s_}.{b}.{nm}"
-            _lib.check(model.lib.seld_debug_relu_output(model.ctx, bi, which, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), model.ctx)
-            fr = free[key]
-            assert cnt.value == fr["gate"].numel()
-            gt = (buf[:cnt.value] > 0).cpu().reshape(fr["gate"].shape)
-            routing[key] = gt
-            flip = gt != fr["gate"]
-            n_gate += gt.numel()
-            if flip.any():
-                n_flip += int(flip.sum())
-                worst_pre = max(worst_pre, float(fr["pre"].abs()[flip].max()))
-    print(f"[routing] resnet50 {blocks}: {n_flip} of {n_gate + gate.numel()} decisions differ from the free-running fp64 oracle "
-          f"(largest fp64 |pre-activation| behind a flipped gate {worst_pre:.2e})")
-    # 16 bottlenecks deep the fp32 forward itself is 1e-4 off the fp64 one at the OUTPUTS (checked above at that bar), and a gate
-    # can only be resolved to the error of its pre-activation
-    assert worst_pre < (1e-3 if len(O.resnet_plan(spec)) > 8 else 1e-5) and n_flip <= 1e-5 * n_gate + 4
-    ref_r = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
-    # [3,4,6,3]: 5e-4 — fifty-three training-mode BatchNormalizations deep the fp32 forward is already 1e-4 off at the outputs
-    worst = _per_var(model, "resnet50 routed grad", g, ref_r["grad"], tol=5e-4 if len(O.resnet_plan(spec)) > 8 else 1e-4)
-    print(f"[routing] resnet50 {blocks}: worst variable against the fp64 oracle WITH the library's decisions: {worst:.2e}")
+    _resnet_routed_grad_check(model, spec, w, st, x, ys, yd, free, kw, f"resnet50 {blocks}")
 
 
 def test_full_size_first_block_gram_form_vs_stored_z_form(seldnet_config):
@@ -994,3 +1009,84 @@ def test_block_model_full_batch_vs_golden(xception_config, resnet50_config, whic
         s2, d2 = small(x[i:i + 2], training=False)
         np.testing.assert_array_equal(s2.cpu().numpy(), sed_i[i:i + 2])
         np.testing.assert_array_equal(d2.cpu().numpy(), doa_i[i:i + 2])
+
+
+def test_config5_composition_features_normalize_trainstep(resnet50_config):
+    """BASELINE.json configs[4] as it is composed in a training job: "resnet50_gru.json deep conv stack ... with on-device STFT
+    feature_extractor" — 16 FOA waveforms resident in HBM -> FeatureExtractor.batch (seld_feat_extract_batch,
+    feature_extractor.py:53-88) -> statistics fitted on the device (calculate_statistics, :218-224) -> pad / trim + normalise per clip
+    (seld_feat_normalize, :117-149, 226-234) -> train.trainstep on resnet50_gru [3,4,6,3] (train.py:22-36), against the ORACLE's
+    composition: fp64 features of the same waveforms -> numpy statistics -> apply_normalizer -> fp64 train step.  6.25-s clips
+    (T = 300 after the trim of the 301st frame: the oracle finishes in seconds; 60-s clips through the same feature calls are
+    test_full_clip_and_normalize, the model at T = 3000 is test_block_model_full_batch_vs_golden).  Outputs / losses / BN state
+    at 1e-4 free-running, gradients at 5e-4 GIVEN the library's ReLU gates (test_resnet50_gru_train_step's two halves)."""
+    from oracle import features_oracle as FO
+    from oracle import seldnet_oracle as O
+    from seld_amd import feature_extractor as FE, losses, models, train
+    B, n, T = 16, 150000, 300
+    rng = np.random.default_rng(21)
+    t = np.arange(n) / 24000.0
+    wavs = (rng.standard_normal((B, 4, n)) * 0.05).astype(np.float32)
+    for b in range(B):                                   # a tone per clip with inter-channel phase: non-trivial intensity vectors
+        f0 = 200.0 + 150.0 * b
+        for c in range(4):
+            wavs[b, c] += (0.2 * np.sin(2 * np.pi * f0 * t + 0.3 * c * (b + 1))).astype(np.float32)
+    kw_f = dict(win_length=960, hop_length=480, n_fft=1024)
+    fx = FE.FeatureExtractor(24000, "foa", 64, **kw_f)
+    feats = fx.batch(torch.as_tensor(wavs).cuda())        # [16, 313, 64, 7]
+    assert tuple(feats.shape) == (B, 1 + n // 480, 64, 7)
+    mean, std = FE.FeatureStatistics(64, 7).update(feats).result()
+    x_dev = torch.stack([fx.normalize(feats[b], mean, std, T) for b in range(B)])
+    ref_f = [FO.extract_features(wavs[b], 24000, "foa", dtype=torch.float64, **kw_f) for b in range(B)]
+    rm, rs = FO.calculate_statistics(ref_f)
+    x_ref = np.stack([FO.apply_normalizer(f[:T], rm, rs) for f in ref_f])
+    check("config 5 statistics mean", mean.cpu().numpy(), rm)
+    check("config 5 statistics std", std.cpu().numpy(), rs)
+    check("config 5 model input (features, normalised)", x_dev.cpu().numpy(), x_ref)
+    spec = O.Spec.from_config(resnet50_config)
+    w, st = O.random_weights(spec, 7)
+    _, ys, yd = O.synthetic_batch(B, T, seed=19)
+    model = models.seldnet((B, T, 64, 7), resnet50_config)
+    model.set_weights(w, st)
+    y_p, sl, dl = train.trainstep(model, x_dev, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    # the oracle's step on the ORACLE's features (fp64 end to end) for outputs / losses / state ...
+    ref = O.train_step(spec, w, st, x_ref, ys, yd, **kw)
+    # bar at the outputs: 1e-4, or 3 x what the SAME oracle evaluated in fp32 (on the fp32-rounded oracle features) differs from its fp64
+    # evaluation by — fifty-three training-mode BatchNormalizations deep that is itself ~1e-4 (the full-size fixture's out_err_fp32)
+    r32 = O.train_step(spec, w, st, x_ref.astype(np.float32), ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float32)
+    from helpers import rel_err
+    bar_s, bar_d = (max(1e-4, 3.0 * rel_err(r32[k], ref[k])) for k in ("sed", "doa"))
+    print(f"[parity] config 5: fp32 oracle vs fp64 oracle at the outputs: sed {rel_err(r32['sed'], ref['sed']):.2e}, doa {rel_err(r32['doa'], ref['doa']):.2e}")
+    check("config 5 trainstep sed", y_p[0].cpu().numpy(), ref["sed"], tol=bar_s)
+    check("config 5 trainstep doa", y_p[1].cpu().numpy(), ref["doa"], tol=bar_d)
+    check("config 5 trainstep dloss", dl.cpu().numpy(), ref["dloss"], tol=2 * bar_d)
+    _, st1 = model.get_weights()
+    check("config 5 BN moving stats", st1, ref["new_state"])
+    # ... and the gradients given the library's gates, on the LIBRARY's features: the gate margins are a statement about the model on
+    # identical inputs (the oracle's features differ from the library's by 2e-5, which 53 BatchNormalizations amplify past the 1e-3 that a
+    # flipped gate's pre-activation is held to)
+    x_lib = x_dev.cpu().numpy().astype(np.float64)
+    free = {}
+    O.train_step(spec, w, st, x_lib, ys, yd, record_routing=free, **kw)
+    _resnet_routed_grad_check(model, spec, w, st, x_lib, ys, yd, free, kw, "config 5 composition")
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("SELD_FULL_ROUTED"), reason="two fp64 oracle steps at full size (~5 min of host time, 40 GB): "
+                    "run by hand with SELD_FULL_ROUTED=1; log kept as profiles/r03_resnet50_full_routed_parity.log")
+def test_resnet50_full_size_given_library_gates(resnet50_config):
+    """resnet50_gru [3,4,6,3] at BASELINE configs[4]'s per-GPU size (16 clips of [3000,64,7]): test_resnet50_gru_train_step's two
+    halves AT FULL SIZE, with the oracle run on the GPU box's host cores."""
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    B, T = 16, 3000
+    spec = O.Spec.from_config(resnet50_config)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T, seed=1234)
+    model = models.seldnet((B, T, 64, 7), resnet50_config)
+    model.set_weights(w, st)
+    train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    free = {}
+    O.train_step(spec, w, st, x, ys, yd, record_routing=free, **kw)
+    _resnet_routed_grad_check(model, spec, w, st, x, ys, yd, free, kw, "resnet50 [3,4,6,3] B=16 T=3000")
