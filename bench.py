@@ -38,10 +38,13 @@ SPLIT_BF16_GROUPS = {"conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "co
                      # the split-bf16 kernels, the 32- / 64-column rest on the f32 MFMA: the whole group is priced against the split peak
                      "rn_stages_fwd", "rn_stages_bwd"}   # with the default options (seld_set_option)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
-# GRU recurrence (gru.hip): S dependent steps per launch; the floor of a step is the VALU issue time of its two waves per
-# SIMD — per wave 48 v_pk_fma_f32 + ~23 (forward) / ~37 (BPTT) other VALU + 6 (0) transcendental instructions at the
-# measured two-waves-per-SIMD issue rates (tools/valu_probe.hip: 6.5 / 5.9 / 8 cycles) — no LDS, barrier or dependency stall.
-GRU_ISSUE_CYCLES_PER_STEP = {"gru_fwd": 2 * (48 * 6.5 + 23 * 5.9 + 6 * 8), "gru_bwd": 2 * (48 * 6.5 + 37 * 5.9)}
+# GRU recurrence (gru.hip): S dependent steps per launch on the 2B CUs that hold a (clip, direction) each.  The HARDWARE floor of a step is
+# its mat-vec at the CU's fp32 rate: 128 x 384 multiply-adds / (128 FMA per clock per CU: 4 SIMD-32 x 32 lanes) = 384 cycles, forward and
+# backward alike (MI355X_MICROARCH.md: 157.3 TFLOP/s = 256 CUs x 2.4 GHz x 256 FLOP/clk).  Where the measured cycles go beyond that is
+# profiles/r03_gru_experiments.txt (in-kernel timeline, instruction latencies, the rejected forms).
+GRU_FMA_PER_STEP = 128 * 384
+CU_FMA_PER_CLK = 128
+GRU_GROUPS = ("gru_fwd", "gru_bwd")
 
 
 def kernel_work(name, B, T, F=64, C=7):
@@ -80,9 +83,35 @@ def kernel_work(name, B, T, F=64, C=7):
         "xc_depthwise_fwd": ("hbm", 4 * 2 * px2 * 64), "xc_pointwise_fwd": ("mfma", 2 * px2 * 64 * 64),
         # fused unit forward (default): read the unit's input once, write the depthwise output and z
         "xc_unit_fwd": ("hbm", 4 * 3 * px2 * 64),
-        "xc_bn_fwd": ("hbm", 4 * 3 * px2 * 64), "xc_bn_bwd": ("hbm", 4 * 5 * px2 * 64),
-        "xc_pointwise_bwd": ("mfma", 2 * 2 * px2 * 64 * 64), "xc_depthwise_bwd": ("hbm", 4 * 5 * px2 * 64),
+        # per scope (one per unit): BatchNorm finalisation (tiny) and, for a module's last unit only, the apply + residual pass (3 tensors):
+        # 8 of 24 scopes move data -> a third of 3 tensors on average
+        "xc_bn_fwd": ("hbm", 4 * 1 * px2 * 64),
+        # backward of a unit on the main stream: BatchNorm' sums (read gY, z), then xc_pw_bwd (dz formed on load: reads gY, z, the depthwise
+        # output; writes the gradient w.r.t. the depthwise output; two 64 x 64 products on the f32 MFMA), then the depthwise input gradient
+        # (reads that gradient, the unit's input for the ReLU mask, the residual gradient; writes the input gradient)
+        "xc_bn_bwd": ("hbm", 4 * 2 * px2 * 64),
+        "xc_pointwise_bwd": ("hbm", 4 * 4 * px2 * 64), "xc_depthwise_bwd": ("hbm", 4 * 4 * px2 * 64),
     }
+    if name.startswith("rn_") and name not in ("rn_stages_fwd", "rn_stages_bwd"):
+        # level-3 groups of resnet50_block, per SCOPE sums are not meaningful (one scope per launch of very different sizes): work per STEP
+        mac, bn_f, bn_b, cin, wbins = 0, 0, 0, 64, 16
+        for s_, nb in enumerate(RESNET_BLOCKS):
+            w = 32 * 2 ** s_
+            for b in range(nb):
+                if b == 0 and s_ > 0:
+                    wbins //= 2
+                px = B * S * wbins
+                proj = b == 0
+                mac += px * (cin * w + 9 * w * w + w * 4 * w + (cin * 4 * w if proj else 0))
+                chans = [w, w, 4 * w] + ([4 * w] if proj else [])
+                # forward per BatchNormalization: statistics read z, apply reads z and writes y; the block output also reads the shortcut
+                bn_f += sum(4 * px * ch * 3 for ch in chans) + 4 * px * 4 * w
+                # backward per BatchNormalization: sums read dy and z, dz reads dy and z and writes dz
+                bn_b += sum(4 * px * ch * 5 for ch in chans)
+                cin = 4 * w
+        per_step = {"rn_products_fwd": ("mfma", 2 * mac), "rn_products_dgrad": ("mfma", 2 * mac), "rn_bn_fwd": ("hbm", bn_f),
+                    "rn_bn_bwd": ("hbm", bn_b)}
+        return per_step.get(name)
     if name in ("rn_stages_fwd", "rn_stages_bwd"):
         # resnet50_block (spec/RESNET50_BLOCK.md): the products of every bottleneck (1x1 reduce, 3x3, 1x1 expand, projection shortcut);
         # the backward pass runs each twice (kernel gradient + input gradient).  The group's time also holds the BatchNorm passes,
@@ -210,6 +239,204 @@ def features_leg(dev, clips=8, reps=6):
                          "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None}}
 
 
+def model_config_of(name):
+    import copy
+    cfg = copy.deepcopy(SELDNET_CONFIG)
+    if name == "xception_gru":        # model_config/xception_gru.json:2-11
+        cfg["FIRST"] = "xception_block"
+        cfg["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    if name == "resnet50_gru":        # model_config/resnet50_gru.json:2-11
+        cfg["FIRST"] = "resnet50_block"
+        cfg["FIRST_ARGS"] = {"filters": 32, "block_num": list(RESNET_BLOCKS), "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
+    return cfg
+
+
+def workload_text(name, B, T, with_features):
+    return (f"model_config/{name}.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12"
+            + (" (FIRST block per spec/XCEPTION_BLOCK.md: absent from the reference snapshot)" if name == "xception_gru" else "")
+            + (" (FIRST block per spec/RESNET50_BLOCK.md: absent from the reference snapshot)" if name == "resnet50_gru" else "")
+            + (", features extracted on the device from 60-s FOA waveforms, normalised with statistics fitted on the device, inside every step"
+               if with_features else ""))
+
+
+def read_timers(model):
+    import ctypes as C
+    kernels = []
+    for i in range(model.lib.seld_profile_count(model.ctx)):
+        name = C.create_string_buffer(64)
+        n, ms = C.c_int64(), C.c_double()
+        model.lib.seld_profile_get(model.ctx, i, name, 64, C.byref(n), C.byref(ms))
+        kernels.append((name.value.decode(), int(n.value), float(ms.value)))
+    return kernels
+
+
+def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=False):
+    """Per timed kernel group: achieved rate = algorithmic work / HIP-event time, against the gfx950 peak of its bound.  `per_step_groups`:
+    the group's work table is per STEP (the block models' level-3 scopes wrap launches of very different sizes), else per launch."""
+    per_kernel, breakdown = {}, {}
+
+    def roof(name, n, ms):
+        work = kernel_work(name, B, T)
+        if not work or n == 0:
+            return None
+        bound, amount = work
+        per_unit_s = (ms / steps if (per_step_groups and name.startswith("rn_") and name not in ("rn_stages_fwd", "rn_stages_bwd")) else ms / n) / 1e3
+        path = None
+        if bound == "mfma":
+            split = name in SPLIT_BF16_GROUPS and not opts
+            ach, unit = amount / per_unit_s / 1e12, "TFLOP/s"
+            peak = round(PEAK_SPLIT_BF16_TFLOPS, 1) if split else PEAK_F32_MFMA_TFLOPS
+            path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
+        else:
+            ach, peak, unit = amount / per_unit_s / 1e9, PEAK_HBM_GBPS, "GB/s"
+        extra = {}
+        if name in GRU_GROUPS and valu_clock_mhz:
+            # the recurrence is a serial chain on 2B of the 256 CUs: HBM (what north_star asks to see) is not what bounds it.  Against the
+            # fp32 rate of the CUs it occupies:
+            cyc = per_unit_s * valu_clock_mhz * 1e6 / (T // 5)
+            floor = GRU_FMA_PER_STEP / CU_FMA_PER_CLK
+            extra = {"cus_used": 2 * B, "cycles_per_step": round(cyc, 1), "fp32_floor_cycles_per_step": floor,
+                     "frac_of_fp32_peak_of_used_cus": round(floor / cyc, 4),
+                     "clock_MHz": round(valu_clock_mhz), "phase_split": "profiles/r03_gru_experiments.txt (in-kernel timeline: the two waves of a SIMD "
+                     "queue; gate tail = a chain of ~20 dependent VALU ops at 8.3-17.6 cycles each)"}
+        return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name, {}).get("hbm_bytes_per_launch"),
+                "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // steps, "ms_per_step": round(ms / steps, 4),
+                **({"mfma_path": path} if path else {}), **extra}
+
+    for name, n, ms in kernels:
+        breakdown[name] = round(ms / steps, 4)
+        r = roof(name, n, ms)
+        if r:
+            per_kernel[name] = r
+    return per_kernel, breakdown
+
+
+def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(), timing_level=1, with_features=False, profile_level=0,
+                 allreduce_ablation=False):
+    """One BASELINE workload on this rank's GPU: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize
+    (max over ranks), with the library's HIP-event timers at `timing_level` inside the timed region.  `profile_level` > timing_level:
+    a SECOND pass of `steps` steps with the finer per-kernel scopes (hundreds of event pairs per step for the block models: they cost a few
+    percent, so they never run in the pass that is timed for `value`)."""
+    import ctypes as C
+    from seld_amd import losses, models, train
+    from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only
+    dist = torch.distributed
+    global N_PARAMS
+    model = models.seldnet((B, T, 64, 7), model_config_of(name), device=local)
+    N_PARAMS = model.n_params
+    for kv in opts:
+        key, _, val = kv.partition("=")
+        model.set_option(key, int(val))
+    x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
+    x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
+    opt = train.Adam(1e-3)
+    sed_loss, doa_loss, lw = losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0)
+    featurize = None
+    if with_features:
+        from seld_amd import _lib, feature_extractor as FE
+        if T != 3000:
+            raise SystemExit("--with-features extracts 60-s clips: --frames must be 3000")
+        rng = np.random.default_rng(77 + rank)
+        wavs = torch.as_tensor((rng.standard_normal((B, 4, 1440000)) * 0.1).astype(np.float32)).to(dev)
+        fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=local)
+        # the normaliser's statistics are FITTED on the device (feature_extractor.calculate_statistics, :218-224) from this rank's clips,
+        # once, as the reference fits them once per dataset
+        f_mean, f_std = FE.FeatureStatistics(64, 7, device=local).update(fx.batch(wavs)).result()
+        f_mean, f_std = f_mean.reshape(-1).contiguous(), f_std.reshape(-1).contiguous()
+
+        def featurize():
+            st_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            f = fx.batch(wavs)                                   # [B, 3001, 64, 7]: one pair of launches
+            for b in range(B):
+                _lib.check(fx.lib.seld_feat_normalize(f[b].data_ptr(), f_mean.data_ptr(), f_std.data_ptr(), x[b].data_ptr(), 3001, 3000,
+                                                      64 * 7, 1e-8, st_))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_pass(level, n, **kw):
+        model.lib.seld_profile_reset(model.ctx)
+        model.lib.seld_profile_enable(model.ctx, level)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            if featurize:
+                featurize()
+            r = train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt, **kw)
+        barrier()
+        el = time.perf_counter() - t0
+        model.lib.seld_profile_enable(model.ctx, 0)
+        return el, r
+
+    for _ in range(warmup):
+        if featurize:
+            featurize()
+        train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
+    elapsed, (y_p, sl, dl) = timed_pass(timing_level, steps)
+    elapsed_local = elapsed
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.isfinite(float(sl.item())), "non-finite loss"
+    kernels = read_timers(model)
+    res = {"model": model, "elapsed": elapsed, "kernels": kernels, "comm": None, "profile": None}
+    if world > 1 and allreduce_ablation:
+        # exposed communication per step and rank: the same steps again without the gradient all-reduce (timing aid only:
+        # replicas then drift apart, nothing is reported from them but the time)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            if featurize:
+                featurize()
+            train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt, allreduce=False)
+        torch.cuda.synchronize()
+        local_no_comm = time.perf_counter() - t1
+        barrier()
+        both = torch.tensor([elapsed_local, local_no_comm], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(both) for _ in range(world)]
+        dist.all_gather(allr, both)
+        res["comm"] = {"exposed_ms_per_step_by_rank": [round(float((a[0] - a[1]).item()) / steps * 1e3, 4) for a in allr],
+                       "ms_per_step_without_allreduce_by_rank": [round(float(a[1].item()) / steps * 1e3, 4) for a in allr],
+                       "note": "timed region repeated with the gradient all-reduce skipped; exposed = with - without, per rank"}
+    if profile_level > timing_level:
+        el2, _ = timed_pass(profile_level, steps)
+        res["profile"] = {"kernels": read_timers(model), "ms_per_step_with_events": round(el2 / steps * 1e3, 3)}
+    return res
+
+
+def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_mhz, with_features):
+    per_kernel, breakdown = rooflines(res["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz)
+    fine = None
+    if res["profile"]:
+        fine, fine_breakdown = rooflines(res["profile"]["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=True)
+        # the dominant kernel is chosen among the FINE groups (a level-1 group such as rn_stages_bwd lumps products, BatchNorm passes and
+        # waits for the side stream); groups that enclose other groups are not candidates
+        cand = {k: v for k, v in fine.items() if k not in ("rn_stages_fwd", "rn_stages_bwd")}
+        roofline = max(cand.values(), key=lambda r: r["ms_per_step"]) if cand else None
+        breakdown = fine_breakdown
+        per_kernel = fine
+    else:
+        roofline = max(per_kernel.values(), key=lambda r: r["ms_per_step"]) if per_kernel else None
+    out = {
+        "metric": METRIC, "value": round(world * B * steps / res["elapsed"], 2), "unit": "clips/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(res["elapsed"] / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_text(name, B, T, with_features), "global_batch": world * B, "parallelism": f"dp{world}",
+                   "doa_loss": "MSE", "loss_weight": "1,1000"},
+        "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
+    }
+    if res["profile"]:
+        out["roofline_pass"] = {"what": "per-kernel HIP-event scopes in a second pass of the same steps (not the pass timed for `value`)",
+                                "ms_per_step_with_events": res["profile"]["ms_per_step_with_events"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +447,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-level", type=int, default=1, help="1: major kernel groups (default), 2: every group")
+    ap.add_argument("--timing-level", type=int, default=1, help="1: major kernel groups (default), 2: every group, 3: + per-kernel scopes of resnet50_block")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=0|1",
                     help="kernel-selection option of the C library (seld_set_option), for A/B runs; the default build is the product")
     ap.add_argument("--cpu-steps", type=int, default=10, help="cpu_baseline: timed steps per batch size (median), after --cpu-warmup")
@@ -228,6 +455,9 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="cpu_baseline at the GPU batch: fewer than --cpu-steps steps are timed (never fewer than 3) if they would exceed this")
     ap.add_argument("--no-features", action="store_true", help="skip the feature-stage leg")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N=1, --model seldnet only: skip the `configs` sub-records (BASELINE configs[3] xception_gru and configs[4] resnet50_gru "
+                         "with in-step features, each timed like the headline after it)")
     ap.add_argument("--model", default="seldnet", choices=["seldnet", "xception_gru", "resnet50_gru"],
                     help="model_config of the reference: seldnet.json (the headline, BASELINE configs[1]), xception_gru.json "
                          "(configs[3]) or resnet50_gru.json (configs[4]); the FIRST blocks of the latter two are defined by "
@@ -258,175 +488,53 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from seld_amd import losses, models, train
-    from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only
-
     B, T = args.batch, args.frames
-    import copy
-    model_config = copy.deepcopy(SELDNET_CONFIG)
-    if args.model == "xception_gru":        # model_config/xception_gru.json:2-11
-        model_config["FIRST"] = "xception_block"
-        model_config["FIRST_ARGS"] = {"filters": 32, "block_num": 8, "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
-    if args.model == "resnet50_gru":        # model_config/resnet50_gru.json:2-11
-        model_config["FIRST"] = "resnet50_block"
-        model_config["FIRST_ARGS"] = {"filters": 32, "block_num": list(RESNET_BLOCKS), "kernel_regularizer": {"l1": 0, "l2": 1e-3}}
-    model = models.seldnet((B, T, 64, 7), model_config, device=local)
-    global N_PARAMS
-    N_PARAMS = model.n_params
-    for kv in args.opt:
-        key, _, val = kv.partition("=")
-        model.set_option(key, int(val))
-    x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
     dev = torch.device("cuda", local)
-    x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
-    opt = train.Adam(1e-3)
-    sed_loss, doa_loss, lw = losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0)
-    featurize = None
-    if args.with_features:
-        import ctypes as C
-        from seld_amd import _lib, feature_extractor as FE
-        if T != 3000:
-            raise SystemExit("--with-features extracts 60-s clips: --frames must be 3000")
-        rng = np.random.default_rng(77 + rank)
-        wavs = torch.as_tensor((rng.standard_normal((B, 4, 1440000)) * 0.1).astype(np.float32)).to(dev)
-        fx = FE.FeatureExtractor(24000, "foa", 64, win_length=960, hop_length=480, n_fft=1024, device=local)
-        f_mean = torch.full((64 * 7,), -3.0, device=dev)     # a fitted normalizer's statistics (data_loader.py:226-234), synthetic here
-        f_std = torch.full((64 * 7,), 2.0, device=dev)
-
-        def featurize():
-            st_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            f = fx.batch(wavs)                                   # [B, 3001, 64, 7]: one pair of launches
-            for b in range(B):
-                _lib.check(fx.lib.seld_feat_normalize(f[b].data_ptr(), f_mean.data_ptr(), f_std.data_ptr(), x[b].data_ptr(), 3001, 3000,
-                                                      64 * 7, 1e-8, st_))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # run on a non-default stream: the legacy null stream serialises against every other blocking stream
     # and makes event records / launches heavier
     run_stream = torch.cuda.Stream(device=dev)
     run_stream.wait_stream(torch.cuda.current_stream(dev))
     torch.cuda.set_stream(run_stream)
-    for _ in range(args.warmup):
-        if featurize:
-            featurize()
-        train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
-    timing = not args.no_kernel_timing
-    model.lib.seld_profile_reset(model.ctx)
-    model.lib.seld_profile_enable(model.ctx, args.timing_level if timing else 0)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if featurize:
-            featurize()
-        y_p, sl, dl = train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_local = elapsed
-    model.lib.seld_profile_enable(model.ctx, 0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert np.isfinite(float(sl.item())), "non-finite loss"
-    comm = None
-    if world > 1:
-        # exposed communication per step and rank: the same steps again without the gradient all-reduce (timing aid only:
-        # replicas then drift apart, nothing is reported from them but the time)
-        model.lib.seld_profile_enable(model.ctx, 0)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            if featurize:
-                featurize()
-            train.trainstep(model, x, (ys, yd), sed_loss, doa_loss, lw, opt, allreduce=False)
-        torch.cuda.synchronize()
-        local_no_comm = time.perf_counter() - t1
-        barrier()
-        both = torch.tensor([elapsed_local, local_no_comm], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(both) for _ in range(world)]
-        dist.all_gather(allr, both)
-        comm = {"exposed_ms_per_step_by_rank": [round(float((a[0] - a[1]).item()) / args.steps * 1e3, 4) for a in allr],
-                "ms_per_step_without_allreduce_by_rank": [round(float(a[1].item()) / args.steps * 1e3, 4) for a in allr],
-                "note": "timed region repeated with the gradient all-reduce skipped; exposed = with - without, per rank"}
-
+    timing = 0 if args.no_kernel_timing else args.timing_level
+    res = run_workload(args.model, B, T, args.steps, args.warmup, world, rank, local, dev, opts=args.opt, timing_level=timing,
+                       with_features=args.with_features, allreduce_ablation=True)
     if rank == 0:
         import ctypes as C
-        kernels = []
-        for i in range(model.lib.seld_profile_count(model.ctx)):
-            name = C.create_string_buffer(64)
-            n, ms = C.c_int64(), C.c_double()
-            model.lib.seld_profile_get(model.ctx, i, name, 64, C.byref(n), C.byref(ms))
-            kernels.append((name.value.decode(), int(n.value), float(ms.value)))
-        roofline, breakdown, per_kernel = None, {}, {}
+        model = res["model"]
         mhz = C.c_double()
         valu_clock_mhz = float(mhz.value) if model.lib.seld_k_valu_clock_mhz(2 * B, C.byref(mhz)) == 0 else None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
-
-        def roof(name, n, ms):
-            work = kernel_work(name, B, T)
-            if not work or n == 0:
-                return None
-            bound, amount = work
-            avg_s = ms / n / 1e3
-            path = None
-            if bound == "mfma":
-                split = name in SPLIT_BF16_GROUPS and not args.opt
-                ach, unit = amount / avg_s / 1e12, "TFLOP/s"
-                peak = round(PEAK_SPLIT_BF16_TFLOPS, 1) if split else PEAK_F32_MFMA_TFLOPS
-                path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
-            else:
-                ach, peak, unit = amount / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s"
-            extra = {}
-            if name in GRU_ISSUE_CYCLES_PER_STEP and valu_clock_mhz:
-                # the recurrence is a serial chain on 2B of the 256 CUs: HBM (what north_star asks to see) is not what bounds it
-                floor_ms = (T // 5) * GRU_ISSUE_CYCLES_PER_STEP[name] / (valu_clock_mhz * 1e3)
-                extra = {"latency_floor_ms": round(floor_ms, 4), "frac_of_latency_floor": round(floor_ms / (avg_s * 1e3), 4),
-                         "latency_model": f"{T // 5} dependent steps x {GRU_ISSUE_CYCLES_PER_STEP[name]:.0f} VALU issue cycles "
-                                          f"(2 waves per SIMD) / {valu_clock_mhz:.0f} MHz measured under a VALU-only load on {2 * B} CUs",
-                         "cycles_per_step": round(avg_s * valu_clock_mhz * 1e6 / (T // 5), 1)}
-            return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name, {}).get("hbm_bytes_per_launch"),
-                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": n // args.steps,
-                    **({"mfma_path": path} if path else {}), **extra}
-
-        if kernels:
-            for name, n, ms in kernels:
-                breakdown[name] = round(ms / args.steps, 4)
-                r = roof(name, n, ms)
-                if r:
-                    per_kernel[name] = r
-            # the dominant kernel group = largest summed time over the timed region
-            name, n, ms = max(kernels, key=lambda k: k[2])
-            roofline = roof(name, n, ms)
-        out = {
-            "metric": METRIC, "value": round(world * B * args.steps / elapsed, 2), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"model_config/{args.model}.json train step (fwd+BCE/MSE+bwd+Adam), {B} clips/GPU of [T={T},F=64,C=7], n_classes=12"
-                                   + (" (FIRST block per spec/XCEPTION_BLOCK.md: absent from the reference snapshot)" if args.model == "xception_gru" else "")
-                                   + (" (FIRST block per spec/RESNET50_BLOCK.md: absent from the reference snapshot)" if args.model == "resnet50_gru" else "")
-                                   + (", features extracted on the device from 60-s FOA waveforms inside every step" if featurize else ""),
-                       "global_batch": world * B, "parallelism": f"dp{world}", "doa_loss": "MSE", "loss_weight": "1,1000"},
-            "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
-        }
+        out = record(args.model, B, T, args.steps, args.warmup, world, res, args.opt, traffic_tab, valu_clock_mhz, args.with_features)
+        mu = os.path.join(ROOT, "profiles", "mfma_util.json")
+        if os.path.exists(mu):
+            out["mfma_util"] = json.load(open(mu))       # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES pass (tools/pmc_mfma.py)
         out["peaks_on_box"] = box_peaks(model.lib, local)
-        if comm:
-            out["comm"] = comm
+        if res["comm"]:
+            out["comm"] = res["comm"]
         if world == 1 and not args.no_features:
             out["features"] = features_leg(dev)
             # PMC bytes of the extraction kernel per LAUNCH (tools/bench_features.py: 8 clips per launch) -> per clip, like `achieved`
             ft = traffic_tab.get("feat_dft", traffic_tab.get("feat_frame", {})).get("hbm_bytes_per_launch")
             out["features"]["roofline"]["traffic"] = None if ft is None else int(ft / (8 if "feat_dft" in traffic_tab else 1))
             out["features"]["roofline"]["kernel"] = "feat_dft" if "feat_dft" in traffic_tab else "feat_frame"
+        del model
+        res["model"] = None
+        if world == 1 and args.model == "seldnet" and not args.no_configs and not args.opt and T == 3000:
+            # BASELINE.json configs[3] and configs[4] as sub-records of the same driver-timed run: each its own model, warm-ups, barrier-
+            # bracketed timed steps and rooflines (configs[4] = the per-GPU share, 16 clips, of the batch-128 DP-8 job, features in the step)
+            out["configs"] = {}
+            sub_steps = max(10, args.steps // 2)
+            for sub, sb, feat, lvl in (("xception_gru", 32, False, 2), ("resnet50_gru", 16, True, 3)):
+                torch.cuda.empty_cache()
+                r = run_workload(sub, sb, T, sub_steps, args.warmup, world, rank, local, dev, timing_level=1, with_features=feat,
+                                 profile_level=0 if args.no_kernel_timing else lvl)
+                out["configs"][sub] = record(sub, sb, T, sub_steps, args.warmup, world, r, (), traffic_tab, valu_clock_mhz, feat)
+                out["configs"][sub].pop("metric")
+                r["model"] = None
+                del r
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config)
+            out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config_of(args.model))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -225,7 +225,8 @@ int seld_metrics_update(const float* sed_true, const float* doa_true, const floa
                         int n_classes, int block_size, float doa_threshold, double* state, float* scratch, void* stream);
 
 /* ---- measurement: HIP-event timing of named kernel groups on the ctx stream (bench.py roofline).
- * seld_profile_enable(ctx, level): 0 off, 1 the four largest groups (conv1 fwd / conv1 wgrad / GRU fwd / GRU BPTT), 2 every group */
+ * seld_profile_enable(ctx, level): 0 off, 1 the largest groups (conv1 fwd / conv1 wgrad / GRU fwd / GRU BPTT, the resnet stages), 2 every group,
+ * 3 additionally one scope per product / BatchNorm launch of resnet50_block (hundreds of event pairs per step: a profile pass, not a timed one) */
 int seld_profile_enable(seld_ctx* ctx, int on);
 int seld_profile_count(const seld_ctx* ctx);
 int seld_profile_get(seld_ctx* ctx, int index, char* name, int name_cap, int64_t* launches, double* total_ms);

@@ -199,6 +199,9 @@ struct ProfScope {
 #define PROF_CAT(a, b) PROF_CAT2(a, b)
 #define PROF(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name, 1)
 #define PROF2(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name, 2)
+// level 3: per-kernel-kind scopes INSIDE the level-1 groups of the block models (hundreds of event pairs per step: a separate
+// profile pass of bench.py, never the pass that is timed for `value`)
+#define PROF3(c, name) ProfScope PROF_CAT(prof_scope_, __LINE__)(c, name, 3)
 
 int check_launch(seld_ctx* c, const char* what) {
     hipError_t e = hipGetLastError();
@@ -855,6 +858,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         PROF(c, "rn_stages_fwd");
         const bool sb = c->rn_split_bf16 != 0;
         if (sb) {      // this step's weight planes, 16 operands per launch
+            PROF3(c, "rn_weight_prep");
             const float* src[16]; unsigned short* dst[16]; int ldb[16], tb[16], Ks[16], Ns[16];
             int n = 0;
             auto add = [&](const float* w, unsigned short* d, int ld, int transb, int k, int nn) {
@@ -896,43 +900,43 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 hipEventRecord(c->ev_rn_free[0], c->side);
             }
             // 1x1 (frequency stride = doubled row stride of the operand), BN, ReLU
-            launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w);
-            rn_bn(c, st, R.c[0], M, training);
-            launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1);
+            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w); }
+            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[0], M, training); }
+            { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1); }
             // 3x3, BN, ReLU: 64 -> 64 (stage 1) on the implicit-GEMM kernel of the conv blocks (BatchNorm's sums from its epilogue),
             // the other widths as a product on im2col rows
             if (sb && rn_c1_direct(R)) {
                 int npart = 0;
                 if (R.c[1].w2) {      // stage 0: the epilogue's sums are per (bin parity, channel): the statistics pass instead
-                    launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, nullptr, nullptr, B, S, rn_c1_width(R));
-                    rn_bn(c, st, R.c[1], M, training);
+                    { PROF3(c, "rn_products_fwd"); launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, nullptr, nullptr, B, S, rn_c1_width(R)); }
+                    { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
                 } else {
-                    launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout);
-                    rn_bn(c, st, R.c[1], M, training, npart);
+                    { PROF3(c, "rn_products_fwd"); launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout); }
+                    { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training, npart); }
                 }
             } else if (sb && rn_c1_implicit(c, R)) {
-                launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w);
-                rn_bn(c, st, R.c[1], M, training);
+                { PROF3(c, "rn_products_fwd"); launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w); }
+                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
             } else {
                 // (only with rn_split_bf16 / rn_implicit3x3 off, or a width no direct kernel takes: the col tensor is allocated here, once)
                 if (!R.c[1].col && dalloc(c, &R.c[1].col, (size_t)M * 9 * w)) return fail(c, SELD_ERR_NOMEM, "im2col tensor");
                 launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
-                launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w);
-                rn_bn(c, st, R.c[1], M, training);
+                { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w); }
+                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
             }
-            launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1);
+            { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1); }
             // 1x1 expand, BN; shortcut; out = ReLU(y + r)
-            launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w);
-            rn_bn(c, st, R.c[2], M, training);
+            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w); }
+            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[2], M, training); }
             if (R.proj) {
                 if (sc_side) hipStreamWaitEvent(st, c->ev_rn_free[0], 0);
                 else {
-                    launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
-                    rn_bn(c, st, R.sc, M, training);
+                    { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w); }
+                    { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.sc, M, training); }
                 }
-                launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w, save ? R.gate : nullptr);
+                { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w, save ? R.gate : nullptr); }
             } else {
-                launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1, save ? R.gate : nullptr);
+                { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply(st, R.c[2].z, R.c[2].coef, X, R.out, M, 4 * w, 1, save ? R.gate : nullptr); }
             }
             X = R.out;
         }
@@ -1260,12 +1264,12 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const int ldx = R.Cin * R.stride_f;
             // main branch: BN2 (behind the block's ReLU: mask = out), 1x1 expand
             float* dz2 = take(0, 2, zi);
-            rn_bn_bwd(c, st, R.c[2], g, R.gate, dz2, M);
+            { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.c[2], g, R.gate, dz2, M); }
             wgrad(zi, R.y1, w, dz2, (int)M, w, 4 * w, R.c[2].w_off);
-            launch_rn_product_dgrad(st, dz2, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0);
+            { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dz2, c->params + R.c[2].w_off, sb ? R.c[2].wsp_t : nullptr, c->rn_ba, w, (int)M, w, 4 * w, 0); }
             // BN1 (mask = y1), 3x3: stage 1 on the conv blocks' kernels, the other widths through im2col / col2im
             float* dz1 = take(2, 3, bbi);
-            rn_bn_bwd(c, st, R.c[1], c->rn_ba, nullptr, dz1, M);
+            { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.c[1], c->rn_ba, nullptr, dz1, M); }
             if (sb && rn_c1_direct(R)) {
                 fork(bbi);
                 int ns = 0;
@@ -1276,34 +1280,34 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 } else
                     launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
                 done(bbi);
-                launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, rn_c1_width(R));
+                { PROF3(c, "rn_products_dgrad"); launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, rn_c1_width(R)); }
             } else if (sb && rn_c1_implicit(c, R)) {
                 fork(bbi);
                 launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, tn_slab_capacity(), c->grads + R.c[1].w_off, B, S,
                                       R.Wout, w, w);
                 done(bbi);
-                launch_rn_conv3_dgrad(st, dz1, R.c[1].wsp_t, c->rn_ba, B, S, R.Wout, w, w);
+                { PROF3(c, "rn_products_dgrad"); launch_rn_conv3_dgrad(st, dz1, R.c[1].wsp_t, c->rn_ba, B, S, R.Wout, w, w); }
             } else {
                 if (!R.c[1].col) return fail(c, SELD_ERR_INVALID, "resnet50_block: the options changed between forward and backward");
                 if (!c->rn_bcol && dalloc(c, &c->rn_bcol, c->rn_col_elems)) return fail(c, SELD_ERR_NOMEM, "col2im tensor");
                 wgrad(bbi, R.c[1].col, 9 * w, dz1, (int)M, 9 * w, w, R.c[1].w_off);
-                launch_rn_product_dgrad(st, dz1, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0);
+                { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dz1, c->params + R.c[1].w_off, sb ? R.c[1].wsp_t : nullptr, c->rn_bcol, 9 * w, (int)M, 9 * w, w, 0); }
                 launch_col2im3x3(st, c->rn_bcol, c->rn_ba, B, S, R.Wout, w);
             }
             // BN0 (mask = y0), 1x1 reduce; its input gradient lands on the strided rows of dX
             float* dz0 = take(2, 3, bbi);
-            rn_bn_bwd(c, st, R.c[0], c->rn_ba, nullptr, dz0, M);
+            { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.c[0], c->rn_ba, nullptr, dz0, M); }
             wgrad(bbi, X, ldx, dz0, (int)M, R.Cin, w, R.c[0].w_off);
             if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
-            launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0);
+            { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0); }
             // shortcut
             if (R.proj) {
                 float* dzs = take(0, 2, zi);
-                rn_bn_bwd(c, st, R.sc, g, R.gate, dzs, M);
+                { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.sc, g, R.gate, dzs, M); }
                 wgrad(zi, X, ldx, dzs, (int)M, R.Cin, 4 * w, R.sc.w_off);
-                launch_rn_product_dgrad(st, dzs, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1);
+                { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dzs, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1); }
             } else {
-                launch_rn_add_gated(st, dX, g, R.gate, M * 4 * w);
+                { PROF3(c, "rn_bn_bwd"); launch_rn_add_gated(st, dX, g, R.gate, M * 4 * w); }
             }
             g = dX;
             flip ^= 1;
@@ -1582,10 +1586,10 @@ int seld_debug_relu_output(seld_ctx* c, int block, int which, float* dst, int64_
 // ---------------------------------------------------------------------------------------------- profiling
 int seld_profile_enable(seld_ctx* c, int on) {
     if (!c) return SELD_ERR_INVALID;
-    c->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
+    c->prof = on < 0 ? 0 : (on > 3 ? 3 : on);
     if (c->prof) {      // events for a default bench run of scopes up front; prof_resolve (seld_profile_get / _reset) recycles them
         hipSetDevice(c->device);
-        while (c->ev_pool.size() < (c->prof == 1 ? 1024u : 8192u)) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; c->ev_pool.push_back(e); }
+        while (c->ev_pool.size() < (c->prof == 1 ? 1024u : (c->prof == 2 ? 8192u : 32768u))) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; c->ev_pool.push_back(e); }
     }
     return SELD_OK;
 }
