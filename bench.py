@@ -328,6 +328,11 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
     for kv in opts:
         key, _, val = kv.partition("=")
         model.set_option(key, int(val))
+    if world > 1:
+        # RCCL process group: the LIBRARY owns the communicator, the communication stream and the two gradient buckets (seld_dp_*);
+        # over gloo (the one-GPU rehearsal) the torch.distributed path stays
+        from seld_amd import parallel
+        parallel.init_library_dp(model)
     x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
     opt = train.Adam(1e-3)

@@ -82,6 +82,12 @@ SIGNATURES = {
     "seld_grads_bucket_count": (_I, [_P]),
     "seld_grads_bucket_ready": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_L)]),
     "seld_set_sync_bn": (_I, [_P, _P, _P, _I]),
+    "seld_dp_unique_id": (_I, [_P]),
+    "seld_dp_init": (_I, [_P, _I, _I, _P]),
+    "seld_dp_world": (_I, [_P]),
+    "seld_dp_allreduce_grads": (_I, [_P]),
+    "seld_dp_set_sync_bn": (_I, [_P, _I]),
+    "seld_dp_destroy": (_I, [_P]),
     "seld_adam_step": (_I, [_P, _F, _F, _F, _F, _I]),
     "seld_train_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _F, _I, _P, _P, _P, _P]),
     "seld_test_step": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P]),

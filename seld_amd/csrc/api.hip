@@ -4,6 +4,8 @@
 #include "../../include/seld_hip.h"
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the functions are bound with dlsym (see struct Rccl)
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -127,6 +129,11 @@ struct seld_ctx {
     int sync_world = 1;
     double* sync_buf = nullptr;                   // [128] (resnet50_block: [16][128]) sums handed to sync_fn
     bool sync_failed = false;                     // the all-reduce callback failed inside a helper: reported at the end of the pass
+    // data parallelism inside the library (seld_dp_*): one RCCL communicator, a communication stream, two events
+    void* dp_comm = nullptr;                      // ncclComm_t
+    int dp_rank = 0, dp_world = 1;
+    hipStream_t dp_stream = nullptr;
+    hipEvent_t ev_dp_main = nullptr, ev_dp_done = nullptr;
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
@@ -207,6 +214,40 @@ int check_launch(seld_ctx* c, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, SELD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     return 0;
+}
+
+// ---- RCCL, bound at run time
+struct Rccl {
+    bool ok = false;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    Rccl() {
+        void* h = nullptr;
+        for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString;
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+
+// in-place SUM over the ranks of the library's communicator; 0 = enqueued
+int dp_allreduce(seld_ctx* c, void* buf, int64_t count, int dtype, hipStream_t st) {
+    if (!c->dp_comm || count < 0) return 1;
+    if (count == 0) return 0;
+    return rccl().AllReduce(buf, buf, (size_t)count, dtype == SELD_DTYPE_F64 ? ncclFloat64 : ncclFloat32, ncclSum,
+                            static_cast<ncclComm_t>(c->dp_comm), st) == ncclSuccess ? 0 : 1;
+}
+int dp_sync_bn_fn(void* user, void* buf, int64_t count, int dtype, void* hip_stream) {
+    return dp_allreduce(static_cast<seld_ctx*>(user), buf, count, dtype, static_cast<hipStream_t>(hip_stream));
 }
 
 }  // namespace
@@ -527,6 +568,7 @@ void seld_destroy(seld_ctx* c) {
     if (c->ev_rn_ready) hipEventDestroy(c->ev_rn_ready);
     for (auto e_ : c->ev_rn_free) if (e_) hipEventDestroy(e_);
     for (auto e : c->ev_bucket) if (e) hipEventDestroy(e);
+    seld_dp_destroy(c);
     if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -889,6 +931,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         }
         const float* X = in;      // [B,S,Win,Cin]
         for (auto& R : c->rn) {
+            if (c->sync_failed) break;     // a failed SyncBN collective: enqueue nothing further (the error is reported below)
             const int64_t M = (int64_t)B * S * R.Wout;
             const int w = R.w;
             // the projection shortcut (first block of a stage) depends on the block input only: side stream, joined before the add
@@ -1033,6 +1076,8 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
             hipStreamSynchronize(st);  // cfg may live on the caller's stack
         } else {
             launch_mmse_den(st, y_doa, c->den_dev, c->loss_scratch, rows, nc);
+            // data parallel (seld_dp_init): the mask count of the GLOBAL batch, summed in place on this stream — no host round trip
+            if (c->dp_comm && c->dp_world > 1 && dp_allreduce(c, c->den_dev, 1, SELD_DTYPE_F32, st)) return fail(c, SELD_ERR_HIP, "RCCL all-reduce of the MMSE denominator failed");
         }
     }
     float* sl = sloss ? sloss : c->loss_out;
@@ -1256,6 +1301,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
         const float* g = dout;
         int flip = 0;
         for (int bi = (int)c->rn.size() - 1; bi >= 0; --bi) {
+            if (c->sync_failed) break;     // a failed SyncBN collective: enqueue nothing further (the error is reported below)
             RnBlock& R = c->rn[bi];
             const int64_t M = (int64_t)B * S * R.Wout;
             const int w = R.w;
@@ -1521,6 +1567,89 @@ int seld_set_sync_bn(seld_ctx* c, seld_allreduce_fn fn, void* user, int world) {
     c->sync_user = user;
     c->sync_world = fn ? world : 1;
     return SELD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- data parallelism (RCCL)
+// one process per GPU, a full weight replica per rank, clips sharded; the library owns the communicator.
+// RCCL is bound at run time (dlopen: a process that already carries an RCCL, e.g. PyTorch's, is joined to THAT copy by its SONAME;
+// a plain C host gets /opt/rocm/lib's) so that libseld_hip.so has no link-time dependency on it and loads where RCCL is absent.
+int seld_dp_unique_id(void* id_out) {
+    if (!id_out) return SELD_ERR_INVALID;
+    if (!rccl().ok) return SELD_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return SELD_ERR_HIP;
+    memcpy(id_out, &id, sizeof id);
+    return SELD_OK;
+}
+
+int seld_dp_init(seld_ctx* c, int rank, int world, const void* unique_id) {
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return SELD_ERR_INVALID;
+    if (c->dp_comm) return fail(c, SELD_ERR_INVALID, "seld_dp_init: this context already has a communicator");
+    if (!rccl().ok) return fail(c, SELD_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = rccl().CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return fail(c, SELD_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    c->dp_comm = comm;
+    c->dp_rank = rank;
+    c->dp_world = world;
+    // the communication stream reads gradients the side stream wrote and hands them back to the main stream: events with the default
+    // (system-scope) release, as the bucket events have
+    if (hipStreamCreateWithFlags(&c->dp_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dp_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dp_done, hipEventDisableTiming) != hipSuccess)
+        return fail(c, SELD_ERR_HIP, "seld_dp_init: stream / event creation failed");
+    return SELD_OK;
+}
+
+int seld_dp_world(const seld_ctx* c) { return c ? (c->dp_comm ? c->dp_world : 1) : -1; }
+
+int seld_dp_destroy(seld_ctx* c) {
+    if (!c) return SELD_ERR_INVALID;
+    if (c->dp_comm) {
+        hipSetDevice(c->device);
+        hipDeviceSynchronize();
+        if (c->sync_fn == dp_sync_bn_fn) { c->sync_fn = nullptr; c->sync_user = nullptr; c->sync_world = 1; }
+        rccl().CommDestroy(static_cast<ncclComm_t>(c->dp_comm));
+        c->dp_comm = nullptr;
+    }
+    if (c->dp_stream) { hipStreamDestroy(c->dp_stream); c->dp_stream = nullptr; }
+    if (c->ev_dp_main) { hipEventDestroy(c->ev_dp_main); c->ev_dp_main = nullptr; }
+    if (c->ev_dp_done) { hipEventDestroy(c->ev_dp_done); c->ev_dp_done = nullptr; }
+    c->dp_world = 1;
+    return SELD_OK;
+}
+
+// The gradient all-reduce of one step, between seld_train_fwd_bwd and seld_adam_step: TWO collectives, both
+// in place on the flat gradient buffer, on the library's communication stream:
+//   1. GRU layers + heads (1.74 MB of the 2.06 MB): final when the FIRST GRU layer's weight-gradient products have drained on the side
+//      stream (its bucket event; the side stream is in order, so the later layers' and the heads' are final too) — about 0.5 ms before the
+//      backward pass ends: the conv backward runs meanwhile;
+//   2. conv / BN variables: final when the main stream has drained (an event recorded here).
+// The main stream then waits for the communication stream: seld_adam_step sees summed gradients.
+int seld_dp_allreduce_grads(seld_ctx* c) {
+    if (!c) return SELD_ERR_INVALID;
+    if (!c->dp_comm) return fail(c, SELD_ERR_INVALID, "seld_dp_allreduce_grads: no communicator (seld_dp_init)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t split = c->gru[0].k_off[0];
+    HIPCHK(c, hipStreamWaitEvent(c->dp_stream, c->ev_bucket[(int)c->gru.size() - 1], 0));
+    if (dp_allreduce(c, c->grads + split, c->nparam - split, SELD_DTYPE_F32, c->dp_stream)) return fail(c, SELD_ERR_HIP, "RCCL all-reduce (GRU + heads gradients) failed");
+    HIPCHK(c, hipEventRecord(c->ev_dp_main, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->dp_stream, c->ev_dp_main, 0));
+    if (dp_allreduce(c, c->grads, split, SELD_DTYPE_F32, c->dp_stream)) return fail(c, SELD_ERR_HIP, "RCCL all-reduce (conv / BN gradients) failed");
+    HIPCHK(c, hipEventRecord(c->ev_dp_done, c->dp_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dp_done, 0));
+    return SELD_OK;
+}
+
+// Synchronised BatchNorm through the library's communicator: the per-channel sums are all-reduced on the stream the BatchNorm runs on.
+// A failed collective is fatal for the process group (the peers block in theirs): the caller must abort the job.
+int seld_dp_set_sync_bn(seld_ctx* c, int on) {
+    if (!c) return SELD_ERR_INVALID;
+    if (on && !c->dp_comm) return fail(c, SELD_ERR_INVALID, "seld_dp_set_sync_bn: no communicator (seld_dp_init)");
+    return seld_set_sync_bn(c, on ? dp_sync_bn_fn : nullptr, on ? c : nullptr, on ? c->dp_world : 1);
 }
 
 int seld_train_fwd_bwd(seld_ctx* c, const float* x, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg,

@@ -34,6 +34,39 @@ def loss_scaling(is_mmse: bool, local_den: torch.Tensor | None, group=None):
     return 1.0 / w, float(den.item())
 
 
+def init_library_dp(model, group=None, force: bool = False) -> bool:
+    """Hand data parallelism to the LIBRARY (include/seld_hip.h, seld_dp_*): one RCCL communicator per ctx, created here from a
+    ncclUniqueId that rank 0 draws (seld_dp_unique_id) and torch.distributed carries to the other ranks — the only thing the host's
+    process group is used for.  From then on `train.trainstep` calls seld_dp_allreduce_grads (two collectives on the library's own
+    communication stream), the MMSE mask count is all-reduced on the device (no `.item()`), and `enable_sync_batchnorm` routes
+    through the same communicator.  Returns False (and leaves the torch.distributed path in charge) when the group's backend is not
+    RCCL — the two-ranks-on-one-GPU rehearsal over gloo — or the group has one rank and `force` is not set (tests force a one-rank
+    communicator)."""
+    import ctypes as C
+    from . import _lib
+    d = torch.distributed
+    world = world_size(group)
+    if getattr(model, "_lib_dp", False):
+        return True
+    if world == 1 and not force:
+        return False
+    if world > 1 and d.get_backend(group) != "nccl":
+        return False
+    ident = torch.zeros(128, dtype=torch.uint8, device=model._dev)
+    rank = d.get_rank(group) if world > 1 else 0
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        _lib.check(model.lib.seld_dp_unique_id(buf), model.ctx)
+        ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+    if world > 1:
+        d.broadcast(ident, src=d.get_global_rank(group, 0) if group is not None else 0, group=group)
+    host = ident.cpu().numpy().tobytes()
+    torch.cuda.synchronize(model._dev)
+    _lib.check(model.lib.seld_dp_init(model.ctx, rank, world, host), model.ctx)
+    model._lib_dp = True
+    return True
+
+
 def allreduce_gradients(flat_grad: torch.Tensor, group=None, model=None, force: bool = False) -> None:
     """Sum the flat gradient buffer in place over ranks.
 
@@ -42,6 +75,10 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None, model=None, force: 
     still running —, then each earlier GRU layer, each on a communication stream that waits for exactly that bucket's
     event; the conv/BN bucket follows on the main stream when the step's kernels are enqueued.  All are complete (for the
     main stream) on return.  Without `model` (CPU tensors, gloo tests): one bucket."""
+    if model is not None and getattr(model, "_lib_dp", False):      # the library's own communicator, stream and bucket order
+        from . import _lib
+        _lib.check(model.lib.seld_dp_allreduce_grads(model.ctx), model.ctx)
+        return
     if world_size(group) <= 1 and not force:        # force: exercise the collective path on a one-rank group (tests)
         return
     d = torch.distributed
@@ -71,22 +108,35 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None, model=None, force: 
 def enable_sync_batchnorm(model, group=None, force: bool = False) -> None:
     """Synchronised BatchNorm over the ranks of `group` (seld_set_sync_bn): the per-channel sums of every conv block's
     BatchNormalization are all-reduced in the training forward and in the backward pass, so that B/world clips per rank
-    reproduce the reference's single-device batch of B (layers.py:33).  Six 1-KB collectives per step."""
+    reproduce the reference's single-device batch of B (layers.py:33).  Six 1-KB collectives per step.
+    EVERY RANK MUST HOLD THE SAME NUMBER OF CLIPS: the library takes the global element count as local count x world (only the sums
+    are all-reduced); `train.trainstep` checks that across the group whenever the local batch size changes (`check_equal_batch`).
+    A failing callback is fatal for the process group (the peers block in their collectives): exit the job."""
     import ctypes as C
     from . import _lib
     world = world_size(group)
+    if getattr(model, "_lib_dp", False):            # the library's communicator carries the sums (seld_dp_set_sync_bn)
+        _lib.check(model.lib.seld_dp_set_sync_bn(model.ctx, 1), model.ctx)
+        model._sync_bn_on, model._sync_bn_group, model._sync_bn_B = True, group, None
+        return
     if world <= 1 and not force:
         model.lib.seld_set_sync_bn(model.ctx, None, None, 1)
         model._sync_bn_cb = None
+        model._sync_bn_on = False
         return
     dev = model._dev
+    model._sync_bn_on, model._sync_bn_group, model._sync_bn_B = True, group, None
 
     def _cb(_user, buf, count, dtype, _stream):
         try:
             t = torch.as_tensor(_F64Ptr(int(buf), int(count)), device=dev) if dtype == _lib.SELD_DTYPE_F64 else None
             if t is None:
                 return 1
-            torch.distributed.all_reduce(t, group=group)       # enqueued behind the library's stream (= torch's current stream)
+            # the ABI says "enqueue on `stream`": torch.distributed enqueues on torch's CURRENT stream, which SeldNet._prep makes the
+            # ctx stream before every call — anything else would be an unordered collective on the library's buffer
+            if int(_stream or 0) != int(torch.cuda.current_stream(dev).cuda_stream):
+                return 1
+            torch.distributed.all_reduce(t, group=group)
             return 0
         except Exception:                                       # never let an exception cross the C ABI
             import traceback
@@ -102,3 +152,19 @@ class _F64Ptr:
 
     def __init__(self, ptr: int, n: int):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+
+def check_equal_batch(model, B: int) -> None:
+    """Synchronised BatchNorm needs the same clip count on every rank (see enable_sync_batchnorm).  One tiny MAX / MIN all-reduce
+    whenever this rank's batch size changes (a partial last batch); raises on every rank if they disagree."""
+    if not getattr(model, "_sync_bn_on", False) or getattr(model, "_sync_bn_B", None) == B:
+        return
+    group = model._sync_bn_group
+    if world_size(group) > 1:
+        d = torch.distributed
+        dev = model._dev if d.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([B, -B], dtype=torch.int64, device=dev)
+        d.all_reduce(t, op=d.ReduceOp.MAX, group=group)
+        if int(t[0]) != -int(t[1]):
+            raise ValueError(f"synchronised BatchNorm: ranks hold between {-int(t[1])} and {int(t[0])} clips; every rank must hold the same number")
+    model._sync_bn_B = B

@@ -54,16 +54,23 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     sloss, dloss = _loss_outputs(model, doa_loss, B)
     world = parallel.world_size(process_group)
     is_mmse = isinstance(doa_loss, losses._MMSE)
+    lib_dp = getattr(model, "_lib_dp", False)        # parallel.init_library_dp: the library owns the RCCL communicator
+    parallel.check_equal_batch(model, B)
     dent = None
-    if world > 1 and is_mmse:
+    if lib_dp:
+        pass            # the mask count is all-reduced on the device inside seld_train_fwd_bwd (cfg.mmse_den = 0)
+    elif world > 1 and is_mmse:
         # scalar objective: BCE is a mean over the GLOBAL batch, MMSE divides by the GLOBAL sum(mask)
         dent = torch.empty(1, dtype=torch.float32, device=model._dev)
         _lib.check(model.lib.seld_mmse_den(model.ctx, yd.data_ptr(), dent.data_ptr()), model.ctx)
-    sed_scale, den = parallel.loss_scaling(is_mmse, dent, process_group)
+    if lib_dp:
+        sed_scale, den = (1.0 / int(model.lib.seld_dp_world(model.ctx)) if is_mmse else 1.0), 0.0
+    else:
+        sed_scale, den = parallel.loss_scaling(is_mmse, dent, process_group)
     cfg = _cfg(doa_loss, loss_weight, sed_scale, den)
     _lib.check(model.lib.seld_train_fwd_bwd(model.ctx, x.data_ptr(), ys.data_ptr(), yd.data_ptr(), C.byref(cfg),
                                             sed.data_ptr(), doa.data_ptr(), sloss.data_ptr(), dloss.data_ptr()), model.ctx)
-    if world > 1 and allreduce:      # allreduce=False: timing aid only (bench.py measures the exposed communication time with it)
+    if (world > 1 or lib_dp) and allreduce:      # allreduce=False: timing aid only (bench.py measures the exposed communication time with it)
         parallel.allreduce_gradients(model.grad_tensor(), process_group, model)
     _lib.check(model.lib.seld_adam_step(model.ctx, optimizer.learning_rate, optimizer.beta_1, optimizer.beta_2,
                                         optimizer.epsilon, int(bool(agc))), model.ctx)

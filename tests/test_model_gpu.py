@@ -192,6 +192,40 @@ def test_grad_tensor_is_zero_copy_and_rccl_accepts_it(seldnet_config):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("doa_loss", ["MSE", "MMSE"])
+def test_library_owned_dp_one_rank_rccl(seldnet_config, doa_loss):
+    """Data parallelism inside the library (include/seld_hip.h seld_dp_*): a ONE-rank RCCL communicator on
+    the single test GPU (RCCL accepts world = 1; N > 1 needs a multi-GPU node, which this pool's test box is not) drives every code
+    path of the DP step — seld_dp_unique_id / seld_dp_init (RCCL bound with dlopen), the two in-place ncclAllReduce of
+    seld_dp_allreduce_grads on the library's communication stream between seld_train_fwd_bwd and seld_adam_step, the on-device
+    all-reduce of the MMSE mask count, synchronised BatchNorm through the same communicator.  On one rank every collective is the
+    identity, so the step must reproduce a plain step: gradients and post-Adam weights bit for bit (SyncBN: 1e-6, its finalisation
+    sums in a different order)."""
+    from seld_amd import losses, parallel, train
+    O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, 3, 100)
+    dl = losses.get_doa_loss(doa_loss)
+    step = lambda m: train.trainstep(m, x, (ys, yd), losses.BinaryCrossentropy(), dl, (1.0, 1000.0), train.Adam(1e-3))
+    step(model)
+    g0, (w0, s0) = model.get_grads().copy(), model.get_weights()
+    O2, spec2, m2, *_ = _setup(seldnet_config, 3, 100)
+    assert parallel.init_library_dp(m2, force=True) and m2._lib_dp
+    assert m2.lib.seld_dp_world(m2.ctx) == 1
+    assert m2.lib.seld_dp_init(m2.ctx, 0, 1, bytes(128)) != 0              # a second communicator on one ctx is refused
+    y_p, sl, dlo = step(m2)
+    np.testing.assert_array_equal(m2.get_grads(), g0)
+    w1, s1 = m2.get_weights()
+    np.testing.assert_array_equal(w1, w0)
+    np.testing.assert_array_equal(s1, s0)
+    # synchronised BatchNorm through the library's communicator
+    m2.set_weights(w, st)
+    parallel.enable_sync_batchnorm(m2)
+    step(m2)
+    check("library DP + SyncBN (one rank) grads", m2.get_grads(), g0, tol=1e-6)
+    assert m2.lib.seld_dp_set_sync_bn(m2.ctx, 0) == 0
+    assert m2.lib.seld_dp_destroy(m2.ctx) == 0 and m2.lib.seld_dp_world(m2.ctx) == 1
+    assert m2.lib.seld_dp_allreduce_grads(m2.ctx) != 0                     # no communicator any more: refused, not ignored
+
+
 @pytest.mark.parametrize("B,T", [(1, 5), (1, 35), (5, 20)])
 def test_edge_shapes(seldnet_config, B, T):
     """Smallest / ragged shapes: S = 1 (a single GRU step), S not a multiple of the GRU staging chunks,
