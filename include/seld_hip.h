@@ -67,6 +67,9 @@ typedef struct seld_arch {
     int32_t rn_filters;
     int32_t rn_blocks[4];
 } seld_arch;
+/* sizeof(seld_arch), sizeof(seld_loss_cfg) as the LIBRARY was compiled, into out[0..min(n,2)); returns how many it knows (2).  A binding
+ * compares them with its own struct declarations before the first seld_create. */
+int seld_abi_sizes(int32_t* out, int n);
 #define SELD_FIRST_SIMPLE_CONV 0
 #define SELD_FIRST_XCEPTION 1
 #define SELD_FIRST_RESNET50 2

@@ -55,6 +55,7 @@ _FP = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); must list every symbol include/seld_hip.h declares
 SIGNATURES = {
+    "seld_abi_sizes": (_I, [C.POINTER(C.c_int32), _I]),
     "seld_create": (_I, [C.POINTER(Arch), _I, _I, _I, _I, C.POINTER(_P)]),
     "seld_destroy": (None, [_P]),
     "seld_last_error": (C.c_char_p, [_P]),
@@ -179,6 +180,10 @@ def load():
             raise SeldLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    sizes = (C.c_int32 * 2)()
+    if lib.seld_abi_sizes(sizes, 2) != 2 or sizes[0] != C.sizeof(Arch) or sizes[1] != C.sizeof(LossCfg):
+        raise SeldLibraryError(f"{LIB_PATH}: struct layout mismatch (library seld_arch {sizes[0]} B, seld_loss_cfg {sizes[1]} B; "
+                               f"binding {C.sizeof(Arch)} / {C.sizeof(LossCfg)} B): rebuild the library or update seld_amd/_lib.py")
     _lib = lib
     return lib
 

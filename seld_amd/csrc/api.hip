@@ -254,6 +254,12 @@ int dp_sync_bn_fn(void* user, void* buf, int64_t count, int dtype, void* hip_str
 
 extern "C" {
 
+int seld_abi_sizes(int32_t* out, int n) {
+    const int32_t v[2] = {(int32_t)sizeof(seld_arch), (int32_t)sizeof(seld_loss_cfg)};
+    for (int i = 0; out && i < n && i < 2; ++i) out[i] = v[i];
+    return 2;
+}
+
 const char* seld_last_error(const seld_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ctx** out) {
