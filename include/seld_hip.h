@@ -31,6 +31,13 @@ extern "C" {
 #define SELD_ERR_NOMEM (-4)
 
 #define SELD_DTYPE_F32 0
+/* BASELINE.json configs[1]'s literal "bf16": every dense product of the step that has a single-product kernel (the three conv blocks'
+ * forward / input gradient / kernel gradient, the GRU input projections and their input and kernel gradients) takes ONE bf16 MFMA product
+ * with both operands rounded to nearest-even bf16 and fp32 accumulation, instead of the six products of the exact 3-way split that
+ * SELD_DTYPE_F32 uses; tensors, BatchNorm statistics, the GRU recurrence, losses and Adam stay fp32.  Not within north_star's 1e-4: the
+ * measured distance from the fp64 oracle is documented in DESIGN.md (outputs ~1e-3, gradients ~1e-2 of a variable's maximum).  The same
+ * switch at run time: seld_set_option(ctx, "bf16_single", 0 | 1).  (2: SELD_DTYPE_F64 = 1 names the SyncBN callback's buffer type.) */
+#define SELD_DTYPE_BF16 2
 
 #define SELD_DOA_MSE 0  /* tf.keras.losses.MSE function form (train.py:317-320): [B,S] rows, tape sums them */
 #define SELD_DOA_MMSE 1 /* losses.MMSE (losses.py:4-13) */

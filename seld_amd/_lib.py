@@ -18,6 +18,7 @@ SELD_OK = 0
 SELD_DOA_MSE, SELD_DOA_MMSE, SELD_DOA_MAE, SELD_DOA_MSLE = 0, 1, 2, 3
 SELD_DTYPE_F32 = 0
 SELD_DTYPE_F64 = 1
+SELD_DTYPE_BF16 = 2
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # seld_allreduce_fn
 MAX_LAYERS = 4
 ERR_NAMES = {-1: "SELD_ERR_INVALID", -2: "SELD_ERR_UNSUPPORTED", -3: "SELD_ERR_HIP", -4: "SELD_ERR_NOMEM"}

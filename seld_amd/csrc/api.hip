@@ -129,6 +129,7 @@ struct seld_ctx {
     int sync_world = 1;
     double* sync_buf = nullptr;                   // [128] (resnet50_block: [16][128]) sums handed to sync_fn
     bool sync_failed = false;                     // the all-reduce callback failed inside a helper: reported at the end of the pass
+    int bf16_single = 0;                          // SELD_DTYPE_BF16 / option "bf16_single": one bf16 MFMA product per fp32 product (common.h g_mfma_one)
     // data parallelism inside the library (seld_dp_*): one RCCL communicator, a communication stream, two events
     void* dp_comm = nullptr;                      // ncclComm_t
     int dp_rank = 0, dp_world = 1;
@@ -265,7 +266,7 @@ const char* seld_last_error(const seld_ctx* ctx) { return ctx ? ctx->err.c_str()
 int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ctx** out) {
     if (!a || !out) return fail(nullptr, SELD_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (dtype != SELD_DTYPE_F32) return fail(nullptr, SELD_ERR_UNSUPPORTED, "only SELD_DTYPE_F32 is built");
+    if (dtype != SELD_DTYPE_F32 && dtype != SELD_DTYPE_BF16) return fail(nullptr, SELD_ERR_UNSUPPORTED, "dtype must be SELD_DTYPE_F32 or SELD_DTYPE_BF16");
     if (B <= 0 || T <= 0) return fail(nullptr, SELD_ERR_INVALID, "B and T must be positive");
     if (a->n_conv < 1 || a->n_conv > SELD_MAX_LAYERS || a->n_gru < 1 || a->n_gru > SELD_MAX_LAYERS ||
         a->n_sed_dense < 0 || a->n_sed_dense > SELD_MAX_LAYERS || a->n_doa_dense < 0 || a->n_doa_dense > SELD_MAX_LAYERS)
@@ -311,6 +312,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
 
     seld_ctx* c = new seld_ctx();
     c->arch = *a; c->B = B; c->Bmax = B; c->T = T; c->S = S; c->device = device;
+    c->bf16_single = dtype == SELD_DTYPE_BF16;
 
     // ---- variable layout (Keras creation order; oracle/seldnet_oracle.py::variable_specs is the twin)
     int64_t off = 0, soff = 0;
@@ -604,6 +606,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
+    if (!strcmp(key, "bf16_single")) { c->bf16_single = value != 0; return SELD_OK; }     // = SELD_DTYPE_BF16 at seld_create
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
 int seld_sync(seld_ctx* c) {
@@ -737,6 +740,7 @@ static bool rn_c1_direct(const RnBlock& R) {
 }
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
+    g_mfma_one = c->bf16_single;      // process-wide kernel choice, read by the launchers this pass calls (common.h)
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
     const int rows = B * S;
@@ -744,6 +748,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     // weights (with the gradient orientations / flipped taps when a backward follows) and the folded head weights
     {
         GemmSplitJobs a; SplitWeightJobs b; HeadsLin h;
+        a.one = b.one = g_mfma_one;     // bf16 single-product mode: plane 0 = round-to-nearest bf16 (prep.h)
         int na = 0, nb = 0;
         bool fits = true;
         auto adda = [&](const float* w, unsigned short* d, int ld, int transb, int k, int nn) {
@@ -1189,6 +1194,7 @@ static void heads_lin_side(seld_ctx* c, int rows) {
 }
 
 static int backward_impl(seld_ctx* c, const float* x) {
+    g_mfma_one = c->bf16_single;
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S, rows = B * S;
     GruL& Glast = c->gru.back();

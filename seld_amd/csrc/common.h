@@ -50,13 +50,25 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ---- per-step weight pre-passes: job descriptors (kernel arguments by value) and the merged launch (prep.hip) ----------------
 #define GSB_MAX_JOBS 16
+// bf16 single-product mode (SELD_DTYPE_BF16 / option "bf16_single"): the split-bf16 kernels that implement it take ONE bf16 MFMA product per
+// fp32 product, operands rounded to nearest-even bf16 (fp32 accumulation), instead of the six products of the exact 3-way split.  Set by
+// api.hip from the ctx before it enqueues a pass (process-wide: contexts of different modes must not enqueue concurrently from different
+// host threads); kernels without a single-product form keep the exact six (more accurate, never less).
+extern int g_mfma_one;
+// round-to-nearest-even bf16 of an fp32 value, as its 16 high bits (finite inputs)
+__host__ __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 struct GemmSplitJobs {
     int njobs;
+    int one;       // 1: plane 0 = round-to-nearest bf16 (the other planes are not read)
     const float* src[GSB_MAX_JOBS];
     unsigned short* dst[GSB_MAX_JOBS];
     int ldb[GSB_MAX_JOBS], transb[GSB_MAX_JOBS], K[GSB_MAX_JOBS], N[GSB_MAX_JOBS];
 };
-struct SplitWeightJobs { const float* w[8]; unsigned short* dst[8]; int flip[8]; };
+struct SplitWeightJobs { const float* w[8]; unsigned short* dst[8]; int flip[8]; int one; };
 struct HeadsLin { const float *w1[2], *b1[2], *w2[2], *b2[2]; int n[2]; int K, Hd; };
 // one launch for all three kinds (any of them may be empty: na / nb = 0, weff = nullptr)
 int launch_weight_prep(hipStream_t st, const GemmSplitJobs& a, int na, const SplitWeightJobs& b, int nb, const HeadsLin& h, float* weff);

@@ -45,7 +45,8 @@ struct PoolSbGeom {
     static constexpr size_t SMEM = (size_t)(3 * PLANE + 3 * WPLANE) * 2 + 512 * sizeof(float);
 };
 
-template <int CIN, bool WRITE_AMAX>
+// ONE: bf16 single-product mode (common.h g_mfma_one): operands rounded to nearest bf16, plane 0 only, one MFMA per (k-step, row, half)
+template <int CIN, bool WRITE_AMAX, bool ONE>
 __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ gamma, float* __restrict__ zext,
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         const unsigned vv = __float_as_uint(r);
         const float s = r - __uint_as_float(vv & 0xffff0000u);
         unsigned short* o = Wl + co * KW + kk;
+        if (ONE) { o[0] = (unsigned short)bf16_rne_bits(v); continue; }
         o[0] = (unsigned short)(u >> 16);
         o[WPLANE] = (unsigned short)(vv >> 16);
         o[2 * WPLANE] = (unsigned short)(__float_as_uint(s) >> 16);
@@ -107,6 +109,14 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         const int idx = tid + 256 * u;                                                                  \
         unsigned short* d_ = patch + (((idx >> 6) * 66 + (idx & 63) + 1) * CP);                         \
         _Pragma("unroll") for (int q = 0; q < CP / 8; ++q) {                                            \
+            if (ONE) {                                                                                  \
+                const u32x4 rv_ = {bf16_rne_bits(CPSB_SLOT(u, 8 * q + 0)) | (bf16_rne_bits(CPSB_SLOT(u, 8 * q + 1)) << 16), \
+                                   bf16_rne_bits(CPSB_SLOT(u, 8 * q + 2)) | (bf16_rne_bits(CPSB_SLOT(u, 8 * q + 3)) << 16), \
+                                   bf16_rne_bits(CPSB_SLOT(u, 8 * q + 4)) | (bf16_rne_bits(CPSB_SLOT(u, 8 * q + 5)) << 16), \
+                                   bf16_rne_bits(CPSB_SLOT(u, 8 * q + 6)) | (bf16_rne_bits(CPSB_SLOT(u, 8 * q + 7)) << 16)}; \
+                *reinterpret_cast<u32x4*>(d_ + 8 * q) = rv_;                                            \
+                continue;                                                                               \
+            }                                                                                           \
             unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_, l0_, l1_, l2_, l3_;                        \
             cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 0), CPSB_SLOT(u, 8 * q + 1), h0_, m0_, l0_);          \
             cpsb_split3_pair(CPSB_SLOT(u, 8 * q + 2), CPSB_SLOT(u, 8 * q + 3), h1_, m1_, l1_);          \
@@ -137,11 +147,14 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
 #define CPSB_ROW(j_, ACCA_, ACCB_)                                                                      \
     {                                                                                                   \
         const unsigned short* ap_ = pa + (j_) * 66 * CP;                                                \
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), am = *reinterpret_cast<const bf16x8*>(ap_ + PLANE),   \
-                     al = *reinterpret_cast<const bf16x8*>(ap_ + 2 * PLANE);                            \
-        CPSB_MFMA(ah, bh0, ACCA_); CPSB_MFMA(ah, bh1, ACCB_); CPSB_MFMA(ah, bm0, ACCA_); CPSB_MFMA(ah, bm1, ACCB_);   \
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_);                                        \
+        CPSB_MFMA(ah, bh0, ACCA_); CPSB_MFMA(ah, bh1, ACCB_);                                           \
+        if (!ONE) {                                                                                     \
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap_ + PLANE), al = *reinterpret_cast<const bf16x8*>(ap_ + 2 * PLANE);   \
+        CPSB_MFMA(ah, bm0, ACCA_); CPSB_MFMA(ah, bm1, ACCB_);                                           \
         CPSB_MFMA(am, bh0, ACCA_); CPSB_MFMA(am, bh1, ACCB_); CPSB_MFMA(ah, bl0, ACCA_); CPSB_MFMA(ah, bl1, ACCB_);   \
         CPSB_MFMA(al, bh0, ACCA_); CPSB_MFMA(al, bh1, ACCB_); CPSB_MFMA(am, bm0, ACCA_); CPSB_MFMA(am, bm1, ACCB_);   \
+        }                                                                                               \
     }
     // window reduction of one accumulator register of one channel half: conv_pool.hip's CP_DRAIN without the z store
 #define CPSB_DRAIN(r_, c_, Y0, Y1, Y2, Y3, Y4)                                                          \
@@ -194,8 +207,11 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
             const unsigned short* pa = pbase + (kg ? CPSB_AOFF(s, 1) : CPSB_AOFF(s, 0));
             const unsigned short* wp = wbase + 16 * s;
             const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(wp), bh1 = *reinterpret_cast<const bf16x8*>(wp + 32 * KW);
-            const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(wp + WPLANE), bm1 = *reinterpret_cast<const bf16x8*>(wp + WPLANE + 32 * KW);
-            const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE), bl1 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE + 32 * KW);
+            bf16x8 bm0 = bh0, bm1 = bh1, bl0 = bh0, bl1 = bh1;       // (single-product mode: unused)
+            if (!ONE) {
+                bm0 = *reinterpret_cast<const bf16x8*>(wp + WPLANE); bm1 = *reinterpret_cast<const bf16x8*>(wp + WPLANE + 32 * KW);
+                bl0 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE); bl1 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE + 32 * KW);
+            }
             CPSB_ROW(0, accA0, accB0)
             CPSB_ROW(1, accA1, accB1)
             CPSB_ROW(2, accA2, accB2)
@@ -269,10 +285,17 @@ static int launch_cpsb(hipStream_t st, const float* x, const float* w, const flo
     const int grid = ntiles < CPSB_MAX_PERSISTENT ? ntiles : CPSB_MAX_PERSISTENT;
 #define CPSB_GO(A_)                                                                                                  \
     {                                                                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_sb_kernel<CIN, A_>),                   \
+        if (g_mfma_one) {                                                                                            \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_sb_kernel<CIN, A_, true>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);                               \
-        hipLaunchKernelGGL((conv_first_fwd_pool_sb_kernel<CIN, A_>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
+        hipLaunchKernelGGL((conv_first_fwd_pool_sb_kernel<CIN, A_, true>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
                            gamma, zext, amax, stat_partial, B, H);                                                   \
+        } else {                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_fwd_pool_sb_kernel<CIN, A_, false>),            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);                               \
+        hipLaunchKernelGGL((conv_first_fwd_pool_sb_kernel<CIN, A_, false>), dim3(grid), dim3(256), G::SMEM, st, x, w, bias, \
+                           gamma, zext, amax, stat_partial, B, H);                                                   \
+        }                                                                                                            \
     }
     if (amax) CPSB_GO(true)
     else CPSB_GO(false)

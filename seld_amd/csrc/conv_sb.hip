@@ -36,12 +36,18 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
     l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
 }
 
+// bf16 single-product mode: the two floats rounded to nearest-even bf16, packed like the planes above
+__device__ __forceinline__ unsigned rne_pair(float x0, float x1) { return bf16_rne_bits(x0) | (bf16_rne_bits(x1) << 16); }
+
+int g_mfma_one = 0;
+
 // w [9][in 64][out 64] fp32 -> planes [9][3][out 64][in 64] bf16 (transposed so a B fragment is 8 contiguous k)
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsp) {
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wsp, int one) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 9 * 4096) return;
     const int tap = idx >> 12, rem = idx & 4095, out = rem >> 6, in = rem & 63;
     const float x = w[tap * 4096 + in * 64 + out];
+    if (one) { wsp[(size_t)tap * 3 * 4096 + out * 64 + in] = (unsigned short)bf16_rne_bits(x); return; }
     const unsigned u = __float_as_uint(x);
     const float r = x - __uint_as_float(u & 0xffff0000u);
     const unsigned v = __float_as_uint(r);
@@ -59,13 +65,14 @@ __global__ __launch_bounds__(256) void split_weights_batch_kernel(SplitWeightJob
 int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, unsigned short* const* dst, const int* flip) {
     if (n <= 0 || n > 8) return -1;
     SplitWeightJobs j;
+    j.one = g_mfma_one;
     for (int i = 0; i < n; ++i) { j.w[i] = w[i]; j.dst[i] = dst[i]; j.flip[i] = flip[i]; }
     hipLaunchKernelGGL(split_weights_batch_kernel, dim3(9 * 4096 / 256, n), dim3(256), 0, st, j);
     return 0;
 }
 
 int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp) {
-    hipLaunchKernelGGL(split_weights_kernel, dim3(9 * 4096 / 256), dim3(256), 0, st, w, wsp);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(9 * 4096 / 256), dim3(256), 0, st, w, wsp, g_mfma_one);
     return 0;
 }
 
@@ -458,17 +465,20 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
 //  * a SECOND weight buffer: tap t + 1's pre-split weights are committed while tap t's MFMAs run (they were loaded to registers a
 //    tap earlier), so a tap needs one barrier instead of commit-between-two-barriers.
 // Region = (R + 2) rows x W columns, three bf16 planes, rows XOR-swizzled; weights [2][3][64][64].
-template <int WLOG2, int R, bool STATS>
+// ONE: bf16 single-product mode — operands rounded to nearest bf16, plane 0 only (region, weights, fragments), one MFMA per k-step and
+// column tile instead of six.
+template <int WLOG2, int R, bool STATS, bool ONE>
 __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
     float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
     constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
     constexpr int RR = R + 2, NPIX = RR * W, ZROW = NPIX;               // region pixels; index of the all-zero row
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
-    constexpr int NW4 = 3 * 64 * 8, NWF = (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
+    constexpr int NW4 = (ONE ? 1 : 3) * 64 * 8, NWF = ONE ? (512 + NT - 1) / NT : (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
     constexpr int LD = 64, PLANE = (NPIX + 1) * LD, WBUF = 3 * 64 * LD;
     static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
-    static_assert(NWF == 4 || NWF == 3, "weight staging is three or four named registers");
+    static_assert(ONE || NWF == 4 || NWF == 3, "weight staging is three or four named registers");
+    static_assert(!ONE || NWF <= 2, "single-product weight staging is one or two named registers");
     extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
     unsigned short* Rp = sb_smem;                          // [3][NPIX + 1][LD]
     unsigned short* Wp = sb_smem + 3 * PLANE;              // [2][3][64][LD]
@@ -509,13 +519,17 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                   \
         const int idx = tid + NT * u;                                                                   \
         if (idx < NREG4) {                                                                              \
+            unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
+            if (ONE) {                                                                                  \
+                *reinterpret_cast<uint2*>(d_) = make_uint2(rne_pair(rreg[u].x, rreg[u].y), rne_pair(rreg[u].z, rreg[u].w)); \
+            } else {                                                                                    \
             unsigned h0, m0, l0, h1, m1, l1;                                                            \
             split3_pair(rreg[u].x, rreg[u].y, h0, m0, l0);                                              \
             split3_pair(rreg[u].z, rreg[u].w, h1, m1, l1);                                              \
-            unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
             *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                         \
             *reinterpret_cast<uint2*>(d_ + PLANE) = make_uint2(m0, m1);                                 \
             *reinterpret_cast<uint2*>(d_ + 2 * PLANE) = make_uint2(l0, l1);                             \
+            }                                                                                           \
         }                                                                                               \
     }
 #define SBD_W_SRC(tap_, u_) \
@@ -523,8 +537,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
 #define SBD_ISSUE_W(tap_)                                                                               \
     {                                                                                                   \
         wreg0 = SBD_W_SRC(tap_, 0);                                                                     \
-        wreg1 = SBD_W_SRC(tap_, 1);                                                                     \
-        wreg2 = SBD_W_SRC(tap_, 2);                                                                     \
+        if (NWF > 1) wreg1 = SBD_W_SRC(tap_, 1);                                                        \
+        if (NWF > 2) wreg2 = SBD_W_SRC(tap_, 2);                                                        \
         if (NWF > 3) wreg3 = SBD_W_SRC(tap_, 3);                                                        \
     }
 #define SBD_W_DST(buf_, u_, v_)                                                                         \
@@ -538,8 +552,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
 #define SBD_COMMIT_W(buf_)                                                                              \
     {                                                                                                   \
         SBD_W_DST(buf_, 0, wreg0)                                                                       \
-        SBD_W_DST(buf_, 1, wreg1)                                                                       \
-        SBD_W_DST(buf_, 2, wreg2)                                                                       \
+        if (NWF > 1) SBD_W_DST(buf_, 1, wreg1)                                                          \
+        if (NWF > 2) SBD_W_DST(buf_, 2, wreg2)                                                          \
         if (NWF > 3) SBD_W_DST(buf_, 3, wreg3)                                                          \
     }
     int tile = blockIdx.x;
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
             for (int s = 0; s < 4; ++s) {
                 bf16x8 a[3], bb[3][2];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < (ONE ? 1 : 3); ++pl) {
                     const int ca = (2 * s + hi) ^ asw, cw = (2 * s + hi) ^ wsw;
                     a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * PLANE + 8 * ca);
                     bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 8 * cw);
@@ -587,11 +601,13 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
                 }
 #define SBD_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
                 SBD_MFMA(a[0], bb[0][0], acc[0]);  SBD_MFMA(a[0], bb[0][1], acc[1]);     // hi*hi
+                if (!ONE) {
                 SBD_MFMA(a[0], bb[1][0], accs[0]); SBD_MFMA(a[0], bb[1][1], accs[1]);    // hi*mid
                 SBD_MFMA(a[1], bb[0][0], acc[0]);  SBD_MFMA(a[1], bb[0][1], acc[1]);     // mid*hi
                 SBD_MFMA(a[0], bb[2][0], accs[0]); SBD_MFMA(a[0], bb[2][1], accs[1]);    // hi*lo
                 SBD_MFMA(a[2], bb[0][0], acc[0]);  SBD_MFMA(a[2], bb[0][1], acc[1]);     // lo*hi
                 SBD_MFMA(a[1], bb[1][0], accs[0]); SBD_MFMA(a[1], bb[1][1], accs[1]);    // mid*mid
+                }
 #undef SBD_MFMA
             }
             lds_barrier();      // tap + 1's weights are visible; everyone is done with this tap's buffer
@@ -664,13 +680,14 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
     const size_t smem = (size_t)(3 * (NPIX + 1) * 64 + 2 * 3 * 64 * 64) * sizeof(unsigned short);
     static_assert((size_t)(3 * ((R + 2) * (1 << WLOG2) + 1) * 64 + 2 * 3 * 64 * 64) * 2 <= 163840, "LDS");
     static_assert((size_t)NW * 128 * 4 <= (size_t)3 * (NPIX + 1) * 64 * 2, "the statistics buffer aliases the region");
-    if (stat_partial) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+#define SBD_GO(S_, O_)                                                                                                                    \
+    {                                                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);   \
     }
+    if (g_mfma_one) { if (stat_partial) SBD_GO(true, true) else SBD_GO(false, true) }
+    else { if (stat_partial) SBD_GO(true, false) else SBD_GO(false, false) }
+#undef SBD_GO
     if (n_partial) *n_partial = grid;
     return 0;
 }

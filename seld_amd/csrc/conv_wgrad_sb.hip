@@ -45,7 +45,10 @@ __device__ __forceinline__ bf16x8 wgsb_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int WLOG2>
+__device__ __forceinline__ unsigned wgsb_rne_pair(float x0, float x1) { return bf16_rne_bits(x0) | (bf16_rne_bits(x1) << 16); }
+
+// ONE: bf16 single-product mode (common.h g_mfma_one): operands rounded to nearest bf16, plane 0 only, one MFMA per (k-step, tap)
+template <int WLOG2, bool ONE>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                  float* __restrict__ slab, int B, int H) {
     constexpr int W = 1 << WLOG2, R = WGSB_PXC / W, RW = W + 2, RR = R + 2;
@@ -84,13 +87,18 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
     // registers) above the MFMAs and spills the accumulators.
 #define WGSB_LDA(s_, tap_, H_, M_, L_)                                                                                \
     H_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 0), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 0));       \
+    if (!ONE) {                                                                                                       \
     M_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 1), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 1));       \
-    L_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 2), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 2));
+    L_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 2), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 2));       \
+    }
 #define WGSB_LDB(s_, H_, M_, L_)                                                                                      \
     {                                                                                                                 \
         const char* bp_ = dl + (16 * (s_)) * 128 + offB;                                                              \
-        H_ = wgsb_frag(bp_, bp_ + 4 * 128); M_ = wgsb_frag(bp_ + DPL, bp_ + DPL + 4 * 128);                           \
+        H_ = wgsb_frag(bp_, bp_ + 4 * 128);                                                                           \
+        if (!ONE) {                                                                                                   \
+        M_ = wgsb_frag(bp_ + DPL, bp_ + DPL + 4 * 128);                                                               \
         L_ = wgsb_frag(bp_ + 2 * DPL, bp_ + 2 * DPL + 4 * 128);                                                       \
+        }                                                                                                             \
     }
 #define WGSB_TAP(s_, tap_, ACC_)                                                                                      \
     {                                                                                                                 \
@@ -100,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
         if (!last_) { WGSB_LDA(ns_, nt_, nh, nm, nl) }                                                                \
         if (!last_ && (tap_) == 8) WGSB_LDB(ns_, nbh, nbm, nbl)                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        WGSB_MFMA(al, bh, ACC_); WGSB_MFMA(am, bh, ACC_); WGSB_MFMA(am, bm, ACC_);                                    \
-        WGSB_MFMA(ah, bh, ACC_); WGSB_MFMA(ah, bm, ACC_); WGSB_MFMA(ah, bl, ACC_);                                    \
+        if (!ONE) { WGSB_MFMA(al, bh, ACC_); WGSB_MFMA(am, bh, ACC_); WGSB_MFMA(am, bm, ACC_); }                      \
+        WGSB_MFMA(ah, bh, ACC_);                                                                                      \
+        if (!ONE) { WGSB_MFMA(ah, bm, ACC_); WGSB_MFMA(ah, bl, ACC_); }                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         ah = nh; am = nm; al = nl;                                                                                    \
         if ((tap_) == 8) { bh = nbh; bm = nbm; bl = nbl; }                                                            \
@@ -139,13 +148,17 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
     }
 #define WGSB_PUT(v_, base_, PL_, P_, g_)                                                                              \
     {                                                                                                                 \
+        char* d = (base_) + (P_) * 128 + ((8 * (g_)) ^ (64 * (((P_) >> 1) & 1)));                                     \
+        if (ONE) {                                                                                                    \
+            *reinterpret_cast<uint2*>(d) = make_uint2(wgsb_rne_pair(v_.x, v_.y), wgsb_rne_pair(v_.z, v_.w));          \
+        } else {                                                                                                      \
         unsigned h0, m0, l0, h1, m1, l1;                                                                              \
         wgsb_split3_pair(v_.x, v_.y, h0, m0, l0);                                                                     \
         wgsb_split3_pair(v_.z, v_.w, h1, m1, l1);                                                                     \
-        char* d = (base_) + (P_) * 128 + ((8 * (g_)) ^ (64 * (((P_) >> 1) & 1)));                                     \
         *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);                                                            \
         *reinterpret_cast<uint2*>(d + (PL_)) = make_uint2(m0, m1);                                                    \
         *reinterpret_cast<uint2*>(d + 2 * (PL_)) = make_uint2(l0, l1);                                                \
+        }                                                                                                             \
     }
 #define WGSB_COMMIT()                                                                                                 \
     {                                                                                                                 \
@@ -216,9 +229,15 @@ int launch_conv64_wgrad_sb(hipStream_t st, const float* x, const float* dz, floa
     const size_t smem = (size_t)3 * WGSB_HALO * 128 + (size_t)3 * WGSB_PXC * 128 + 16 * 64 * sizeof(float);
 #define WGSB_GO(L)                                                                                            \
     {                                                                                                         \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L>),                         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                           \
-        hipLaunchKernelGGL(conv64_wgrad_sb_kernel<L>, dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);    \
+        if (g_mfma_one) {                                                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L, true>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
+            hipLaunchKernelGGL((conv64_wgrad_sb_kernel<L, true>), dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);  \
+        } else {                                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L, false>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
+            hipLaunchKernelGGL((conv64_wgrad_sb_kernel<L, false>), dim3(grid), dim3(256), smem, st, x, dz, slab, B, H); \
+        }                                                                                                     \
     }
     if (W == 16) WGSB_GO(4) else if (W == 8) WGSB_GO(3) else WGSB_GO(2)
 #undef WGSB_GO

@@ -33,6 +33,8 @@ __device__ __forceinline__ void gsb_split3_pair(float x0, float x1, unsigned& h,
     l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
 }
 
+__device__ __forceinline__ unsigned gsb_rne_pair(float x0, float x1) { return bf16_rne_bits(x0) | (bf16_rne_bits(x1) << 16); }
+
 // ---- weight pre-pass ---------------------------------------------------------------------------
 // B fp32 ([K,N] if !transb, [N,K] if transb) -> planes [chunk c = k/32][plane][n][piece'][8] bf16 with
 // piece' = piece ^ ((n >> 2) & 3): the image of one (chunk, plane, 128-column group) is the 8 KB the GEMM copies
@@ -51,6 +53,7 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
     if (njobs <= 0 || njobs > GSB_MAX_JOBS) return -1;
     GemmSplitJobs j;
     j.njobs = njobs;
+    j.one = g_mfma_one;
     for (int i = 0; i < njobs; ++i) {
         if (K[i] % GSB_KC) return -2;
         j.src[i] = src[i]; j.dst[i] = dst[i]; j.ldb[i] = ldb[i]; j.transb[i] = transb[i]; j.K[i] = K[i]; j.N[i] = N[i];
@@ -63,7 +66,9 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
 // mode 0: C0 = act(A0 B0 + bias0).
 // mode 1 (two products sharing A): column groups >= N/128 compute C1 = act(A0 B1 + bias1).
 // mode 2 (one product over a concatenated K axis): C0 = act(A0 B0 + A1 B1 + bias0).
-template <int NG>   // 4: K = 128, one product (or two sharing A): every A row of the tile is requested up front; 0: runtime loop
+// ONE: bf16 single-product mode (common.h g_mfma_one): A rounded to nearest bf16 in registers, B's plane 0 holds the rounded weights
+// (gemm_split_b with jobs.one); one MFMA per k-step and column tile.  The B staging still moves all three planes (untouched code path).
+template <int NG, bool ONE = false>   // NG 4: K = 128, one product (or two sharing A): every A row of the tile is requested up front; 0: runtime loop
 __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
@@ -116,6 +121,14 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
     const int boff0 = li * GSB_KC + (((2 * kg) ^ swz) << 3), boff1 = li * GSB_KC + (((2 * kg + 1) ^ swz) << 3);
 #define GSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
 #define GSB_STEP(x0_, x1_, boff_)                                                                     \
+    if (ONE) {                                                                                        \
+        const u32x4 h_ = {gsb_rne_pair(x0_.x, x0_.y), gsb_rne_pair(x0_.z, x0_.w), gsb_rne_pair(x1_.x, x1_.y), gsb_rne_pair(x1_.z, x1_.w)}; \
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h_);                                             \
+        const unsigned short* bb_ = bl + boff_;                                                       \
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb_), bh1 = *reinterpret_cast<const bf16x8*>(bb_ + 32 * GSB_KC), \
+                     bh2 = *reinterpret_cast<const bf16x8*>(bb_ + 64 * GSB_KC), bh3 = *reinterpret_cast<const bf16x8*>(bb_ + 96 * GSB_KC); \
+        GSB_MFMA(ah, bh0, acc0); GSB_MFMA(ah, bh1, acc1); GSB_MFMA(ah, bh2, acc2); GSB_MFMA(ah, bh3, acc3);   \
+    } else                                                                                            \
     {                                                                                                 \
         unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_, l0_, l1_, l2_, l3_;                          \
         gsb_split3_pair(x0_.x, x0_.y, h0_, m0_, l0_);                                                 \
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
 // M = 19200): K = 2 x 384, N = 128: 37 us against 52 us; K = 128, N = 2 x 384: 38 us against 35 us — the launcher
 // picks by the number of column groups.  (Prefetching three chunks ahead and placing the next chunk's split / LDS stores
 // in the MFMA gaps with sched_group_barrier were both measured slower than this plain form.)
-template <int NG, bool CONV = false>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
+template <int NG, bool CONV = false, bool ONE = false>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
 __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
@@ -277,13 +290,17 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     }
 #define G16_COMMIT(buf_)                                                                                        \
     {                                                                                                           \
+        unsigned short* ad_ = Al[buf_] + a_dst;                                                                 \
+        if (ONE) {                                                                                              \
+            *reinterpret_cast<uint2*>(ad_) = make_uint2(gsb_rne_pair(na.x, na.y), gsb_rne_pair(na.z, na.w));    \
+        } else {                                                                                                \
         unsigned h0_, m0_, l0_, h1_, m1_, l1_;                                                                  \
         gsb_split3_pair(na.x, na.y, h0_, m0_, l0_);                                                             \
         gsb_split3_pair(na.z, na.w, h1_, m1_, l1_);                                                             \
-        unsigned short* ad_ = Al[buf_] + a_dst;                                                                 \
         *reinterpret_cast<uint2*>(ad_) = make_uint2(h0_, h1_);                                                  \
         *reinterpret_cast<uint2*>(ad_ + 128 * GSB_KC) = make_uint2(m0_, m1_);                                   \
         *reinterpret_cast<uint2*>(ad_ + 2 * 128 * GSB_KC) = make_uint2(l0_, l1_);                               \
+        }                                                                                                       \
         u32x4* bd_ = reinterpret_cast<u32x4*>(Bl[buf_]);                                                        \
         bd_[tid] = nb0;                                                                                         \
         if (tid < 512) bd_[1024 + tid] = nb1;                                                                   \
@@ -300,12 +317,16 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     {                                                                                                           \
         const unsigned short* ap_ = al + aofs + foff_;                                                          \
         const unsigned short* bp_ = bl + bofs + foff_;                                                          \
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), am = *reinterpret_cast<const bf16x8*>(ap_ + 128 * GSB_KC),   \
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), bh = *reinterpret_cast<const bf16x8*>(bp_);    \
+        GSB_MFMA(ah, bh, acc0);                                                                                 \
+        if (!ONE) {                                                                                             \
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap_ + 128 * GSB_KC),                                 \
                      al_ = *reinterpret_cast<const bf16x8*>(ap_ + 2 * 128 * GSB_KC);                            \
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp_), bm = *reinterpret_cast<const bf16x8*>(bp_ + GSB_BN * GSB_KC), \
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp_ + GSB_BN * GSB_KC),                              \
                      bl_ = *reinterpret_cast<const bf16x8*>(bp_ + 2 * GSB_BN * GSB_KC);                         \
-        GSB_MFMA(ah, bh, acc0); GSB_MFMA(ah, bm, acc1); GSB_MFMA(am, bh, acc0);                                 \
+        GSB_MFMA(ah, bm, acc1); GSB_MFMA(am, bh, acc0);                                                         \
         GSB_MFMA(ah, bl_, acc1); GSB_MFMA(al_, bh, acc0); GSB_MFMA(am, bm, acc1);                               \
+        }                                                                                                       \
     }
     if constexpr (NG == 0) {
     for (int g = 0; g < ng; ++g) {
@@ -404,14 +425,21 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     // (an implicit convolution always takes the 16-wave form: its per-chunk address work is shared by 4 column waves there — K = 9 x 256,
     // N = 256: 198 us against 264 for the 4-wave form)
     if (cvs ? false : (g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide) {
-#define GSB_GO(NG_) hipLaunchKernelGGL(gemm_sb_kernel<NG_>, grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
-                                       mode, g_gsb_dbg & 3, accum)
-        if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4);
-        else GSB_GO(0);
+#define GSB_GO(NG_) { if (g_mfma_one) hipLaunchKernelGGL((gemm_sb_kernel<NG_, true>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
+                                       mode, g_gsb_dbg & 3, accum);                                                                                            \
+                      else hipLaunchKernelGGL((gemm_sb_kernel<NG_, false>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
+                                       mode, g_gsb_dbg & 3, accum); }
+        if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4)
+        else GSB_GO(0)
 #undef GSB_GO
     } else {
         const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
 #define G16_GO(NG_, CV_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
+#define G16_GO1(NG_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
+        // bf16 single-product mode: instantiated for the shapes of the headline model (the GRU input gradients, K = 128, and the generic loop);
+        // the implicit-convolution and resnet50 shapes keep the exact products
+        if (g_mfma_one && !cvs && !(g_gsb_dbg & 16) && (ng == 24 || ng == 4)) { if (ng == 24) G16_GO1(24); else G16_GO1(4); return 0; }
+        if (g_mfma_one && !cvs && ng != 36 && ng != 16 && ng != 12 && ng != 8) { G16_GO1(0); return 0; }
         if (cvs) { if (ng == 36) G16_GO(36, true); else if (ng == 72) G16_GO(72, true); else G16_GO(0, true); }      // implicit 3x3: K = 9 x 128 / 9 x 256 unrolled
         else if (g_gsb_dbg & 16) G16_GO(0, false);
         else if (ng == 36) G16_GO(36, false);       // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
@@ -422,6 +450,7 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
         else if (ng == 4) G16_GO(4, false);
         else G16_GO(0, false);
 #undef G16_GO
+#undef G16_GO1
     }
     return 0;
 }

@@ -40,7 +40,8 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 // cvs = log2 C > 0 (tile mode only): A is an NHWC image [M pixels][C] and the product's A matrix its virtual im2col [M][9 C] (3 x 3
 // 'same', zeros outside the H x W image): tile y covers columns 128 y .. of it, i.e. ONE tap (C % 128 == 0) at channel offset
 // (128 y) % C — the row of the image is the pixel shifted by the tap, masked at the image border.
-template <bool CONV>      // a template parameter: the GRU's instantiation (the headline step's side stream) must not carry the convolution's index work
+// ONE: bf16 single-product mode (common.h g_mfma_one): both operands rounded to nearest bf16, plane 0 only, one MFMA per tile pair
+template <bool CONV, bool ONE = false>      // a template parameter: the GRU's instantiation (the headline step's side stream) must not carry the convolution's index work
 __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
                                                             int S, int want_bias, long long tile_stride, int cvs, int cvH, int cvW) {
     const int job = tile_stride ? 0 : blockIdx.y;
@@ -91,13 +92,17 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
     }
 #define TNSB_PUT(v_, img_, m_)                                                                               \
     {                                                                                                        \
+        char* d = (img_) + (m_) * 256 + ((((c4 >> 3) ^ ((m_) & 3)) << 6) | (8 * (c4 & 7)));                  \
+        if (ONE) {                                                                                           \
+            *reinterpret_cast<uint2*>(d) = make_uint2(bf16_rne_bits(v_.x) | (bf16_rne_bits(v_.y) << 16), bf16_rne_bits(v_.z) | (bf16_rne_bits(v_.w) << 16)); \
+        } else {                                                                                             \
         unsigned h0, m0, l0, h1, m1, l1;                                                                     \
         tnsb_split3_pair(v_.x, v_.y, h0, m0, l0);                                                            \
         tnsb_split3_pair(v_.z, v_.w, h1, m1, l1);                                                            \
-        char* d = (img_) + (m_) * 256 + ((((c4 >> 3) ^ ((m_) & 3)) << 6) | (8 * (c4 & 7)));                  \
         *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);                                                   \
         *reinterpret_cast<uint2*>(d + TNSB_PL) = make_uint2(m0, m1);                                         \
         *reinterpret_cast<uint2*>(d + 2 * TNSB_PL) = make_uint2(l0, l1);                                     \
+        }                                                                                                    \
     }
 #define TNSB_COMMIT()                                                                                        \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                          \
@@ -111,6 +116,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
     TNSB_MFMA(AL, BH, ACC_); TNSB_MFMA(AM, BH, ACC_); TNSB_MFMA(AM, BM_, ACC_);                              \
     TNSB_MFMA(AH, BH, ACC_); TNSB_MFMA(AH, BM_, ACC_); TNSB_MFMA(AH, BL, ACC_);
 #define TNSB_KSTEP(s_)                                                                                       \
+    if (ONE) {                                                                                               \
+        constexpr int o_ = (16 * (s_)) * 256;                                                                \
+        const bf16x8 a0h = tnsb_frag(Al + o_ + oa0, Al + o_ + oa0 + 4 * 256), a1h = tnsb_frag(Al + o_ + oa1, Al + o_ + oa1 + 4 * 256); \
+        const bf16x8 b0h = tnsb_frag(Bl + o_ + ob0, Bl + o_ + ob0 + 4 * 256), b1h = tnsb_frag(Bl + o_ + ob1, Bl + o_ + ob1 + 4 * 256); \
+        TNSB_MFMA(a0h, b0h, c00); TNSB_MFMA(a0h, b1h, c01); TNSB_MFMA(a1h, b0h, c10); TNSB_MFMA(a1h, b1h, c11);                        \
+    } else                                                                                                   \
     {                                                                                                        \
         constexpr int o_ = (16 * (s_)) * 256;                                                                \
         const bf16x8 a0h = tnsb_frag(Al + o_ + oa0, Al + o_ + oa0 + 4 * 256), a0m = tnsb_frag(Al + TNSB_PL + o_ + oa0, Al + TNSB_PL + o_ + oa0 + 4 * 256), \
@@ -178,7 +189,8 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    hipLaunchKernelGGL(gemm_tn_sb_kernel<false>, dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    if (g_mfma_one) hipLaunchKernelGGL((gemm_tn_sb_kernel<false, true>), dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    else hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false>), dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
     *nslab = splits;
     return 0;
 }

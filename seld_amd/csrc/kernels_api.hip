@@ -38,6 +38,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!strcmp(key, "conv1_split_bf16")) { g_conv1_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
+    if (!strcmp(key, "bf16_single")) { g_mfma_one = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { g_rn_split_bf16 = value != 0; return SELD_OK; }
     return SELD_ERR_INVALID;

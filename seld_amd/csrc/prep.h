@@ -26,6 +26,7 @@ __device__ __forceinline__ void gemm_split_b_body(const GemmSplitJobs& jobs, int
         const float s = r - __uint_as_float(v & 0xffff0000u);
         const int c = k >> 5, kk = k & 31, piece = (kk >> 3) ^ ((n >> 2) & 3);
         unsigned short* o = dst + ((size_t)c * 3 * N + n) * 32 + piece * 8 + (kk & 7);
+        if (jobs.one) { o[0] = (unsigned short)bf16_rne_bits(x); continue; }
         o[0] = (unsigned short)(u >> 16);
         o[(size_t)N * 32] = (unsigned short)(v >> 16);
         o[(size_t)2 * N * 32] = (unsigned short)(__float_as_uint(s) >> 16);
@@ -45,6 +46,7 @@ __device__ __forceinline__ void split_weights_body(const SplitWeightJobs& jobs, 
     const unsigned v = __float_as_uint(r);
     const float s = r - __uint_as_float(v & 0xffff0000u);
     unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;
+    if (jobs.one) { o[0] = (unsigned short)bf16_rne_bits(x); return; }
     o[0] = (unsigned short)(u >> 16);
     o[4096] = (unsigned short)(v >> 16);
     o[2 * 4096] = (unsigned short)(__float_as_uint(s) >> 16);

@@ -98,7 +98,7 @@ class SeldNet:
     """The object `models.seldnet` returns: `model(x, training)`, `trainable_variables`,
     `get_weights/set_weights`, `summary()`, `save_weights/load_weights`."""
 
-    def __init__(self, input_shape: Sequence[int], model_config: dict, device: int | None = None):
+    def __init__(self, input_shape: Sequence[int], model_config: dict, device: int | None = None, dtype: str = "float32"):
         if len(input_shape) != 4 or input_shape[0] is None:
             raise ValueError("input_shape must be [B, T, F, C] with a concrete batch size")
         B, T, F, Cc = (int(v) for v in input_shape)
@@ -110,7 +110,12 @@ class SeldNet:
         self.input_shape = (B, T, F, Cc)
         self.model_config = model_config
         ctx = C.c_void_p()
-        _lib.check(self.lib.seld_create(C.byref(self.arch), B, T, _lib.SELD_DTYPE_F32, self.device, C.byref(ctx)))
+        if dtype not in ("float32", "bfloat16"):
+            raise ValueError("dtype must be 'float32' (fp32-equivalent products, the default) or 'bfloat16' (one bf16 MFMA product per fp32 "
+                             "product: BASELINE configs[1]'s \"bf16\", include/seld_hip.h SELD_DTYPE_BF16)")
+        self.dtype = dtype
+        _lib.check(self.lib.seld_create(C.byref(self.arch), B, T, _lib.SELD_DTYPE_BF16 if dtype == "bfloat16" else _lib.SELD_DTYPE_F32,
+                                        self.device, C.byref(ctx)))
         self.ctx = ctx
         self.n_params = int(self.lib.seld_param_count(ctx))
         self.n_state = int(self.lib.seld_state_count(ctx))
@@ -230,9 +235,9 @@ class SeldNet:
             pass
 
 
-def seldnet(input_shape, model_config, device=None) -> SeldNet:
-    """reference models.seldnet (models.py:18-32)."""
-    return SeldNet(input_shape, model_config, device)
+def seldnet(input_shape, model_config, device=None, dtype: str = "float32") -> SeldNet:
+    """reference models.seldnet (models.py:18-32).  `dtype="bfloat16"`: bf16 single-product mode (SELD_DTYPE_BF16)."""
+    return SeldNet(input_shape, model_config, device, dtype)
 
 
 # ---------------------------------------------------------------------- Keras initialisers

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import check, dev, ptr
+from helpers import check, dev, ptr, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -622,3 +622,41 @@ def test_rn_bn_fwd_bwd(seld_lib, npix, C, relu, with_res, with_mask):
     check("rn_bn dz", dz.cpu().numpy(), zt.grad.numpy())
     check("rn_bn dgamma", dg.cpu().numpy(), gt.grad.numpy())
     check("rn_bn dbeta", db.cpu().numpy(), bt.grad.numpy())
+
+
+def _bf16(a):
+    """round-to-nearest-even bf16 of an fp32 array, back as float64 (what the single-product kernels feed the matrix cores)"""
+    return torch.as_tensor(np.asarray(a, np.float32)).bfloat16().double().numpy()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 16), (3, 10, 4), (1, 37, 16), (2, 45, 8)])
+def test_bf16_single_product_conv64(seld_lib, B, H, W):
+    """bf16 single-product mode (BASELINE configs[1] "bf16": seld_k_set_option("bf16_single", 1) / SELD_DTYPE_BF16): the 64 -> 64
+    convolution kernels take ONE v_mfma_f32_32x32x16_bf16 product per fp32 product with both operands rounded to nearest-even bf16 and
+    fp32 accumulation.  Exact statement of that arithmetic = the fp64 convolution of the bf16-ROUNDED operands: the kernel must agree
+    with it to fp32 accumulation error (2e-6), forward, input gradient and kernel gradient; against the unrounded fp64 result the
+    mode's own error (operand rounding, 2^-9 relative each) is what is printed."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, H, W, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, 64)) / 24).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    dz = rng.standard_normal((B, H, W, 64)).astype(np.float32)
+    assert seld_lib.seld_k_set_option(b"bf16_single", 1) == 0
+    try:
+        z = torch.full((B, H, W, 64), float("nan"), device="cuda")
+        st = torch.zeros(128, device="cuda")
+        assert seld_lib.seld_k_conv3x3_fwd(ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(z), ptr(st), B, H, W, 64, 64) == 0
+        ref_r = _conv_ref(_bf16(x), _bf16(w), b)
+        check(f"bf16-single conv_fwd {B,H,W} vs fp64 of rounded operands", z.cpu().numpy(), ref_r, tol=2e-6)
+        print(f"[bf16] conv_fwd {B,H,W}: error of the mode against the unrounded fp64 result {rel_err(z.cpu().numpy(), _conv_ref(x, w, b)):.2e}")
+        check("bf16-single conv_fwd sum(z)", st.cpu().numpy()[:64], ref_r.sum(axis=(0, 1, 2)), tol=1e-4 * np.sqrt(ref_r.size / 64))
+        # input gradient = the same kernel on dz with flipped weights
+        xg = torch.zeros((B, H, W, 64), dtype=torch.float64, requires_grad=True)
+        wt = torch.as_tensor(_bf16(w)).permute(3, 2, 0, 1)
+        y = F.conv2d(xg.permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
+        (g,) = torch.autograd.grad(y, xg, torch.as_tensor(_bf16(dz)))
+        dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
+        assert seld_lib.seld_k_conv3x3_dgrad(ptr(dev(dz)), ptr(dev(w)), ptr(dx), B, H, W, 64, 64) == 0
+        check(f"bf16-single conv_dgrad {B,H,W} vs fp64 of rounded operands", dx.cpu().numpy(), g.numpy(), tol=2e-6)
+    finally:
+        seld_lib.seld_k_set_option(b"bf16_single", 0)
