@@ -270,7 +270,7 @@ def read_timers(model):
     return kernels
 
 
-def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=False):
+def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=False, bf16=False):
     """Per timed kernel group: achieved rate = algorithmic work / HIP-event time, against the gfx950 peak of its bound.  `per_step_groups`:
     the group's work table is per STEP (the block models' level-3 scopes wrap launches of very different sizes), else per launch."""
     per_kernel, breakdown = {}, {}
@@ -287,6 +287,8 @@ def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_
             ach, unit = amount / per_unit_s / 1e12, "TFLOP/s"
             peak = round(PEAK_SPLIT_BF16_TFLOPS, 1) if split else PEAK_F32_MFMA_TFLOPS
             path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
+            if bf16 and split:
+                peak, path = PEAK_BF16_MFMA_TFLOPS, "one bf16 MFMA product per product (operands rounded to nearest bf16), dense bf16 peak"
         else:
             ach, peak, unit = amount / per_unit_s / 1e9, PEAK_HBM_GBPS, "GB/s"
         extra = {}
@@ -313,7 +315,7 @@ def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_
 
 
 def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(), timing_level=1, with_features=False, profile_level=0,
-                 allreduce_ablation=False):
+                 allreduce_ablation=False, dtype="float32"):
     """One BASELINE workload on this rank's GPU: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize
     (max over ranks), with the library's HIP-event timers at `timing_level` inside the timed region.  `profile_level` > timing_level:
     a SECOND pass of `steps` steps with the finer per-kernel scopes (hundreds of event pairs per step for the block models: they cost a few
@@ -323,7 +325,7 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
     from seld_amd.synthetic import synthetic_batch      # oracle/ is imported by the cpu_baseline leg only
     dist = torch.distributed
     global N_PARAMS
-    model = models.seldnet((B, T, 64, 7), model_config_of(name), device=local)
+    model = models.seldnet((B, T, 64, 7), model_config_of(name), device=local, dtype=dtype)
     N_PARAMS = model.n_params
     for kv in opts:
         key, _, val = kv.partition("=")
@@ -414,11 +416,12 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
     return res
 
 
-def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_mhz, with_features):
-    per_kernel, breakdown = rooflines(res["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz)
+def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_mhz, with_features, dtype="float32"):
+    bf16 = dtype == "bfloat16"
+    per_kernel, breakdown = rooflines(res["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz, bf16=bf16)
     fine = None
     if res["profile"]:
-        fine, fine_breakdown = rooflines(res["profile"]["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=True)
+        fine, fine_breakdown = rooflines(res["profile"]["kernels"], B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_groups=True, bf16=bf16)
         # the dominant kernel is chosen among the FINE groups (a level-1 group such as rn_stages_bwd lumps products, BatchNorm passes and
         # waits for the side stream); groups that enclose other groups are not candidates
         cand = {k: v for k, v in fine.items() if k not in ("rn_stages_fwd", "rn_stages_bwd")}
@@ -431,8 +434,10 @@ def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_
         "metric": METRIC, "value": round(world * B * steps / res["elapsed"], 2), "unit": "clips/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(res["elapsed"] / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload_text(name, B, T, with_features), "global_batch": world * B, "parallelism": f"dp{world}",
+        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": workload_text(name, B, T, with_features) + (" — bf16 single-product mode (SELD_DTYPE_BF16): conv / GEMM operands rounded to "
+                                                                             "bf16, fp32 accumulation and tensors; NOT within 1e-4 (DESIGN.md section 3c)" if bf16 else ""),
+                   "global_batch": world * B, "parallelism": f"dp{world}",
                    "doa_loss": "MSE", "loss_weight": "1,1000"},
         "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
     }
@@ -530,12 +535,15 @@ def main():
             # bracketed timed steps and rooflines (configs[4] = the per-GPU share, 16 clips, of the batch-128 DP-8 job, features in the step)
             out["configs"] = {}
             sub_steps = max(10, args.steps // 2)
-            for sub, sb, feat, lvl in (("xception_gru", 32, False, 2), ("resnet50_gru", 16, True, 3)):
+            # configs[1]'s literal wording ("seldnet.json bf16 batch=32"): the same workload in bf16 single-product mode, as a SECOND record —
+            # the headline above stays the fp32-equivalent mode that meets the 1e-4 parity bar
+            for key, sub, sb, feat, lvl, dt in (("seldnet_bf16", "seldnet", 32, False, 2, "bfloat16"), ("xception_gru", "xception_gru", 32, False, 2, "float32"),
+                                                ("resnet50_gru", "resnet50_gru", 16, True, 3, "float32")):
                 torch.cuda.empty_cache()
                 r = run_workload(sub, sb, T, sub_steps, args.warmup, world, rank, local, dev, timing_level=1, with_features=feat,
-                                 profile_level=0 if args.no_kernel_timing else lvl)
-                out["configs"][sub] = record(sub, sb, T, sub_steps, args.warmup, world, r, (), traffic_tab, valu_clock_mhz, feat)
-                out["configs"][sub].pop("metric")
+                                 profile_level=0 if args.no_kernel_timing else lvl, dtype=dt)
+                out["configs"][key] = record(sub, sb, T, sub_steps, args.warmup, world, r, (), traffic_tab, valu_clock_mhz, feat, dtype=dt)
+                out["configs"][key].pop("metric")
                 r["model"] = None
                 del r
         if world == 1 and not args.no_cpu_baseline:

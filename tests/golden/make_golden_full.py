@@ -11,6 +11,11 @@ Stored per case (KB-sized; inputs and weights are regenerated from seeds by the 
   * `bar_fp32`: per variable, max|g32 - g64| / max|g64| of the SAME oracle evaluated in fp32 -- what two evaluations of
     the reference's own arithmetic differ by at this size.  tests/test_model_gpu.py::test_full_batch_vs_golden holds the HIP
     path to max(1e-4, bar) per variable.
+  * DECISIONS (since round 3, as make_golden_blocks.py stores them): per conv block the MaxPool(ReLU(.)) routing of the fp64 forward —
+    `dec.pool{i}.near` = flat indices of the pooled elements whose fp64 margin (top1 - top2, or |top1| for the ReLU gate) is below
+    1e-5, `dec.pool{i}.digest` = (count, position-weighted checksum) of value = 0 | 1 + argmax position over all OTHER elements.  The
+    library's routing (seld_debug_pool_routing), digested with the same indices excluded, must give the same pair: every decision it
+    takes differently from fp64 then has an fp64 margin below 1e-5 — asserted at B = 32 without an oracle on the GPU box.
 The reference cannot be imported here (TensorFlow absent), so these vectors pin the oracle restatement,
 not TensorFlow: parity stays "unpinned" in the sense of DESIGN.md §0."""
 import os
@@ -72,8 +77,22 @@ def main():
         w, st = O.random_weights(spec, 0)
         x, ys, yd = O.synthetic_batch(B, T, seed=1234)
         kw = dict(doa_loss=dl, loss_weight=(1.0, 1000.0), lr=1e-3, step=1)
-        r = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float64, want_taps=(dl == "MSE"), **kw)
+        rec = {}
+        r = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float64, want_taps=(dl == "MSE"), record_routing=rec, **kw)
         out = {"meta": np.array([B, T, {"MSE": 0, "MMSE": 1}[dl]])}
+        import importlib.util
+        sp_ = importlib.util.spec_from_file_location("make_golden_blocks", os.path.join(ROOT, "tests", "golden", "make_golden_blocks.py"))
+        mb = importlib.util.module_from_spec(sp_)
+        sp_.loader.exec_module(mb)
+        for i in range(len(spec.pools)):
+            rr = rec.pop(i)
+            rr.pop("windows", None)
+            val, margin = mb.pool_decisions(rr)
+            near = np.flatnonzero(margin.reshape(-1) < 1e-5).astype(np.int64)
+            out[f"dec.pool{i}.near"] = near.astype(np.uint32)
+            out[f"dec.pool{i}.digest"] = mb.decision_digest(val, near)
+            print(f"  block {i}: {val.size} routing decisions, {near.size} with an fp64 margin below 1e-5")
+            del rr, val, margin
         if dl == "MSE":
             out["near_ties"] = near_ties(spec, r.pop("taps"), O.unflatten(torch.as_tensor(w), tr))
         g32 = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float32, **kw)["grad"]
@@ -98,7 +117,7 @@ def main():
         out["new_w"] = r["new_w"][out_sample_index(r["new_w"].size)]
         # samples as float32 (6e-8 relative: far below the 1e-4 bar), scalars / norms / bars as float64: ~100 KB per case
         f64 = ("grad_norms", "grad_max", "bar_fp32", "sloss", "dloss_sum")
-        out = {k: (v if k in ("meta", "near_ties") else np.asarray(v, np.float64 if k in f64 else np.float32)) for k, v in out.items()}
+        out = {k: (v if k in ("meta", "near_ties") or k.startswith("dec.") else np.asarray(v, np.float64 if k in f64 else np.float32)) for k, v in out.items()}
         path = os.path.join(ROOT, "tests", "golden", f"seldnet_full_b32_t3000_{dl.lower()}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path), "bytes")

@@ -13,7 +13,7 @@ N_SIMD = 256 * 4
 GROUPS = {  # group -> (kernel-name substring, fp32-equivalent GFLOP per launch at B=32, T=3000 or None)
     "conv1_fwd": "conv_first_fwd_pool_sb_kernel", "conv1_gram (side stream)": "conv_first_gram_kernel",
     "conv2_fwd_dgrad (W=16)": "conv64_fwd_sbd_kernel<4", "conv3_fwd_dgrad (W=4)": "conv64_fwd_sbd_kernel<2",
-    "conv2_wgrad": "conv64_wgrad_sb_kernel<4>", "conv3_wgrad": "conv64_wgrad_sb_kernel<2>",
+    "conv2_wgrad": "conv64_wgrad_sb_kernel<4", "conv3_wgrad": "conv64_wgrad_sb_kernel<2",
     "gemm_sb (4-wave: GRU in-projections, dX)": "gemm_sb_kernel", "gemm_sb16 (16-wave)": "gemm_sb16_kernel",
     "gemm_tn_sb (GRU kernel gradients)": "gemm_tn_sb", "gemm_f32 (heads)": "gemm_f32_kernel",
     "gru_fwd": "gru_fwd_kernel", "gru_bwd": "gru_bwd_kernel",

@@ -15,7 +15,7 @@ GROUPS = {  # bench.py timer group -> kernel-name substring
     "conv64_fwd_dgrad_W16": "conv64_fwd_sbd_kernel<4", "conv64_fwd_dgrad_W4": "conv64_fwd_sbd_kernel<2",
     "conv64_fwd_dgrad_W16_sbr": "conv64_fwd_sbr_kernel<4", "conv64_fwd_dgrad_W4_sbr": "conv64_fwd_sbr_kernel<2",
     "feat_dft": "feat_dft_kernel", "feat_frame": "feat_wave_kernel", "feat_frame_workgroup": "feat_frame_kernel", "feat_topdb": "feat_topdb_kernel",
-    "conv2_wgrad": "conv64_wgrad_sb_kernel<4>", "conv3_wgrad": "conv64_wgrad_sb_kernel<2>",
+    "conv2_wgrad": "conv64_wgrad_sb_kernel<4", "conv3_wgrad": "conv64_wgrad_sb_kernel<2",
     "conv2_wgrad_f32": "conv64_wgrad_kernel<4>", "conv3_wgrad_f32": "conv64_wgrad_kernel<2>",
     "pool1_fwd": "bn_relu_ext_kernel", "gemm": "gemm_f32_kernel", "gemm_tn": "gemm_tn_kernel",
     "gemm_sb_4wave": "gemm_sb_kernel", "gemm_sb_16wave": "gemm_sb16_kernel",
