@@ -556,6 +556,25 @@ def test_full_batch_vs_golden(seldnet_config, mode):
     w1, st1 = model.get_weights()
     check("full BN moving stats", st1, z["new_state"])
     check("full post-Adam weights", w1[mg.out_sample_index(w1.size)], z["new_w"], tol=2e-3)
+    # ---- the first half of test_parity_given_identical_routing's claim AT THIS SIZE, without an oracle on the box: the library's
+    # MaxPool(ReLU) routing of every block, digested with the fixture's near-tie elements (fp64 margin < 1e-5) excluded, equals the fp64
+    # oracle's digest -> every decision the library takes differently from fp64 has an fp64 margin below 1e-5
+    import ctypes as C
+    from seld_amd import _lib
+    mb, _ = _block_golden("xception_gru")          # decision_digest: the fixtures' digest rule (tests/golden/make_golden_blocks.py)
+    H, W = T, 64
+    n_near = 0
+    for i, (pt, pf) in enumerate(spec.pools):
+        shape = (B, H // pt, W // pf, 64)
+        pos = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        gate = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, i, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
+        val = torch.where(gate > 0, pos.to(torch.int16) + 1, torch.zeros((), dtype=torch.int16, device="cuda")).cpu().numpy()
+        near = z[f"dec.pool{i}.near"].astype(np.int64)
+        n_near += near.size
+        assert np.array_equal(mb.decision_digest(val, near), z[f"dec.pool{i}.digest"]), f"block {i}: a routing decision outside the near-tie set differs from fp64"
+        H, W = H // pt, W // pf
+    print(f"[decisions] seldnet B=32: every routing decision of the three blocks outside the {n_near} near-ties (fp64 margin < 1e-5) equals the fp64 oracle's")
 
 
 def test_parity_given_identical_routing(seldnet_config):
