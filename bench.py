@@ -334,7 +334,11 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
         # RCCL process group: the LIBRARY owns the communicator, the communication stream and the two gradient buckets (seld_dp_*);
         # over gloo (the one-GPU rehearsal) the torch.distributed path stays
         from seld_amd import parallel
-        parallel.init_library_dp(model)
+        if os.environ.get("SELD_DP", "library") != "torch":      # SELD_DP=torch: round 2's torch.distributed collectives on the library's buckets
+            try:
+                parallel.init_library_dp(model)
+            except Exception as e:      # an RCCL that cannot be bound / initialised: the torch.distributed path is a HIP path too
+                print(f"[bench] rank {rank}: library-owned RCCL communicator unavailable ({e}); gradients go through torch.distributed", file=sys.stderr)
     x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
     opt = train.Adam(1e-3)
@@ -549,6 +553,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config_of(args.model))
         print(json.dumps(out), flush=True)
+    if res.get("model") is not None:
+        res["model"].close()       # every rank: the library's communicator goes before the host's process group does
+        res["model"] = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -226,6 +226,11 @@ class SeldNet:
         _lib.check(self.lib.seld_forward(self.ctx, x.data_ptr(), sed.data_ptr(), doa.data_ptr(), int(bool(training))), self.ctx)
         return [sed, doa]
 
+    def close(self) -> None:
+        """Destroy the HIP context now (and its RCCL communicator, if the library owns one): call it on every rank before the host's process
+        group is torn down, instead of leaving it to interpreter shutdown."""
+        self.__del__()
+
     def __del__(self):
         try:
             if getattr(self, "ctx", None):
