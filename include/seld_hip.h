@@ -145,8 +145,9 @@ int seld_grads_bucket_count(const seld_ctx* ctx);
 int seld_grads_bucket_ready(seld_ctx* ctx, int index, void* stream, int64_t* offset, int64_t* count);
 /* ---- synchronised BatchNorm for data parallelism (a B/world-per-rank run then equals the reference's
  * single-device batch, layers.py:33 with params.py:27's batch of 256).  The library calls `fn(user, buf, count, dtype, stream)`
- * — dtype SELD_DTYPE_F64, count 128 * ceil(C / 64) = [sum z | sum z^2] resp. [sum dy | sum dy xhat] per channel (128 for the 64-channel
- * blocks, up to 2048 for resnet50_block's 1024-channel BatchNormalizations) — once per BatchNormalization in the
+ * — dtype SELD_DTYPE_F64, count 128 * ceil(C / 64) + 1 = [sum z | sum z^2] resp. [sum dy | sum dy xhat] per channel (128 for the 64-channel
+ * blocks, up to 2048 for resnet50_block's 1024-channel BatchNormalizations) followed by THIS rank's element count (so ranks may hold
+ * different numbers of clips: the global count is the all-reduced one) — once per BatchNormalization in the
  * training forward and once in the backward; fn must enqueue an in-place SUM over the `world` ranks of the device buffer `buf`
  * on `stream` (e.g. ncclAllReduce / torch.distributed.all_reduce) and return 0.  fn == NULL switches back to per-replica
  * statistics.  dgamma / dbeta stay per-rank partial sums like every other gradient (the gradient all-reduce completes them). */
@@ -161,8 +162,7 @@ int seld_set_sync_bn(seld_ctx* ctx, seld_allreduce_fn fn, void* user, int world)
  *   seld_dp_allreduce_grads(ctx)     : between seld_train_fwd_bwd and seld_adam_step — TWO in-place ncclAllReduce(SUM) over the flat
  *                                      gradient buffer: GRU + heads as soon as those gradients are final (the conv backward is still
  *                                      running), then the conv / BN variables; the ctx stream waits for both
- *   seld_dp_set_sync_bn(ctx, on)     : synchronised BatchNorm (see seld_set_sync_bn) through the same communicator; every rank must
- *                                      hold the same number of clips (the global count is taken as local count x world)
+ *   seld_dp_set_sync_bn(ctx, on)     : synchronised BatchNorm (see seld_set_sync_bn) through the same communicator
  *   MMSE loss: with a communicator and cfg.mmse_den <= 0 the mask count is all-reduced on the device inside seld_train_fwd_bwd /
  *              seld_test_step; the caller sets cfg.sed_grad_scale = 1 / world (loss-reduction rules: DESIGN.md section 5)
  * A failed collective is fatal for the process group: peers block in theirs — abort the job. */

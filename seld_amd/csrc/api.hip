@@ -528,7 +528,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             seld_destroy(c);
             return fail(nullptr, SELD_ERR_HIP, "event creation failed");
         }
-    ALLOC(c->sync_buf, resn ? 16 * 128 : 128);
+    ALLOC(c->sync_buf, (resn ? 16 * 128 : 128) + 1);      // + this rank's element count, all-reduced with the sums
     for (int hd = 0; hd < 2; ++hd)
         for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
     {
@@ -835,9 +835,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         }
         if (training && c->sync_fn) {
             // synchronised BatchNorm: this rank's [sum z | sum z^2] -> the host's all-reduce -> coefficients of the GLOBAL batch
-            launch_bn_partials_to_sums(st, c->stat_partial, npart, c->sync_buf);
-            if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
-            launch_bn_finalize_sums(st, c->sync_buf, (double)B * L.H * L.W * c->sync_world, c->params + L.g_off, c->params + L.be_off,
+            launch_bn_partials_to_sums(st, c->stat_partial, npart, c->sync_buf, (double)B * L.H * L.W);
+            if (c->sync_fn(c->sync_user, c->sync_buf, 129, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+            launch_bn_finalize_sums(st, c->sync_buf, 0.0 /* the all-reduced count */, c->params + L.g_off, c->params + L.be_off,
                                     c->state + L.mm_off, c->state + L.mv_off, L.mean, L.invstd, L.scale, L.shift);
         } else if (training)
             launch_bn_finalize(st, c->stat_partial, npart, (double)B * L.H * L.W, c->params + L.g_off, c->params + L.be_off,
@@ -886,9 +886,9 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             if (training) {
                 if (!c->xc_fused_fwd) launch_xc_bn_stats(st, U.z, c->xc_part, &np, npix);
                 if (c->sync_fn) {      // synchronised BatchNorm: global sums through the host's all-reduce (see the conv blocks above)
-                    launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf);
-                    if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
-                    launch_bn_finalize_sums(st, c->sync_buf, (double)npix * c->sync_world, c->params + U.g_off, c->params + U.be_off,
+                    launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf, (double)npix);
+                    if (c->sync_fn(c->sync_user, c->sync_buf, 129, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+                    launch_bn_finalize_sums(st, c->sync_buf, 0.0 /* the all-reduced count */, c->params + U.g_off, c->params + U.be_off,
                                             c->state + U.mm_off, c->state + U.mv_off, U.mean, U.invstd, U.scale, U.shift);
                 } else
                     launch_bn_finalize(st, c->xc_part, np, (double)npix, c->params + U.g_off, c->params + U.be_off, c->state + U.mm_off,
@@ -1149,8 +1149,8 @@ static void rn_bn(seld_ctx* c, hipStream_t st, RnConv& cv, int64_t M, int traini
         // synchronised BatchNorm: this rank's per-chunk sums -> the host's all-reduce -> coefficients of the GLOBAL batch
         const int nd = (cv.Cout + 63) / 64 * 128;
         launch_rn_bn_finalize(st, part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 1);
-        if (c->sync_fn(c->sync_user, c->sync_buf, nd, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
-        launch_rn_bn_finalize(st, part, nbx, (double)M * c->sync_world, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 2);
+        if (c->sync_fn(c->sync_user, c->sync_buf, nd + 1, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }      // + the element count
+        launch_rn_bn_finalize(st, part, nbx, 0.0, g, be, mm, mv, cv.coef, cv.Cout, 1, c->sync_buf, 2);
         return;
     }
     launch_rn_bn_finalize(st, part, nbx, (double)M, g, be, mm, mv, cv.coef, cv.Cout, training);
@@ -1165,8 +1165,8 @@ static void rn_bn_bwd(seld_ctx* c, hipStream_t st, RnConv& cv, const float* dy, 
     if (c->sync_fn) {
         const int nd = (cv.Cout + 63) / 64 * 128;
         launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 1);
-        if (c->sync_fn(c->sync_user, c->sync_buf, nd, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
-        launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M * c->sync_world, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 2);
+        if (c->sync_fn(c->sync_user, c->sync_buf, nd + 1, SELD_DTYPE_F64, st)) { c->sync_failed = true; return; }
+        launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, 0.0, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout, c->sync_buf, 2);
     } else
         launch_rn_bn_bwd_finalize(st, c->rn_part, nbx, (double)M, c->grads + cv.g_off, c->grads + cv.be_off, cv.coef, cv.Cout);
     launch_rn_bn_bwd_dz(st, cv.z, dy, mask, cv.coef, dz, M, cv.Cout, gate_z);
@@ -1417,10 +1417,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
                     PROF2(c, "xc_bn_bwd");
                     launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
                     if (c->sync_fn) {
-                        launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf);
+                        launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf, (double)npix);
                         launch_bn_bwd_local(st, c->sync_buf, c->grads + U.g_off, c->grads + U.be_off);
-                        if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
-                        launch_bn_bwd_c1c2(st, c->sync_buf, (double)npix * c->sync_world, U.c1c2);
+                        if (c->sync_fn(c->sync_user, c->sync_buf, 129, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+                        launch_bn_bwd_c1c2(st, c->sync_buf, 0.0 /* the all-reduced count */, U.c1c2);
                     } else
                         launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
                     if (!fpw) launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, dz, npix);
@@ -1474,10 +1474,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_pool_bwd_reduce");
         }
         if (c->sync_fn) {
-            launch_bn_partials_to_sums(st, c->bn_partial, np, c->sync_buf);
+            launch_bn_partials_to_sums(st, c->bn_partial, np, c->sync_buf, (double)B * L.H * L.W);
             launch_bn_bwd_local(st, c->sync_buf, c->grads + L.g_off, c->grads + L.be_off);
-            if (c->sync_fn(c->sync_user, c->sync_buf, 128, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
-            launch_bn_bwd_c1c2(st, c->sync_buf, (double)B * L.H * L.W * c->sync_world, L.c1c2);
+            if (c->sync_fn(c->sync_user, c->sync_buf, 129, SELD_DTYPE_F64, st)) return fail(c, SELD_ERR_HIP, "sync_bn all-reduce callback failed");
+            launch_bn_bwd_c1c2(st, c->sync_buf, 0.0 /* the all-reduced count */, L.c1c2);
         } else
             launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
         int ns = 0;

@@ -399,23 +399,27 @@ int launch_pool_routing(hipStream_t st, const float* z, const float* p, const un
 // ------------------------------------------------------------------------------------------------
 // Synchronised BatchNorm (seld_set_sync_bn): the block partials are first reduced to 128 double sums, the host's
 // all-reduce callback sums those over the ranks, and the coefficients come from the global sums / global count.
+// sums[128] = THIS rank's element count: it is all-reduced with the sums, so that ranks holding different numbers of clips (a partial last
+// batch on one rank) still get the statistics of the global batch (round 2 took the global count as local x world)
 __global__ __launch_bounds__(1024) void bn_partials_to_sums_kernel(const float* __restrict__ partial, int npartial,
-                                                                   double* __restrict__ sums) {
+                                                                   double* __restrict__ sums, double local_count) {
     __shared__ double red[1024];
     const double t = reduce_partials_128(partial, npartial, red);
     if (threadIdx.x < 128) sums[threadIdx.x] = t;
+    if (threadIdx.x == 128) sums[128] = local_count;
 }
-int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums) {
-    hipLaunchKernelGGL(bn_partials_to_sums_kernel, dim3(1), dim3(1024), 0, st, partial, npartial, sums);
+int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums, double local_count) {
+    hipLaunchKernelGGL(bn_partials_to_sums_kernel, dim3(1), dim3(1024), 0, st, partial, npartial, sums, local_count);
     return 0;
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_sums_kernel(const double* __restrict__ sums, double count,
+__global__ __launch_bounds__(64) void bn_finalize_sums_kernel(const double* __restrict__ sums, double count_,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                                               float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                               float* __restrict__ scale_o, float* __restrict__ shift_o) {
     const int c = threadIdx.x;
+    const double count = count_ > 0.0 ? count_ : sums[128];      // count_ <= 0: the all-reduced count beside the sums
     const double mean = sums[c] / count;
     double var = sums[64 + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(128) void bn_bwd_local_kernel(const double* __restr
 }
 // global sums -> c1 = sum dy / N, c2 = sum dy xhat / N over the GLOBAL batch
 __global__ __launch_bounds__(128) void bn_bwd_c1c2_kernel(const double* __restrict__ sums, double count, float* __restrict__ c1c2) {
-    c1c2[threadIdx.x] = (float)(sums[threadIdx.x] / count);
+    c1c2[threadIdx.x] = (float)(sums[threadIdx.x] / (count > 0.0 ? count : sums[128]));      // count <= 0: the all-reduced count beside the sums
 }
 int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float* dbeta) {
     hipLaunchKernelGGL(bn_bwd_local_kernel, dim3(1), dim3(128), 0, st, sums, dgamma, dbeta);

@@ -197,7 +197,7 @@ int launch_xc_pw_bwd(hipStream_t st, const float* z, const float* gy, const floa
 int launch_xc_bn_bwd_dz(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, const float* scale,
                         const float* c1c2, float* dz, int64_t npix);
 int launch_xc_ident(hipStream_t st, float* ident);
-int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums);
+int launch_bn_partials_to_sums(hipStream_t st, const float* partial, int npartial, double* sums, double local_count);   // sums[128] = local_count
 int launch_bn_finalize_sums(hipStream_t st, const double* sums, double count, const float* gamma, const float* beta,
                             float* mov_mean, float* mov_var, float* mean, float* invstd, float* scale, float* shift);
 int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float* dbeta);

@@ -173,12 +173,14 @@ __global__ __launch_bounds__(1024) void rn_bn_finalize_kernel(const float* __res
         __syncthreads();
         if (phase == 1) {
             if (tid < 128) sums[(size_t)blockIdx.x * 128 + tid] = tot[tid];
+            if (tid == 128 && blockIdx.x == 0) sums[(size_t)gridDim.x * 128] = count;     // this rank's element count, all-reduced with the sums
             return;
         }
     }
     if (training && phase == 2) {
         if (tid < 128) tot[tid] = sums[(size_t)blockIdx.x * 128 + tid];
         __syncthreads();
+        count = sums[(size_t)gridDim.x * 128];                                             // the global count
     }
     if (tid >= 64) return;
     const int c = c0 + tid;
@@ -217,8 +219,10 @@ __global__ __launch_bounds__(1024) void rn_bn_bwd_finalize_kernel(const float* _
     if (phase == 2) {
         if (tid >= 128) return;
         t = sums[(size_t)blockIdx.x * 128 + tid];
+        count = sums[(size_t)gridDim.x * 128];                                             // the global count
     } else {
         t = rn_sum_partials(partial, blockIdx.x, nbx, red);
+        if (tid == 128 && blockIdx.x == 0 && phase == 1) sums[(size_t)gridDim.x * 128] = count;    // this rank's element count
         if (tid >= 128) return;
         if (phase == 1) sums[(size_t)blockIdx.x * 128 + tid] = t;
     }

@@ -109,23 +109,19 @@ def enable_sync_batchnorm(model, group=None, force: bool = False) -> None:
     """Synchronised BatchNorm over the ranks of `group` (seld_set_sync_bn): the per-channel sums of every conv block's
     BatchNormalization are all-reduced in the training forward and in the backward pass, so that B/world clips per rank
     reproduce the reference's single-device batch of B (layers.py:33).  Six 1-KB collectives per step.
-    EVERY RANK MUST HOLD THE SAME NUMBER OF CLIPS: the library takes the global element count as local count x world (only the sums
-    are all-reduced); `train.trainstep` checks that across the group whenever the local batch size changes (`check_equal_batch`).
+    Ranks may hold different numbers of clips (a partial last batch): each rank's element count is all-reduced with its sums.
     A failing callback is fatal for the process group (the peers block in their collectives): exit the job."""
     import ctypes as C
     from . import _lib
     world = world_size(group)
     if getattr(model, "_lib_dp", False):            # the library's communicator carries the sums (seld_dp_set_sync_bn)
         _lib.check(model.lib.seld_dp_set_sync_bn(model.ctx, 1), model.ctx)
-        model._sync_bn_on, model._sync_bn_group, model._sync_bn_B = True, group, None
         return
     if world <= 1 and not force:
         model.lib.seld_set_sync_bn(model.ctx, None, None, 1)
         model._sync_bn_cb = None
-        model._sync_bn_on = False
         return
     dev = model._dev
-    model._sync_bn_on, model._sync_bn_group, model._sync_bn_B = True, group, None
 
     def _cb(_user, buf, count, dtype, _stream):
         try:
@@ -153,18 +149,3 @@ class _F64Ptr:
     def __init__(self, ptr: int, n: int):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
-
-def check_equal_batch(model, B: int) -> None:
-    """Synchronised BatchNorm needs the same clip count on every rank (see enable_sync_batchnorm).  One tiny MAX / MIN all-reduce
-    whenever this rank's batch size changes (a partial last batch); raises on every rank if they disagree."""
-    if not getattr(model, "_sync_bn_on", False) or getattr(model, "_sync_bn_B", None) == B:
-        return
-    group = model._sync_bn_group
-    if world_size(group) > 1:
-        d = torch.distributed
-        dev = model._dev if d.get_backend(group) == "nccl" else "cpu"
-        t = torch.tensor([B, -B], dtype=torch.int64, device=dev)
-        d.all_reduce(t, op=d.ReduceOp.MAX, group=group)
-        if int(t[0]) != -int(t[1]):
-            raise ValueError(f"synchronised BatchNorm: ranks hold between {-int(t[1])} and {int(t[0])} clips; every rank must hold the same number")
-    model._sync_bn_B = B

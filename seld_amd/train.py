@@ -55,7 +55,6 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     world = parallel.world_size(process_group)
     is_mmse = isinstance(doa_loss, losses._MMSE)
     lib_dp = getattr(model, "_lib_dp", False)        # parallel.init_library_dp: the library owns the RCCL communicator
-    parallel.check_equal_batch(model, B)
     dent = None
     if lib_dp:
         pass            # the mask count is all-reduced on the device inside seld_train_fwd_bwd (cfg.mmse_den = 0)

@@ -151,3 +151,4 @@ def test_two_rank_sync_batchnorm_equals_single_process_batch():
     assert err < 1e-9
     assert np.abs(sed0 - ref["sed"][:2]).max() < 1e-12
     assert np.abs(state - ref["new_state"]).max() < 1e-9
+

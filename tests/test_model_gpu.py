@@ -629,12 +629,15 @@ def test_parity_given_identical_routing(seldnet_config):
     _per_var(model, "routed grad", g, ref["grad"])
 
 
-@pytest.mark.parametrize("which", ["seldnet", "xception_gru", "resnet50_gru"])
-def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xception_config, resnet50_config, which):
+@pytest.mark.parametrize("which,split", [("seldnet", (2, 2)), ("xception_gru", (2, 2)), ("resnet50_gru", (2, 2)),
+                                         ("seldnet", (3, 1)), ("resnet50_gru", (1, 3))])
+def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xception_config, resnet50_config, which, split):
     """seld_set_sync_bn: two replicas (two ctxs on the one test GPU, driven by two host threads, their all-reduce callback a
     rendezvous that sums the two 128-double buffers on the host) each train on half of a batch; with synchronised BatchNorm the
     SUM of their gradient buffers, their outputs and their BN moving statistics must equal the oracle's single-process step on
     the whole batch — the reference's single-device semantics (layers.py:33), which per-replica statistics only approximate.
+    `split`: clips per replica — UNEQUAL splits too (a partial last batch on one rank): each rank's element count travels with its
+    sums (one more double), so the statistics are those of the global batch whatever the ranks hold (round 2 assumed local x world).
     Also checks the gradient buckets of the DP path (seld_grads_bucket_ready): contiguous, disjoint, covering the buffer."""
     import ctypes as C
     import threading
@@ -651,7 +654,9 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
     w, st = O.random_weights(spec, 0)
     B, T = (4, 100) if which != "resnet50_gru" else (4, 300)
     x, ys, yd = O.synthetic_batch(B, T, seed=31)
-    reps = [models.seldnet((B // 2, T, 64, 7), seldnet_config) for _ in range(2)]
+    assert sum(split) == B
+    lo = [0, split[0]]
+    reps = [models.seldnet((split[r], T, 64, 7), seldnet_config) for r in range(2)]
     host = [None, None]
     bar = threading.Barrier(2)
     calls = [0, 0]
@@ -660,7 +665,7 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
     def make_cb(r):
         def cb(_user, buf, count, dtype, _stream):
             try:
-                assert dtype == _lib.SELD_DTYPE_F64 and count % 128 == 0 and (count == 128 or which == "resnet50_gru")
+                assert dtype == _lib.SELD_DTYPE_F64 and count % 128 == 1 and (count == 129 or which == "resnet50_gru")    # sums + element count
                 from seld_amd.parallel import _F64Ptr
                 t = torch.as_tensor(_F64Ptr(int(buf), int(count)), device="cuda")
                 torch.cuda.current_stream().synchronize()        # the library enqueued the sums on this thread's current stream
@@ -686,10 +691,10 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
             m.set_weights(w, st)
             _lib.check(m.lib.seld_set_sync_bn(m.ctx, C.cast(cbs[r], C.c_void_p), None, 2), m.ctx)
             with torch.cuda.stream(torch.cuda.Stream()):
-                sl = slice(r * B // 2, (r + 1) * B // 2)
+                sl = slice(lo[r], lo[r] + split[r])
                 xd = m._prep(x[sl])
-                ysd, ydd = train._labels(m, (ys[sl], yd[sl]), B // 2)
-                sed, doa = m._outputs(B // 2)
+                ysd, ydd = train._labels(m, (ys[sl], yd[sl]), split[r])
+                sed, doa = m._outputs(split[r])
                 cfg = train._cfg(losses.MSE, (1.0, 1000.0))
                 _lib.check(m.lib.seld_train_fwd_bwd(m.ctx, xd.data_ptr(), ysd.data_ptr(), ydd.data_ptr(), C.byref(cfg), sed.data_ptr(),
                                                     doa.data_ptr(), None, None), m.ctx)
@@ -715,13 +720,13 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
         S = T // 5
         routing = {}
         pos_l, gate_l = [], []
-        for m in reps:
-            pos = torch.empty((B // 2, S, 16, 64), dtype=torch.uint8, device="cuda")
-            gate = torch.empty((B // 2, S, 16, 64), dtype=torch.uint8, device="cuda")
+        for r_, m in enumerate(reps):
+            pos = torch.empty((split[r_], S, 16, 64), dtype=torch.uint8, device="cuda")
+            gate = torch.empty((split[r_], S, 16, 64), dtype=torch.uint8, device="cuda")
             _lib.check(m.lib.seld_debug_pool_routing(m.ctx, 0, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), m.ctx)
             pos_l.append(pos.cpu().to(torch.int64)); gate_l.append(gate.cpu().bool())
         routing[0] = (torch.cat(pos_l), torch.cat(gate_l))
-        buf = torch.empty((B // 2) * S * 16 * 128, device="cuda")
+        buf = torch.empty(max(split) * S * 16 * 128, device="cuda")
         cnt = C.c_int64()
         free = {}
         O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64, record_routing=free)
@@ -729,9 +734,9 @@ def test_sync_batchnorm_two_replicas_equal_one_big_batch(seldnet_config, xceptio
             for wh, nm in enumerate(("y0", "y1", "out")):
                 key = f"rn{s_}.{b}.{nm}"
                 parts = []
-                for m in reps:
+                for r_, m in enumerate(reps):
                     _lib.check(m.lib.seld_debug_relu_output(m.ctx, bi, wh, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), m.ctx)
-                    shp = (B // 2,) + tuple(free[key]["gate"].shape[1:])
+                    shp = (split[r_],) + tuple(free[key]["gate"].shape[1:])
                     parts.append((buf[:cnt.value] > 0).cpu().reshape(shp))
                 routing[key] = torch.cat(parts)
         ref_r = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), dtype=torch.float64, routing=routing)
