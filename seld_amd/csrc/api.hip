@@ -872,6 +872,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 PROF2(c, "xc_unit_fwd");
                 if (launch_xc_unit_fwd(st, uin, c->params + U.dw_off, c->params + U.pw_off, U.dwo, U.z, training ? c->xc_part : nullptr, &np, B, S, 16, aff))
                     return fail(c, SELD_ERR_UNSUPPORTED, "xc_unit_fwd");
+                if (np > xc_partial_capacity()) return fail(c, SELD_ERR_INVALID, "xception_block: more BatchNorm partials than xc_part holds");
             } else {
             {
                 PROF2(c, "xc_depthwise_fwd");
@@ -966,6 +967,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                     { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
                 } else {
                     { PROF3(c, "rn_products_fwd"); launch_conv64_fwd_sb(st, R.y0, R.c[1].wsp9, nullptr, R.c[1].z, training ? c->rn_part : nullptr, &npart, B, S, R.Wout); }
+                    // the conv epilogue's partial sums land in rn_part ([rn_partial_capacity()][16][128] floats): the producer's count must fit
+                    if (npart > rn_partial_capacity() * 16) return fail(c, SELD_ERR_INVALID, "resnet50_block: more BatchNorm partials than rn_part holds");
                     { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training, npart); }
                 }
             } else if (sb && rn_c1_implicit(c, R)) {

@@ -19,7 +19,11 @@
 
 #define XC_MAX_PARTIAL 512      // depthwise kernel-gradient slabs (one per workgroup of image rows): 2048 cost 0.4 ms per step more (slab traffic + combine)
 #define XC_BN_PARTIAL 512       // BatchNorm partial sums: the single-workgroup finalisation reads all of them
-int xc_partial_capacity() { return XC_MAX_PARTIAL; }
+#define XU_MAX_BLOCKS 512       // persistent workgroups of xc_unit_fwd: each leaves one BatchNorm partial
+// ONE buffer (ctx xc_part) receives the BatchNorm partials of xc_unit_fwd (<= XU_MAX_BLOCKS), of the statistics / backward-sum passes
+// (<= XC_BN_PARTIAL) and nothing else: its capacity is the largest of the producers' caps, not whichever constant happens to be equal today
+constexpr int xc_cmax(int a, int b) { return a > b ? a : b; }
+int xc_partial_capacity() { return xc_cmax(xc_cmax(XC_MAX_PARTIAL, XC_BN_PARTIAL), XU_MAX_BLOCKS); }
 
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 __device__ __forceinline__ float4 fma4v(float4 a, float4 b, float4 c) {
@@ -149,7 +153,6 @@ int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* s
 // one's loads and depthwise phase run beside the other's MFMAs.
 #define XU_ROWS 8
 #define XU_LDA 129      // odd row stride: the transposed depthwise writes (row 4 g + j, 16 groups per wave) spread over the banks
-#define XU_MAX_BLOCKS 512
 __global__ __launch_bounds__(256, 2) void xc_unit_fwd_kernel(const float* __restrict__ x, const float* __restrict__ kdw, const float* __restrict__ wpw,
                                                              float* __restrict__ dwo, float* __restrict__ z, float* __restrict__ partial, int B, int H,
                                                              int want_stats, const float* __restrict__ aff) {
