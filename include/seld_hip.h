@@ -73,7 +73,16 @@ typedef struct seld_arch {
      * bottleneck blocks of width rn_filters * 2^s, frequency stride 2 at the first block of stages 1..3 -> [B, T/5, 2, 32 rn_filters] */
     int32_t rn_filters;
     int32_t rn_blocks[4];
+    /* simple_dense_block's `dense_activation` (modules.py:356, 368-371): the activation of the heads' HIDDEN Conv1D layers (the output
+     * Dense layers keep sigmoid / tanh, models.py:28-30).  0 = None / 'linear' (seldnet.json; lets W1 W2 fold into one product),
+     * SELD_ACT_SIGMOID, SELD_ACT_TANH, SELD_ACT_RELU. */
+    int32_t sed_dense_act;
+    int32_t doa_dense_act;
 } seld_arch;
+#define SELD_ACT_NONE 0
+#define SELD_ACT_SIGMOID 1
+#define SELD_ACT_TANH 2
+#define SELD_ACT_RELU 3
 /* sizeof(seld_arch), sizeof(seld_loss_cfg) as the LIBRARY was compiled, into out[0..min(n,2)); returns how many it knows (2).  A binding
  * compares them with its own struct declarations before the first seld_create. */
 int seld_abi_sizes(int32_t* out, int n);

@@ -70,9 +70,21 @@ class Spec:
     xc_blocks: int = 0                 # xception_block: number of middle-flow modules (block_num)
     rn_filters: int = 0                # resnet50_block: base width (FIRST_ARGS.filters)
     rn_blocks: Tuple[int, ...] = ()    # resnet50_block: bottleneck blocks per stage (FIRST_ARGS.block_num)
+    sed_dense_act: str | None = None   # simple_dense_block's dense_activation (modules.py:356): activation of the heads' hidden Conv1D layers
+    doa_dense_act: str | None = None
 
     @staticmethod
     def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
+        sp = Spec._from_config(model_config, in_ch, n_freq)
+        sp.sed_dense_act = model_config["SED_ARGS"].get("dense_activation")
+        sp.doa_dense_act = model_config["DOA_ARGS"].get("dense_activation")
+        for a in (sp.sed_dense_act, sp.doa_dense_act):
+            if a not in (None, "linear", "relu", "tanh", "sigmoid"):
+                raise ValueError(f"dense_activation {a!r} not restated")
+        return sp
+
+    @staticmethod
+    def _from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
         if model_config["FIRST"] not in ("simple_conv_block", "xception_block", "resnet50_block"):
             raise ValueError("oracle restates simple_conv_block, xception_block and resnet50_block only")
         if model_config["SECOND"] != "bidirectional_GRU_block":
@@ -375,11 +387,13 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
         if taps is not None:
             taps[f"gru{i}"] = h
     outs = []
-    for head, units, act in (("sed", spec.sed_units, torch.sigmoid), ("doa", spec.doa_units, torch.tanh)):
+    hidden = {None: lambda t: t, "linear": lambda t: t, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+    for head, units, act, hact in (("sed", spec.sed_units, torch.sigmoid, hidden[spec.sed_dense_act]),
+                                   ("doa", spec.doa_units, torch.tanh, hidden[spec.doa_dense_act])):
         a = h
         for j in range(len(units)):
-            # Conv1D(units, kernel_size=1, activation=None) == per-step dense (modules.py:368-371)
-            a = a @ w[f"{head}.dense{j}.kernel"][0] + w[f"{head}.dense{j}.bias"]
+            # Conv1D(units, kernel_size=1, activation=dense_activation) == per-step dense (modules.py:356, 368-371)
+            a = hact(a @ w[f"{head}.dense{j}.kernel"][0] + w[f"{head}.dense{j}.bias"])
         outs.append(act(a @ w[f"{head}.out.kernel"] + w[f"{head}.out.bias"]))
     return outs[0], outs[1], new_st
 

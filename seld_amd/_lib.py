@@ -19,6 +19,7 @@ SELD_DOA_MSE, SELD_DOA_MMSE, SELD_DOA_MAE, SELD_DOA_MSLE = 0, 1, 2, 3
 SELD_DTYPE_F32 = 0
 SELD_DTYPE_F64 = 1
 SELD_DTYPE_BF16 = 2
+SELD_ACT = {None: 0, "linear": 0, "sigmoid": 1, "tanh": 2, "relu": 3}      # simple_dense_block's dense_activation -> seld_arch.*_dense_act
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # seld_allreduce_fn
 MAX_LAYERS = 4
 ERR_NAMES = {-1: "SELD_ERR_INVALID", -2: "SELD_ERR_UNSUPPORTED", -3: "SELD_ERR_HIP", -4: "SELD_ERR_NOMEM"}
@@ -40,7 +41,8 @@ class Arch(C.Structure):
                 ("pool_f", C.c_int32 * MAX_LAYERS), ("n_gru", C.c_int32), ("gru_units", C.c_int32 * MAX_LAYERS),
                 ("n_sed_dense", C.c_int32), ("sed_units", C.c_int32 * MAX_LAYERS),
                 ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32),
-                ("first_kind", C.c_int32), ("xc_blocks", C.c_int32), ("rn_filters", C.c_int32), ("rn_blocks", C.c_int32 * 4)]
+                ("first_kind", C.c_int32), ("xc_blocks", C.c_int32), ("rn_filters", C.c_int32), ("rn_blocks", C.c_int32 * 4),
+                ("sed_dense_act", C.c_int32), ("doa_dense_act", C.c_int32)]
 
 
 class LossCfg(C.Structure):

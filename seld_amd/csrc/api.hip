@@ -64,6 +64,7 @@ struct XcUnit {
 struct Head {
     std::vector<DenseL> layers;   // dense chain, last = output layer with activation
     int act;
+    int hidden_act = 0;           // simple_dense_block's dense_activation on the hidden layers (SELD_ACT_*; 0 = linear)
 };
 
 }  // namespace
@@ -402,6 +403,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         snprintf(nm, sizeof nm, "%s.out.bias", hn);   D.b_off = off; add_var(c->tr, off, nm, {D.out});
         c->heads[hd].layers.push_back(D);
         c->heads[hd].act = hd == 0 ? 1 : 2;
+        c->heads[hd].hidden_act = hd == 0 ? a->sed_dense_act : a->doa_dense_act;
+        if (c->heads[hd].hidden_act < SELD_ACT_NONE || c->heads[hd].hidden_act > SELD_ACT_RELU) { delete c; return fail(nullptr, SELD_ERR_UNSUPPORTED, "dense_activation: none, sigmoid, tanh or relu"); }
     }
     c->nparam = off; c->nstate = soff;
 
@@ -686,7 +689,7 @@ static bool heads_sb(const seld_ctx* c) {
 // F = feat^T dy and colsum(dy) (gemm.hip, heads_grad_kernel).  Same mathematics, different association of the fp32 sums.
 static bool heads_lin(const seld_ctx* c) {
     const Head &Hs = c->heads[0], &Hdo = c->heads[1];
-    if (!c->heads_fused || Hs.layers.size() != 2 || Hdo.layers.size() != 2) return false;
+    if (!c->heads_fused || Hs.layers.size() != 2 || Hdo.layers.size() != 2 || Hs.hidden_act || Hdo.hidden_act) return false;   // W1 W2 folds only without an activation between them
     const DenseL &S0 = Hs.layers[0], &D0 = Hdo.layers[0];
     return S0.in == D0.in && S0.out == D0.out && Hs.layers[1].out + Hdo.layers[1].out <= 64 && (S0.in & 3) == 0 &&
            ((Hs.layers[1].out + Hdo.layers[1].out) & 3) == 0;
@@ -1046,13 +1049,15 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 return fail(c, SELD_ERR_UNSUPPORTED, "gemm_heads");
             return check_launch(c, "forward");
         }
-        const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out;
+        const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out &&
+                             c->heads[0].hidden_act == c->heads[1].hidden_act;      // one launch, one epilogue activation
+        const int hact0 = c->heads[0].hidden_act;
         if (merged0 && heads_sb(c) && gemm_sb_usable(feat, S0.in, S0.out, S0.in))
             launch_gemm_sb(st, feat, nullptr, S0.in, c->h0sp_fwd[0], c->h0sp_fwd[1], c->params + S0.b_off, c->params + D0.b_off, S0.y,
-                           D0.y, S0.out, rows, S0.out, S0.in, 0, 1);
+                           D0.y, S0.out, rows, S0.out, S0.in, hact0, 1);
         else if (merged0)
             launch_gemm_dual_n(st, feat, S0.in, c->params + S0.w_off, c->params + D0.w_off, S0.out, c->params + S0.b_off,
-                               c->params + D0.b_off, S0.y, D0.y, S0.out, rows, S0.out, S0.in, 0, 0);
+                               c->params + D0.b_off, S0.y, D0.y, S0.out, rows, S0.out, S0.in, 0, hact0);
         for (int hd = 0; hd < 2; ++hd) {
             const float* a = feat;
             Head& Hd = c->heads[hd];
@@ -1064,7 +1069,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 // the head's output layer also writes the caller's copy (no device-to-device copy afterwards)
                 if (!(merged0 && j == 0))
                     launch_gemm_mirror(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, y, lastl ? outp : nullptr, D.out,
-                                       rows, D.out, D.in, 0, lastl ? Hd.act : 0);
+                                       rows, D.out, D.in, 0, lastl ? Hd.act : Hd.hidden_act);
                 a = y;
             }
         }
@@ -1225,6 +1230,8 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
                 const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
                 launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
+                // through the hidden layer's dense_activation: the gradient w.r.t. its pre-activation, from its stored output
+                if (j > 0 && Hd.hidden_act) launch_act_bwd(st, Hd.layers[j - 1].y, din, (int64_t)rows * D.in, Hd.hidden_act);
             }
         }
         if (merged0 && heads_sb(c) && gemm_sb_usable(S0.dy, S0.out, S0.in, S0.out) && gemm_sb_usable(D0.dy, S0.out, S0.in, S0.out))

@@ -276,6 +276,7 @@ int gru_timing_read(int which, unsigned long long* out, int blocks);
 int launch_mul(hipStream_t st, const float* a, const float* b, float* out, int64_t n);
 
 struct seld_loss_cfg;
+int launch_act_bwd(hipStream_t st, const float* y, float* dy, int64_t n, int act);   // loss_adam.hip: dy *= act'(.) from y = act(.)
 int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scratch, int rows, int nc);
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,

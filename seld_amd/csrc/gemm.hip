@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 v_[j] = (acc[4 * q + j] + acc1[4 * q + j]) + bv;
                 if (act == 1) v_[j] = 1.f / (1.f + expf(-v_[j]));
                 else if (act == 2) v_[j] = tanhf(v_[j]);
+                else if (act == 3) v_[j] = fmaxf(v_[j], 0.f);
             }
             float4 o = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
             float4* p = reinterpret_cast<float4*>(C + o0 + (size_t)(8 * q) * ldc);
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 }
                 if (act == 1) v = 1.f / (1.f + expf(-v));
                 else if (act == 2) v = tanhf(v);
+                else if (act == 3) v = fmaxf(v, 0.f);
                 float* p = C + (size_t)row * ldc + col;
                 if (accumulate) v += *p;
                 *p = v;

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
         float v = ACC_[r] + BV_;                                                             \
         if (act == 1) v = 1.f / (1.f + expf(-v));                                            \
         else if (act == 2) v = tanhf(v);                                                     \
+        else if (act == 3) v = fmaxf(v, 0.f);                                                \
         if (full || dr < rows_left) {                                                        \
             if (accum) v += crow[(size_t)dr * ldc + (nt_) * 32];                             \
             crow[(size_t)dr * ldc + (nt_) * 32] = v;                                         \
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
                 v_[j] = (acc0[4 * q + j] + acc1[4 * q + j]) + bv;
                 if (act == 1) v_[j] = 1.f / (1.f + expf(-v_[j]));
                 else if (act == 2) v_[j] = tanhf(v_[j]);
+                else if (act == 3) v_[j] = fmaxf(v_[j], 0.f);
             }
             float4 o_ = quad_transpose4(v_[0], v_[1], v_[2], v_[3], li);
             if (accum) {
@@ -403,6 +405,8 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         float v = (acc0[r] + acc1[r]) + bv;
         if (act == 1) v = 1.f / (1.f + expf(-v));
         else if (act == 2) v = tanhf(v);
+        
+        else if (act == 3) v = fmaxf(v, 0.f);
         if (dr < rows_left) crow[(size_t)dr * ldc] = accum ? v + crow[(size_t)dr * ldc] : v;
     }
 }

@@ -235,3 +235,23 @@ int launch_agc(hipStream_t st, const float* theta, float* g, int64_t off, int ra
     hipLaunchKernelGGL(agc_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, theta + off, g + off, rows, cols);
     return 0;
 }
+
+// dy <- dy * act'(.) from the layer's stored OUTPUT y = act(.): simple_dense_block's dense_activation on the heads' hidden layers
+// (modules.py:356, 368-371).  act: 1 sigmoid y (1 - y), 2 tanh 1 - y^2, 3 relu [y > 0].  n % 4 == 0 (dense units are multiples of 4).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ y, float4* __restrict__ dy, int64_t n4, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = y[i];
+    float4 d = dy[i];
+    if (act == 1) { d.x *= v.x * (1.f - v.x); d.y *= v.y * (1.f - v.y); d.z *= v.z * (1.f - v.z); d.w *= v.w * (1.f - v.w); }
+    else if (act == 2) { d.x *= 1.f - v.x * v.x; d.y *= 1.f - v.y * v.y; d.z *= 1.f - v.z * v.z; d.w *= 1.f - v.w * v.w; }
+    else if (act == 3) { d.x = v.x > 0.f ? d.x : 0.f; d.y = v.y > 0.f ? d.y : 0.f; d.z = v.z > 0.f ? d.z : 0.f; d.w = v.w > 0.f ? d.w : 0.f; }
+    dy[i] = d;
+}
+int launch_act_bwd(hipStream_t st, const float* y, float* dy, int64_t n, int act) {
+    if (n & 3) return -1;
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(y),
+                       reinterpret_cast<float4*>(dy), n4, act);
+    return 0;
+}

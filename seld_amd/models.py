@@ -48,14 +48,14 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         raise ValueError("dropout_rate > 0 has no kernel (seldnet.json uses 0.0)")
     gru = list(model_config["SECOND_ARGS"]["units"])
     sed, doa = list(model_config["SED_ARGS"]["units"]), list(model_config["DOA_ARGS"]["units"])
-    # simple_dense_block honours these keys (modules.py:350-376); the head kernels are per-step LINEAR layers (Conv1D with
-    # kernel_size 1 and no activation, which is what lets W1 W2 fold into one product), so anything else must fail loudly
+    # simple_dense_block honours these keys (modules.py:350-376); the head kernels are per-step layers (Conv1D with kernel_size 1) with
+    # `dense_activation` None (seldnet.json: what lets W1 W2 fold into one product), relu, tanh or sigmoid; anything else must fail loudly
     # instead of training a different network.  `kernel_regularizer` is accepted: it only feeds model.losses, which
     # train.trainstep (train.py:22-36) never adds to the objective.
     for key in ("SED_ARGS", "DOA_ARGS"):
         ha = model_config[key]
-        if ha.get("dense_activation") not in (None, "linear"):
-            raise ValueError(f"{key}['dense_activation']={ha.get('dense_activation')!r}: the head kernels are linear (None / 'linear')")
+        if ha.get("dense_activation") not in _lib.SELD_ACT:
+            raise ValueError(f"{key}['dense_activation']={ha.get('dense_activation')!r}: the head kernels implement {sorted(k for k in _lib.SELD_ACT if k)} and None")
         if int(ha.get("kernel_size", 1)) != 1:
             raise ValueError(f"{key}['kernel_size']={ha.get('kernel_size')!r}: the head kernels are per-step (kernel_size 1)")
         if ha.get("dropout_rate", 0):
@@ -78,6 +78,8 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         a.doa_units[i] = u
     # models.py:19 default 14; train.py:306-307 overrides to 12 before building
     a.n_classes = int(model_config.get("n_classes", 14))
+    a.sed_dense_act = _lib.SELD_ACT[model_config["SED_ARGS"].get("dense_activation")]
+    a.doa_dense_act = _lib.SELD_ACT[model_config["DOA_ARGS"].get("dense_activation")]
     a.first_kind = 2 if resnet else (1 if xception else 0)
     a.xc_blocks = int(fa["block_num"]) if xception else 0
     if resnet:

@@ -93,8 +93,9 @@ def test_synthetic_batch_matches_the_oracles_generator():
 
 
 def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
-    """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376); the HIP heads are
-    linear per-step layers, so any other value must raise instead of silently training a different network."""
+    """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376); the HIP heads are per-step layers
+    with dense_activation None / linear / relu / tanh / sigmoid (config_sampler.py:216-218 samples None and relu), so any other value
+    must raise instead of silently training a different network."""
     import copy
     from seld_amd import models
     a = models._arch_from_config(seldnet_config, 7, 64)
@@ -103,7 +104,11 @@ def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
     ok["SED_ARGS"].update(dense_activation="linear", kernel_size=1, dropout_rate=0, kernel_regularizer={"l1": 0.0, "l2": 1e-3})
     models._arch_from_config(ok, 7, 64)      # the regulariser only feeds model.losses, which train.trainstep never adds
     for head in ("SED_ARGS", "DOA_ARGS"):
-        for key, val in (("dense_activation", "relu"), ("kernel_size", 3), ("dropout_rate", 0.2)):
+        good = copy.deepcopy(seldnet_config)
+        good[head]["dense_activation"] = "relu"
+        ar = models._arch_from_config(good, 7, 64)
+        assert (ar.sed_dense_act, ar.doa_dense_act) == ((3, 0) if head == "SED_ARGS" else (0, 3))
+        for key, val in (("dense_activation", "swish"), ("kernel_size", 3), ("dropout_rate", 0.2)):
             bad = copy.deepcopy(seldnet_config)
             bad[head][key] = val
             with pytest.raises(ValueError):

@@ -83,6 +83,38 @@ def test_train_step(seldnet_config, B, T, doa_loss, opts):
     check("adam update (|g| above noise)", upd[mask], rupd[mask], tol=2e-3)
 
 
+@pytest.mark.parametrize("sed_act,doa_act,opts", [("relu", "relu", {}), ("relu", None, {}), ("tanh", "sigmoid", {"gemm_split_bf16": 0}), ("relu", "relu", {"heads_fused": 0})])
+def test_train_step_dense_activation(seldnet_config, sed_act, doa_act, opts):
+    """simple_dense_block's `dense_activation` (modules.py:356, 368-371: the activation of the heads' hidden Conv1D layers;
+    config_sampler.py:216-218 samples None and 'relu'): forward, losses and every gradient against the fp64 oracle — with an
+    activation between them the two layers of a head cannot fold into one product, so these configurations take the layer-by-layer
+    kernels (merged first layers when both heads use the same activation) and the act' pass of the backward."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["SED_ARGS"]["dense_activation"], cfg["DOA_ARGS"]["dense_activation"] = sed_act, doa_act
+    B, T = 3, 100
+    spec = O.Spec.from_config(cfg)
+    assert (spec.sed_dense_act, spec.doa_dense_act) == (sed_act, doa_act)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    for k, v in opts.items():
+        model.set_option(k, v)
+    model.set_weights(w, st)
+    ref_t = O.test_step(spec, w, st, x, ys, yd, "MSE", dtype=torch.float64)
+    y_t, _, _ = train.teststep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE)
+    check("dense_activation teststep sed", y_t[0].cpu().numpy(), ref_t["sed"])
+    check("dense_activation teststep doa", y_t[1].cpu().numpy(), ref_t["doa"])
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    check("dense_activation trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("dense_activation trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("dense_activation trainstep dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "dense_activation grad", model.get_grads(), ref["grad"])
+
+
 def test_two_steps_and_short_batch(seldnet_config):
     """Second Adam step (bias correction t=2, non-zero slots) and a batch smaller than the ctx's."""
     O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, 3, 50)
