@@ -36,6 +36,8 @@ struct seld_feat {
     int dbg = 0;                // timing ablations of the wave kernel (tools/tune_features.py): 1 no loads, 2 no FFT passes, 4 no mel
     int use_wave_kernel = 1;    // 0: the workgroup-per-frame radix-2 kernel for every size (A/B and parity of the fallback)
     uint4* dft_tab = nullptr;   // foa, n_fft 1024: constant MFMA fragments + twiddles of feat_dft_kernel (DFT_TAB_BYTES)
+    uint4* mel_mm = nullptr;    // feat_dft_kernel's mel projection: [sequences][64] per-lane {first bin, weights, output} | fp32 weights, 16 per slot and mel
+    int n_mel_mm = 0, mel_mm_seq = 0, mel_mm_pmax = 1;
     bool use_dft = true;
     int gmax_clips = 1;         // clips the maxima buffer holds
     float* gmax = nullptr;      // [clips][FEAT_MAX_PARTS]: per-workgroup maxima of the dB channels of the running clip (no atomics: thousands
@@ -600,41 +602,57 @@ __device__ __forceinline__ int dft_bin(int i, int lane) {      // NB (= out of r
     return lane == 0 ? 512 : 513;
 }
 
+// -DFEAT_TRACE (diagnostic build, tools/trace_feat.py): s_memtime stamps of every wave of workgroup (0, 0) over its frames 2 and 3:
+// frame start | after channels 0..3 | after the intensity normalisation | log-mel rows | intensity rows | frame stored.
+#ifdef FEAT_TRACE
+__device__ unsigned long long g_feat_trace[DFT_WAVES][2][10];
+#define FEAT_TR(k_)                                                                                      \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (trace_it == 2 || trace_it == 3)) {                        \
+        unsigned long long t_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((threadIdx.x & 63) == 0) g_feat_trace[threadIdx.x >> 6][trace_it - 2][k_] = t_;             \
+    }
+#else
+#define FEAT_TR(k_)
+#endif
+
+template <int QSEQ>
 __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
-    const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, int n_melw4, const float* __restrict__ win_g,
-    const uint4* __restrict__ dft_g, const int* __restrict__ mel_start4, const int* __restrict__ mel_cnt4, const int* __restrict__ mel_off4,
-    const float* __restrict__ mel_w4, float* __restrict__ out, float* __restrict__ gmax, int wave_bytes, const int* __restrict__ trips_g) {
+    const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, const float* __restrict__ win_g,
+    const uint4* __restrict__ dft_g, const uint4* __restrict__ mm_g, int n_mm, int mm_pmax, float* __restrict__ out, float* __restrict__ gmax,
+    float* __restrict__ gmin, int wave_bytes) {
     constexpr int N = 1024, NB = 513, NBP = 516, NBI = 9, C_OUT = 7;
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* win = smem;                                             // [N]
-    float* melw = win + N;                                         // [n_melw4]
-    int* mst = reinterpret_cast<int*>(melw + n_melw4);
-    int* mct = mst + n_mels;
-    int* mof = mct + n_mels;
-    int* trips = mof + ((n_mels + 3) & ~3);                       // [16]
-    size_t toff = (size_t)(reinterpret_cast<char*>(trips + 16) - reinterpret_cast<char*>(smem));
-    toff = (toff + 15) & ~(size_t)15;
-    char* dtab = reinterpret_cast<char*>(smem) + toff;
+    float* red = win + N;                                          // [2][16]: the waves' maxima / minima at the very end
+    uint4* mm = reinterpret_cast<uint4*>(red + 32);                // [QSEQ][64] per-lane slot descriptions | [64] per-mel slot ranges | weights (see mel_round)
+    char* dtab = reinterpret_cast<char*>(mm + n_mm);
     const h16x8* f1 = reinterpret_cast<const h16x8*>(dtab);                       // [(s * 2 + c) * 2 + t][lane]
     const h16x8* a3 = reinterpret_cast<const h16x8*>(dtab + 8 * 1024);            // [s * 2 + t][lane]
     const float2* tw2 = reinterpret_cast<const float2*>(dtab + 12 * 1024);        // [r][lane]
     const int tid = threadIdx.x, lane_id = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (size_t)wave * wave_bytes);
-    float* stage = val + 4 * NBP;                                  // [n_mels][7]: the frame's outputs, stored as ONE contiguous run
+    float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (size_t)wave * wave_bytes);      // the wave's four per-bin planes [4][NBP]
+    float* stage = val + 4 * NBP;                                  // [n_mels][7] (+ 8 floats the idle blocks add into): the frame's outputs, stored as ONE contiguous run
     for (int i = tid; i < N; i += 64 * DFT_WAVES) win[i] = win_g[i];
-    for (int i = tid; i < n_melw4; i += 64 * DFT_WAVES) melw[i] = mel_w4[i];
-    for (int i = tid; i < n_mels; i += 64 * DFT_WAVES) { mst[i] = mel_start4[i]; mct[i] = mel_cnt4[i]; mof[i] = mel_off4[i]; }
+    for (int i = tid; i < n_mm; i += 64 * DFT_WAVES) mm[i] = mm_g[i];
     for (int i = tid; i < DFT_TAB_BYTES / 16; i += 64 * DFT_WAVES) reinterpret_cast<uint4*>(dtab)[i] = dft_g[i];
-    if (tid < 16) trips[tid] = trips_g[tid];
     __syncthreads();
-    float lmax = -INFINITY;
+    float lmax = -INFINITY, lmin = INFINITY;
     wav += (size_t)blockIdx.y * 4 * n_samples;                     // blockIdx.y = clip of a batch
     out += (size_t)blockIdx.y * T * n_mels * C_OUT;
     gmax += (size_t)blockIdx.y * gridDim.x;
+    gmin += (size_t)blockIdx.y * gridDim.x;
     float xr[16];                                                  // the samples the next channel iteration works on
     bool first_frame = true;
+    int trace_it = -1;
     for (int64_t t = (int64_t)blockIdx.x * DFT_WAVES + wave; t < T; t += (int64_t)gridDim.x * DFT_WAVES) {
+        ++trace_it;
+        FEAT_TR(0)
         int lane = lane_id;
         asm volatile("" : "+v"(lane));                             // see feat_wave_kernel: keeps lane-indexed values out of LICM
         const int li = lane & 31, g = lane >> 5;
@@ -725,7 +743,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
                 Pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, zrh[s], Pa, 0, 0, 0);
                 Qa = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, zih[s], Qa, 0, 0, 0);
             }
-            // this lane's bins: power straight into the channel's plane (pad entries zeroed below), intensity components kept
+            // this lane's bins: power straight into the channel's plane, intensity components kept
 #pragma unroll
             for (int i = 0; i < NBI; ++i) {
                 const int i8 = i < 8 ? i : 0;
@@ -737,6 +755,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) xr[u] = xn[u];
+            FEAT_TR(1 + c)
         }
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
@@ -744,37 +763,75 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ivx * ivx + ivy * ivy + ivz * ivz), 1e-8f));
             IV[0][i] = ivx * inv; IV[1][i] = ivy * inv; IV[2][i] = ivz * inv;
         }
-        // (the pad entries of the four planes: the filters read whole float4 chunks)
-        if (lane < 4 * (NBP - NB)) val[(lane / (NBP - NB)) * NBP + NB + lane % (NBP - NB)] = 0.f;
-        WAVE_LDS_FENCE();
-        auto mel_dot = [&](int m, int c, int trips_) -> float {
-            const int c4n = mct[m];
-            const float4* wv = reinterpret_cast<const float4*>(melw + mof[m]);
-            const float4* vv = reinterpret_cast<const float4*>(val + c * NBP + mst[m]);
-            // two chunks per trip, both pairs of reads in flight before the first FMA (-6 %; four per trip: slower again) (the loop is a chain of LDS round trips otherwise);
-            // chunks past a lane's own count read its last chunk and are multiplied by zero weights' stand-in: skipped by the mask
-            float acc0 = 0.f, acc1 = 0.f;
-            for (int i = 0; i < trips_; i += 2) {
-                const bool p0 = i < c4n, p1 = i + 1 < c4n;
-                const int i0 = p0 ? i : 0, i1 = p1 ? i + 1 : 0;
-                const float4 w0 = wv[i0], x0 = vv[i0], w1 = wv[i1], x1 = vv[i1];
-                if (p0) { acc0 = fmaf(w0.x, x0.x, acc0); acc0 = fmaf(w0.y, x0.y, acc0); acc0 = fmaf(w0.z, x0.z, acc0); acc0 = fmaf(w0.w, x0.w, acc0); }
-                if (p1) { acc1 = fmaf(w1.x, x1.x, acc1); acc1 = fmaf(w1.y, x1.y, acc1); acc1 = fmaf(w1.z, x1.z, acc1); acc1 = fmaf(w1.w, x1.w, acc1); }
+        FEAT_TR(5)
+        // The mel projection on the matrix cores, in fp32: v_mfma_f32_4x4x1_16B_f32 is SIXTEEN independent 4 x 4 x 1 products, one per
+        // group of four lanes.  A "slot" = four mels x sixteen consecutive bins (sixteen steps of K = 1): mel group g (mels 4 g .. 4 g + 3,
+        // whose filters overlap: a run of ~2.5 filter lengths) is cut into ceil(run / 16) slots, and the slots of all groups are dealt to
+        // the 16 blocks of QSEQ successive sequences (64-mel, 513-bin bank: 41 slots, 3 sequences, 48 instructions per round; one block
+        // per group would take 132: the top group alone runs 132 bins).  A = the four planes at the slot's bins (row i = lane & 3 =
+        // channel), B = the slot's weights (column j = lane & 3 = mel 4 g + j; 64 bytes per slot and mel), D[channel r][mel j] in VGPR r.
+        // The slots' sums then meet through LDS, added per mel in slot order (see below).
+        // Measured, same box (8 x 60 s per launch): 41.0 -> 44.6 k clips/s with the top_db early exit.  The per-lane sparse dot products
+        // this replaces were ~2 000 of a frame's ~5 500 vector instructions; the f16 form of the same blocks (4 x 4 x 4, hi / lo terms,
+        // 36 instructions per round) was slower: the hi / lo planes cost 16-bit LDS writes that took longer than the products saved.
+        auto mel_round = [&]() -> f32x4 {
+            if (lane < 4 * (NBP - NB)) val[(lane / (NBP - NB)) * NBP + NB + lane % (NBP - NB)] = 0.f;      // bins 513 .. 515 (a slot reads sixteen bins)
+            WAVE_LDS_FENCE();
+            f32x4 part[QSEQ];
+#pragma unroll
+            for (int q = 0; q < QSEQ; ++q) {
+                const uint4 e = mm[q * 64 + lane];                 // {the slot's first bin, its weights (16-byte units)}
+                const float4* pa = reinterpret_cast<const float4*>(val + (lane & 3) * NBP + e.x);
+                const float4* pw = reinterpret_cast<const float4*>(mm + e.y);
+                float4 a[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = pa[u]; w[u] = pw[u]; }
+                f32x4 d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    d[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, w[u].x, z, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].y, w[u].y, d[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].z, w[u].z, d[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, w[u].w, d[u], 0, 0, 0);
+                part[q] = (d[0] + d[1]) + (d[2] + d[3]);
             }
-            return acc0 + acc1;
+            // the slots' sums -> LDS, slot by slot (the planes are done with); every lane (= mel) then adds up the slots of its group, in
+            // slot order.  (LDS float atomics into the output row instead: 12 instructions, and the kernel took 1.8 x as long.)
+            WAVE_LDS_FENCE();
+            f32x4* ps = reinterpret_cast<f32x4*>(val);
+#pragma unroll
+            for (int q = 0; q < QSEQ; ++q) ps[q * 64 + lane] = part[q];
+            WAVE_LDS_FENCE();
+            const uint4 ge = mm[QSEQ * 64 + lane];                 // {4 x the first slot of the lane's mel group + (lane & 3), the number of its slots}
+            const f32x4* pg = ps + ge.x;
+            f32x4 acc = pg[0];
+#pragma unroll
+            for (int j = 1; j < 12; ++j) {
+                if (j >= mm_pmax) break;
+                if (j < (int)ge.y) acc += pg[4 * j];
+            }
+            WAVE_LDS_FENCE();
+            return acc;
         };
         float* frame_out = out + (size_t)t * n_mels * C_OUT;
-        for (int q = 0; 64 * q < 4 * n_mels; ++q) {
-            const int idx = lane + 64 * q;
-            const int tr = __builtin_amdgcn_readfirstlane(trips[q]);
-            if (idx < 4 * n_mels) {
-                const float md = mel_dot(idx >> 2, idx & 3, tr);
-                const float o = 3.0102999566f * __builtin_amdgcn_logf(fmaxf(md, 1e-10f));
-                lmax = fmaxf(lmax, o);
-                stage[(idx >> 2) * C_OUT + (idx & 3)] = o;
+        {
+            const f32x4 d = mel_round();
+            if (lane < n_mels) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = 3.0102999566f * __builtin_amdgcn_logf(fmaxf(d[r], 1e-10f));
+                    lmax = fmaxf(lmax, o);
+                    lmin = fminf(lmin, o);
+                    stage[lane * C_OUT + r] = o;
+                }
             }
         }
-        WAVE_LDS_FENCE();
+        FEAT_TR(6)
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
             const int k = dft_bin(i, lane);
@@ -784,44 +841,57 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             }
         }
         WAVE_LDS_FENCE();
-        for (int q = 0; 64 * q < 3 * n_mels; ++q) {
-            const int idx = lane + 64 * q;
-            const int tr = __builtin_amdgcn_readfirstlane(trips[8 + q]);
-            if (idx < 3 * n_mels) stage[(idx / 3) * C_OUT + 4 + idx % 3] = mel_dot(idx / 3, idx % 3, tr);
+        {
+            const f32x4 d = mel_round();
+            if (lane < n_mels) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) stage[lane * C_OUT + 4 + r] = d[r];
+            }
         }
         WAVE_LDS_FENCE();
-        // whole 128-byte lines, written once: with seven scattered dword stores per frame the lines of a batch's 43 MB of output were
-        // evicted half-written and went to HBM in pieces (PMC: 16.4 MB written per clip for 5.4 MB of output)
+        FEAT_TR(7)
         for (int j = lane; j < n_mels * C_OUT / 4; j += 64) reinterpret_cast<float4*>(frame_out)[j] = reinterpret_cast<const float4*>(stage)[j];
         WAVE_LDS_FENCE();
+        FEAT_TR(8)
     }
     lmax = wave_max_dpp(lmax);
+    lmin = -wave_max_dpp(-lmin);           // the clip's minimum too: when it is above max - top_db the clamp pass has nothing to do
     __syncthreads();
-    if (lane_id == 0) reinterpret_cast<float*>(trips)[wave] = lmax;
+    if (lane_id == 0) { red[wave] = lmax; red[16 + wave] = lmin; }
     __syncthreads();
     if (tid == 0) {
-        float m = -INFINITY;
-        for (int w = 0; w < DFT_WAVES; ++w) m = fmaxf(m, reinterpret_cast<float*>(trips)[w]);
+        float m = -INFINITY, n = INFINITY;
+        for (int w = 0; w < DFT_WAVES; ++w) { m = fmaxf(m, red[w]); n = fminf(n, red[16 + w]); }
         gmax[blockIdx.x] = m;
+        gmin[blockIdx.x] = n;
     }
 }
 
 // top_db clamp: x_db = max(x_db, max over the clip - top_db) on the four dB channels.  Every workgroup first reduces the
 // per-workgroup maxima the extraction kernel left in gmax[0 .. nparts), then walks its share of the [T * n_mels] rows.
-__global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out, const float* __restrict__ gmax, int nparts,
-                                                         int64_t n_tm, int c_out, float top_db) {
-    __shared__ float red[256];
-    float m = -INFINITY;
+// gmin (feat_dft_kernel's per-workgroup minima; nullptr after the other extraction kernels): a clip whose smallest dB value is
+// already at or above the floor is left alone without being read again (every clip of the bench's noise input; quiet passages of a
+// real recording do reach the floor, and then the pass runs).
+__global__ __launch_bounds__(256) void feat_topdb_kernel(float* __restrict__ out, const float* __restrict__ gmax, const float* __restrict__ gmin,
+                                                         int nparts, int64_t n_tm, int c_out, float top_db) {
+    __shared__ float red[256], redn[256];
+    float m = -INFINITY, n = gmin ? INFINITY : -INFINITY;
     gmax += (size_t)blockIdx.y * nparts;          // blockIdx.y = clip of a batch
     out += (size_t)blockIdx.y * n_tm * c_out;
     for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, gmax[i]);
+    if (gmin) for (int i = threadIdx.x; i < nparts; i += 256) n = fminf(n, gmin[(size_t)blockIdx.y * nparts + i]);
     red[threadIdx.x] = m;
+    redn[threadIdx.x] = n;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
-        if (threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+        if (threadIdx.x < w) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+            redn[threadIdx.x] = fminf(redn[threadIdx.x], redn[threadIdx.x + w]);
+        }
         __syncthreads();
     }
     const float floor_db = red[0] - top_db;
+    if (redn[0] >= floor_db) return;               // uniform over the workgroup; NaNs compare false and take the pass
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tm * 4; i += (int64_t)gridDim.x * 256) {
         float* p = out + (i >> 2) * c_out + (int)(i & 3);
         if (*p < floor_db) *p = floor_db;          // a read-only pass unless a value is actually below the floor (-1 us per clip)
@@ -972,7 +1042,7 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
     ok &= hipMalloc(&f->mel_count, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_off, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_w, mw.size() * sizeof(float)) == hipSuccess;
-    ok &= hipMalloc(&f->gmax, FEAT_MAX_PARTS * sizeof(float)) == hipSuccess;
+    ok &= hipMalloc(&f->gmax, 2 * FEAT_MAX_PARTS * sizeof(float)) == hipSuccess;      // maxima | minima
     ok &= hipMalloc(&f->mel_start4, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_cnt4, n_mels * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->mel_off4, n_mels * sizeof(int)) == hipSuccess;
@@ -1024,6 +1094,61 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
         if (hipMalloc(&f->dft_tab, DFT_TAB_BYTES) != hipSuccess) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
         hipMemcpy(f->dft_tab, tab.data(), DFT_TAB_BYTES, hipMemcpyHostToDevice);
     }
+    if (mode == 0 && n_fft == 1024 && n_mels <= 64) {
+        // the mel projection as 4 x 4 x 4 blocks (see feat_dft_kernel's mel_round): group g = mels 4 g .. 4 g + 3 runs over bins
+        // [gs, ge), gs a multiple of 4, cut into slots of four steps of four bins; slot v goes to block v & 15 of sequence v >> 4
+        struct Slot { int g, bin; };
+        std::vector<Slot> slots;
+        for (int g = 0; g < 16; ++g) {
+            int gs = 1 << 30, ge = 0;
+            for (int m = 4 * g; m < 4 * g + 4 && m < n_mels; ++m)
+                if (mcount[m]) { gs = std::min(gs, mstart[m] & ~3); ge = std::max(ge, mstart[m] + mcount[m]); }
+            for (int b0 = gs; b0 < ge; b0 += 16) slots.push_back({g, std::min(b0, 500)});      // sixteen bins from b0; the planes end at bin 515
+        }
+        const int n_seq = std::max(1, ((int)slots.size() + 15) / 16);
+        if (n_seq <= 4 && slots.size() * 64 <= 4 * 516 * 4) {     // (the slots' sums use the planes' space)
+            std::vector<unsigned> mmv((size_t)(n_seq + 1) * 64 * 4, 0u);
+            const unsigned zero_w = (unsigned)mmv.size() / 4;
+            mmv.resize(mmv.size() + 4 * 4, 0u);                      // sixteen zero weights: the idle blocks'
+            for (int q = 0; q < n_seq; ++q)
+                for (int lane = 0; lane < 64; ++lane) { unsigned* e = &mmv[(q * 64 + lane) * 4]; e[0] = 0; e[1] = zero_w; }
+            int prev_g = -1, prev_end = 0;
+            for (size_t v = 0; v < slots.size(); ++v) {
+                const Slot& sl = slots[v];
+                const int from = (sl.g == prev_g) ? std::max(sl.bin, prev_end) : sl.bin;      // (a slot moved down to bin 500 must not count bins twice)
+                prev_g = sl.g; prev_end = sl.bin + 16;
+                const unsigned base = (unsigned)mmv.size() / 4;
+                for (int n = 0; n < 4; ++n)
+                    for (int k = 0; k < 16; ++k) {
+                        const int m = 4 * sl.g + n, bin = sl.bin + k;
+                        const float w = (m < n_mels && bin >= from && bin >= mstart[m] && bin < mstart[m] + mcount[m]) ? mw[moff[m] + bin - mstart[m]] : 0.f;
+                        unsigned u; memcpy(&u, &w, 4);
+                        mmv.push_back(u);
+                    }
+                for (int n = 0; n < 4; ++n) {
+                    unsigned* e = &mmv[(((v >> 4) * 64) + (v & 15) * 4 + n) * 4];
+                    e[0] = (unsigned)sl.bin; e[1] = base + 4u * (unsigned)n;
+                }
+            }
+            int pmax = 1;
+            for (int g = 0; g < 16; ++g) {
+                int first = -1, cnt = 0;
+                for (size_t v = 0; v < slots.size(); ++v) if (slots[v].g == g) { if (first < 0) first = (int)v; ++cnt; }
+                pmax = std::max(pmax, cnt);
+                for (int n = 0; n < 4; ++n) {
+                    unsigned* e = &mmv[((size_t)n_seq * 64 + 4 * g + n) * 4];
+                    e[0] = (unsigned)(4 * std::max(first, 0) + n); e[1] = (unsigned)std::max(cnt, 1);      // (a group without mels: any slot, never stored)
+                }
+            }
+            if (pmax <= 12) {                                        // (the gather loop's bound)
+                f->n_mel_mm = (int)mmv.size() / 4;
+                f->mel_mm_seq = n_seq;
+                f->mel_mm_pmax = pmax;
+                if (hipMalloc(&f->mel_mm, mmv.size() * sizeof(unsigned)) != hipSuccess) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
+                hipMemcpy(f->mel_mm, mmv.data(), mmv.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+            }
+        }
+    }
     f->n_melw4 = (int)mw4.size();
     hipMemcpy(f->trips, trips.data(), 16 * sizeof(int), hipMemcpyHostToDevice);
     f->maxc4 = maxc4;
@@ -1036,7 +1161,7 @@ void seld_feat_destroy(seld_feat* f) {
     hipSetDevice(f->device);
     hipDeviceSynchronize();
     hipFree(f->win); hipFree(f->tw); hipFree(f->mel_start); hipFree(f->mel_count); hipFree(f->mel_off); hipFree(f->mel_w);
-    hipFree(f->gmax); hipFree(f->dft_tab);
+    hipFree(f->gmax); hipFree(f->dft_tab); hipFree(f->mel_mm);
     hipFree(f->mel_start4); hipFree(f->mel_cnt4); hipFree(f->mel_off4); hipFree(f->mel_w4); hipFree(f->trips);
     delete f;
 }
@@ -1057,7 +1182,7 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     if (n_clips > f->gmax_clips) {          // per-clip maxima: [clips][FEAT_MAX_PARTS]
         hipSetDevice(f->device);
         float* g = nullptr;
-        if (hipMalloc(&g, (size_t)n_clips * FEAT_MAX_PARTS * sizeof(float)) != hipSuccess) return ffail(f, SELD_ERR_NOMEM, "feat_extract_batch: maxima buffer");
+        if (hipMalloc(&g, (size_t)2 * n_clips * FEAT_MAX_PARTS * sizeof(float)) != hipSuccess) return ffail(f, SELD_ERR_NOMEM, "feat_extract_batch: maxima buffer");
         hipStreamSynchronize((hipStream_t)stream);
         hipFree(f->gmax);
         f->gmax = g; f->gmax_clips = n_clips;
@@ -1068,23 +1193,30 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     const int N = f->n_fft, NBP = N / 2 + 1 + 3;
     const int64_t T = 1 + n_samples / f->hop;
     int nparts = 0;
-    bool launched = false;
+    bool launched = false, have_min = false;
     // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
-    if (f->dft_tab && f->use_dft && f->use_wave_kernel && f->n_mels <= 128 && (f->n_mels & 3) == 0 && n_samples < (int64_t)1 << 30) {
-        // foa, n_fft 1024: the transform on the matrix cores (feat_dft_kernel)
-        size_t tables = (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) + (size_t)(2 * f->n_mels + ((f->n_mels + 3) & ~3) + 16) * sizeof(int);
-        tables = ((tables + 15) & ~(size_t)15) + DFT_TAB_BYTES;
-        const size_t wb = (((size_t)4 * (N / 2 + 4) + (size_t)f->n_mels * 7) * sizeof(float) + 15) & ~(size_t)15;      // the four per-bin planes of a wave + its staged output frame
+    // foa, n_fft 1024, n_mels <= 64: the transform AND the mel projection on the matrix cores (feat_dft_kernel)
+    const size_t dft_tables = (size_t)N * sizeof(float) + 32 * sizeof(float) + (size_t)f->n_mel_mm * 16 + DFT_TAB_BYTES;
+    const size_t dft_wb = (((size_t)4 * (N / 2 + 4) + (size_t)f->n_mels * 7 + 8) * sizeof(float) + 15) & ~(size_t)15;      // (+ 8: where idle blocks add their zeros)
+    if (f->dft_tab && f->mel_mm && f->use_dft && f->use_wave_kernel && (f->n_mels & 3) == 0 && n_samples < (int64_t)1 << 30 &&
+        dft_tables + DFT_WAVES * dft_wb <= 160 * 1024) {
+        const size_t tables = dft_tables;
+        const size_t wb = dft_wb;                                   // the four per-bin planes of a wave + its staged output frame
         const size_t smem = tables + DFT_WAVES * wb;
         // persistent workgroups: one per CU over the whole batch (a workgroup loads 30 KB of tables; a wave that walks several frames
         // has the next frame's first channel in flight while it finishes the current one)
         int64_t blocks = (T + DFT_WAVES - 1) / DFT_WAVES;
         const int64_t per_clip = std::max<int64_t>(1, (256 + n_clips - 1) / n_clips);
         if (blocks > per_clip) blocks = per_clip;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(feat_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(feat_dft_kernel, dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * DFT_WAVES), smem, st, wav, n_samples, T, f->hop,
-                           f->n_mels, f->n_melw4, f->win, f->dft_tab, f->mel_start4, f->mel_cnt4, f->mel_off4, f->mel_w4, out, f->gmax, (int)wb, f->trips);
-        launched = true; nparts = (int)blocks;
+#define FEAT_DFT_CASE(Q_)                                                                                                       \
+        {                                                                                                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(feat_dft_kernel<Q_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);       \
+            hipLaunchKernelGGL(feat_dft_kernel<Q_>, dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * DFT_WAVES), smem, st, wav, n_samples, T, f->hop, \
+                               f->n_mels, f->win, f->dft_tab, f->mel_mm, f->n_mel_mm, f->mel_mm_pmax, out, f->gmax, f->gmax + (size_t)f->gmax_clips * FEAT_MAX_PARTS, (int)wb); \
+        }
+        if (f->mel_mm_seq == 1) FEAT_DFT_CASE(1) else if (f->mel_mm_seq == 2) FEAT_DFT_CASE(2) else if (f->mel_mm_seq == 3) FEAT_DFT_CASE(3) else FEAT_DFT_CASE(4)
+#undef FEAT_DFT_CASE
+        launched = true; nparts = (int)blocks; have_min = true;
     }
     if (!launched && f->logn >= 8 && f->logn <= 10 && f->use_wave_kernel && f->n_mels <= 128 && f->n_mels <= N) {
         const size_t tables = (size_t)(N / 2) * sizeof(float2) + (size_t)N * sizeof(float) + (size_t)f->n_melw4 * sizeof(float) +
@@ -1124,8 +1256,8 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     }
     const int64_t n_tm = T * f->n_mels;
     int64_t tb = (n_tm * 4 + 255) / 256;
-    if (tb > 1024) tb = 1024;
-    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)tb, (unsigned)n_clips), dim3(256), 0, st, out, f->gmax, nparts, n_tm, f->mode == 0 ? 7 : 10, 80.f);
+    if (tb > std::max<int64_t>(32, 2048 / n_clips)) tb = std::max<int64_t>(32, 2048 / n_clips);     // (mostly an early exit: keep the grid small)
+    hipLaunchKernelGGL(feat_topdb_kernel, dim3((unsigned)tb, (unsigned)n_clips), dim3(256), 0, st, out, f->gmax, have_min ? f->gmax + (size_t)f->gmax_clips * FEAT_MAX_PARTS : nullptr, nparts, n_tm, f->mode == 0 ? 7 : 10, 80.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ffail(f, SELD_ERR_HIP, std::string("feat_extract: ") + hipGetErrorString(e));
     return SELD_OK;
@@ -1145,3 +1277,9 @@ int seld_feat_normalize(const float* feat, const float* mean, const float* stdv,
 }
 
 }  // extern "C"
+
+#ifdef FEAT_TRACE
+extern "C" int seld_feat_trace_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_feat_trace), sizeof(unsigned long long) * DFT_WAVES * 2 * 10) == hipSuccess ? 0 : 1;
+}
+#endif

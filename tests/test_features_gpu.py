@@ -44,6 +44,21 @@ def test_extract_features(seld_lib, mode, sr, kw, wave_kernel):
     check(f"{mode} spatial channels [{sr}]", got[..., 4:], ref[..., 4:])
 
 
+@pytest.mark.parametrize("n_mels", [32, 40, 64])
+def test_matrix_core_mel_projection_other_bank_sizes(seld_lib, n_mels):
+    """foa, n_fft 1024: the mel projection runs as 4 x 4 x 1 matrix-core blocks whose slot table is built from the filter bank
+    (features.hip, mel_round): banks that leave blocks idle (32, 40 mels) against the fp64 oracle as well."""
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    wav = _wav(24000 * 2 + 55, seed=11)
+    ref = FO.extract_features(wav, 24000, mode="foa", n_mels=n_mels, dtype=torch.float64, **kw)
+    got = FE.FeatureExtractor(24000, "foa", n_mels, **kw)(wav).cpu().numpy()
+    assert got.shape == ref.shape
+    check(f"log-mel [{n_mels} mels]", got[..., :4], ref[..., :4])
+    check(f"intensity [{n_mels} mels]", got[..., 4:], ref[..., 4:])
+
+
 def test_zeros_like_reference_smoke(seld_lib):
     """feature_extractor_test.py:24-34: zeros[4,32000] @16 kHz -> ndim 3, 7 | 10 channels."""
     from seld_amd import feature_extractor as FE
@@ -74,6 +89,27 @@ def test_full_clip_and_normalize(seld_lib):
     check("normalised", out.cpu().numpy(), FO.apply_normalizer(ref[:3000], mean, std))
     with pytest.raises(ValueError):
         FE.FeatureExtractor(24000, "stereo")
+
+
+def test_top_db_clamp_taken_and_skipped_per_clip(seld_lib):
+    """The top_db pass (librosa power_to_db, top_db 80; feature_extractor.py:294-301) runs per clip only when the clip's smallest dB
+    value is below max - 80: one batch holds a clip with a silent half (clamp active: -100 dB -> max - 80) next to a noise clip
+    (nothing below the floor: the pass is skipped) — both against the fp64 oracle."""
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    n = 24000 + 77
+    half = _wav(n, seed=5)
+    half[:, n // 2:] = 0.0
+    wavs = np.stack([half, _wav(n, seed=6), half * 0.01])
+    fx = FE.FeatureExtractor(24000, "foa", 64, **kw)
+    got = fx.batch(wavs).cpu().numpy()
+    for i in range(3):
+        ref = FO.extract_features(wavs[i], 24000, mode="foa", dtype=torch.float64, **kw)
+        check(f"clip {i} log-mel", got[i][..., :4], ref[..., :4])
+        check(f"clip {i} intensity", got[i][..., 4:], ref[..., 4:])
+    assert got[0][..., :4].min() == pytest.approx(got[0][..., :4].max() - 80.0, abs=1e-3)     # the clamp was applied
+    assert got[1][..., :4].min() > got[1][..., :4].max() - 80.0                                # and was not needed here
 
 
 @pytest.mark.parametrize("mode", ["foa", "mic"])
