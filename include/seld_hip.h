@@ -78,6 +78,16 @@ typedef struct seld_arch {
      * SELD_ACT_SIGMOID, SELD_ACT_TANH, SELD_ACT_RELU. */
     int32_t sed_dense_act;
     int32_t doa_dense_act;
+    /* simple_dense_block's `kernel_size` (modules.py:355, 370-372: Conv1D(units, kernel_size, padding='same') over the frames of a clip;
+     * 0 or 1 = per-step, seldnet.json) and `dropout_rate` (modules.py:357, 373-374: Dropout after every hidden layer, training only) of the
+     * two heads.  The dropout masks are a counter-based function of (option "dropout_seed", the training step counter, layer, element):
+     * see loss_adam.hip::dropout_kernel; TensorFlow's generator cannot be reproduced by another program. */
+    int32_t sed_kernel_size;
+    int32_t doa_kernel_size;
+    float sed_dropout;
+    float doa_dropout;
+    /* 1 = models.seldnet_v1 (models.py:36-52; model_config/seldnet_v1.json): doa_out = tanh(doa * Concatenate([sed] * 3)). */
+    int32_t output_coupling;
 } seld_arch;
 #define SELD_ACT_NONE 0
 #define SELD_ACT_SIGMOID 1

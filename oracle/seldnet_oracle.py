@@ -72,12 +72,22 @@ class Spec:
     rn_blocks: Tuple[int, ...] = ()    # resnet50_block: bottleneck blocks per stage (FIRST_ARGS.block_num)
     sed_dense_act: str | None = None   # simple_dense_block's dense_activation (modules.py:356): activation of the heads' hidden Conv1D layers
     doa_dense_act: str | None = None
+    sed_kernel_size: int = 1           # simple_dense_block's kernel_size (modules.py:355, 370-372): Conv1D('same') over the frames of a clip
+    doa_kernel_size: int = 1
+    sed_dropout: float = 0.0           # simple_dense_block's dropout_rate (modules.py:357, 373-374), training only
+    doa_dropout: float = 0.0
+    output_coupling: bool = False      # models.seldnet_v1 (models.py:36-52): doa_out = tanh(doa * Concatenate([sed] * 3))
+    dropout_seed: int = 0x5e1d5e1d5e1d5e1d   # the library's default (api.hip); option "dropout_seed" v -> 0x5e1d5e1d00000000 ^ v
 
     @staticmethod
     def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
         sp = Spec._from_config(model_config, in_ch, n_freq)
         sp.sed_dense_act = model_config["SED_ARGS"].get("dense_activation")
         sp.doa_dense_act = model_config["DOA_ARGS"].get("dense_activation")
+        sp.sed_kernel_size = int(model_config["SED_ARGS"].get("kernel_size", 1))
+        sp.doa_kernel_size = int(model_config["DOA_ARGS"].get("kernel_size", 1))
+        sp.sed_dropout = float(model_config["SED_ARGS"].get("dropout_rate", 0))
+        sp.doa_dropout = float(model_config["DOA_ARGS"].get("dropout_rate", 0))
         for a in (sp.sed_dense_act, sp.doa_dense_act):
             if a not in (None, "linear", "relu", "tanh", "sigmoid"):
                 raise ValueError(f"dense_activation {a!r} not restated")
@@ -167,12 +177,12 @@ def variable_specs(spec: Spec) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[
                    (f"gru{i}.{d}.recurrent_kernel", (u, 3 * u)),
                    (f"gru{i}.{d}.bias", (2, 3 * u))]
         feat = u
-    for head, units, nout in (("sed", spec.sed_units, spec.n_classes),
-                              ("doa", spec.doa_units, 3 * spec.n_classes)):
+    for head, units, nout, ks in (("sed", spec.sed_units, spec.n_classes, spec.sed_kernel_size),
+                                  ("doa", spec.doa_units, 3 * spec.n_classes, spec.doa_kernel_size)):
         fin = feat
         for j, u in enumerate(units):
-            # Conv1D(kernel_size=1) kernel is rank 3 in Keras: [1, in, out]
-            tr += [(f"{head}.dense{j}.kernel", (1, fin, u)), (f"{head}.dense{j}.bias", (u,))]
+            # a Conv1D kernel is rank 3 in Keras: [kernel_size, in, out] (seldnet.json: kernel_size 1)
+            tr += [(f"{head}.dense{j}.kernel", (ks, fin, u)), (f"{head}.dense{j}.bias", (u,))]
             fin = u
         tr += [(f"{head}.out.kernel", (fin, nout)), (f"{head}.out.bias", (nout,))]
     return tr, nt
@@ -300,8 +310,44 @@ def bigru_mul(x, w, prefix):
 
 
 # --------------------------------------------------------------------------- model
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC11; Random123): uint64 arrays holding 32-bit
+    counter / key words -> the four output words.  tests/test_oracle_cpu.py checks the published known-answer vectors."""
+    m32 = np.uint64(0xffffffff)
+    c = [np.asarray(v, np.uint64) & m32 for v in (c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0) & m32, np.uint64(k1) & m32
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return c
+
+
+def philox_uniform(n: int, seed: int, layer: int, step: int) -> np.ndarray:
+    """The library's dropout uniforms (loss_adam.hip::dropout_kernel): word j of Philox4x32-10 at counter (i, layer, step, i >> 32) under the
+    key (seed & 0xffffffff, seed >> 32) is element 4 i + j; u = (word >> 8) * 2^-24.  Not TensorFlow's generator (no other program
+    reproduces that): the reference's Dropout (modules.py:373-374) fixes the distribution, this fixes the draws."""
+    n4 = (n + 3) // 4
+    i = np.arange(n4, dtype=np.uint64)
+    c = philox4x32_10(i, np.full(n4, layer, np.uint64), np.full(n4, step, np.uint64), i >> np.uint64(32), seed, seed >> 32)
+    words = np.stack(c, axis=1).reshape(-1)[:n]
+    return (words >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+
+
+def conv1d_same(a, kernel, bias):
+    """Conv1D(units, kernel_size, padding='same') over axis 1 of a [B, S, C] tensor (modules.py:370-372); kernel [ks, C, units].
+    TensorFlow's 'same': pad (ks - 1) // 2 frames in front, the rest behind."""
+    ks = kernel.shape[0]
+    if ks == 1:
+        return a @ kernel[0] + bias
+    S = a.shape[1]
+    ap = torch.nn.functional.pad(a, (0, 0, (ks - 1) // 2, ks - 1 - (ks - 1) // 2))
+    return sum(ap[:, j:j + S] @ kernel[j] for j in range(ks)) + bias
+
+
 def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor], x, training: bool,
-            taps: dict | None = None, routing: dict | None = None, record_routing: dict | None = None, bn_sync=None):
+            taps: dict | None = None, routing: dict | None = None, record_routing: dict | None = None, bn_sync=None,
+            dropout_step: int = 0):
     """models.seldnet forward (models.py:18-32). x [B,T,F,C] -> sed [B,S,nc], doa [B,S,3nc].
     Returns (sed, doa, new_state). `taps` (optional dict) receives intermediate tensors.
 
@@ -388,13 +434,18 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             taps[f"gru{i}"] = h
     outs = []
     hidden = {None: lambda t: t, "linear": lambda t: t, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
-    for head, units, act, hact in (("sed", spec.sed_units, torch.sigmoid, hidden[spec.sed_dense_act]),
-                                   ("doa", spec.doa_units, torch.tanh, hidden[spec.doa_dense_act])):
+    for hd, (head, units, act, hact, rate) in enumerate((("sed", spec.sed_units, torch.sigmoid, hidden[spec.sed_dense_act], spec.sed_dropout),
+                                                         ("doa", spec.doa_units, torch.tanh, hidden[spec.doa_dense_act], spec.doa_dropout))):
         a = h
         for j in range(len(units)):
-            # Conv1D(units, kernel_size=1, activation=dense_activation) == per-step dense (modules.py:356, 368-371)
-            a = hact(a @ w[f"{head}.dense{j}.kernel"][0] + w[f"{head}.dense{j}.bias"])
+            # Conv1D(units, kernel_size, padding='same', activation=dense_activation) [+ Dropout] (modules.py:355-357, 368-374)
+            a = hact(conv1d_same(a, w[f"{head}.dense{j}.kernel"], w[f"{head}.dense{j}.bias"]))
+            if training and rate > 0:
+                u = philox_uniform(a.numel(), spec.dropout_seed, 16 * hd + j, dropout_step).reshape(a.shape)
+                a = a * torch.as_tensor((u >= np.float32(rate)).astype(np.float64) / (1.0 - float(np.float32(rate))), dtype=a.dtype)
         outs.append(act(a @ w[f"{head}.out.kernel"] + w[f"{head}.out.bias"]))
+    if spec.output_coupling:                     # models.seldnet_v1 (models.py:48-50)
+        outs[1] = torch.tanh(outs[1] * torch.cat([outs[0]] * 3, dim=-1))
     return outs[0], outs[1], new_st
 
 
@@ -489,7 +540,7 @@ def test_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, doa_loss="MSE", d
 
 def train_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, *, doa_loss="MSE", loss_weight=(1.0, 1000.0),
                lr=1e-3, step=1, m=None, v=None, agc=False, dtype=torch.float32, want_taps=False, routing=None,
-               record_routing=None):
+               record_routing=None, dropout_step=0):
     """train.trainstep (train.py:22-36). Returns dict with outputs, losses, flat grads,
     updated flat weights / BN state / Adam slots."""
     tr, nt = variable_specs(spec)
@@ -498,7 +549,7 @@ def train_step(spec: Spec, flat_w, flat_state, x, y_sed, y_doa, *, doa_loss="MSE
     st = unflatten(_as_t(flat_state, dtype), nt)
     taps = {} if want_taps else None
     sed, doa, new_st = forward(spec, w, st, _as_t(x, dtype), training=True, taps=taps, routing=routing,
-                               record_routing=record_routing)
+                               record_routing=record_routing, dropout_step=dropout_step)
     obj, sloss, dloss = losses_and_objective(sed, doa, _as_t(y_sed, dtype), _as_t(y_doa, dtype), doa_loss, loss_weight)
     (g,) = torch.autograd.grad(obj, fw)
     with torch.no_grad():

@@ -42,7 +42,9 @@ class Arch(C.Structure):
                 ("n_sed_dense", C.c_int32), ("sed_units", C.c_int32 * MAX_LAYERS),
                 ("n_doa_dense", C.c_int32), ("doa_units", C.c_int32 * MAX_LAYERS), ("n_classes", C.c_int32),
                 ("first_kind", C.c_int32), ("xc_blocks", C.c_int32), ("rn_filters", C.c_int32), ("rn_blocks", C.c_int32 * 4),
-                ("sed_dense_act", C.c_int32), ("doa_dense_act", C.c_int32)]
+                ("sed_dense_act", C.c_int32), ("doa_dense_act", C.c_int32),
+                ("sed_kernel_size", C.c_int32), ("doa_kernel_size", C.c_int32), ("sed_dropout", C.c_float), ("doa_dropout", C.c_float),
+                ("output_coupling", C.c_int32)]
 
 
 class LossCfg(C.Structure):

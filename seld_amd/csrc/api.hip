@@ -34,7 +34,12 @@ struct GruL {
     float *gx[2], *sv[2], *h[2], *out, *din;   // din: gradient w.r.t. this layer's input
 };
 
-struct DenseL { int in, out; int64_t w_off, b_off; float* y; float* dy; };
+struct DenseL {
+    int in, out; int64_t w_off, b_off; float* y; float* dy;      // in = the product's K (= ks * in_base)
+    // simple_dense_block's hidden layers (modules.py:355-374): Conv1D kernel_size, Dropout rate; xe = the input rows laid side by side
+    // [rows][ks * in_base] (ks > 1), yd = the layer's output after dropout (rate > 0), drop_id = the layer's dropout stream
+    int ks = 1, in_base = 0; float rate = 0.f; float *xe = nullptr, *yd = nullptr; unsigned drop_id = 0;
+};
 
 // Conv2D(k in {1, 3}, strides (1, stride_f), use_bias=False) + BatchNormalization of resnet50_block (spec/RESNET50_BLOCK.md)
 struct RnConv {
@@ -137,6 +142,9 @@ struct seld_ctx {
     hipStream_t dp_stream = nullptr;
     hipEvent_t ev_dp_main = nullptr, ev_dp_done = nullptr;
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
+    float *doa_v1 = nullptr;                   // models.seldnet_v1 (models.py:36-52): tanh(doa * [sed | sed | sed]), the prediction the losses see
+    float *head_tmp = nullptr;                 // [rows][max ks * in_base]: a Conv1D head layer's input gradient before it is folded back over the taps
+    uint64_t dropout_seed = 0x5e1d5e1d5e1d5e1dull; unsigned dropout_step = 0; int last_training = 0;
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
     int fin_doa_loss = 0;
@@ -390,14 +398,18 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         int in = fin;
         for (int j = 0; j < nd; ++j) {
             if (units[j] <= 0 || (units[j] & 3)) { delete c; return fail(nullptr, SELD_ERR_UNSUPPORTED, "dense units must be a positive multiple of 4"); }
-            DenseL D; D.in = in; D.out = units[j];
+            DenseL D; D.out = units[j];
+            D.ks = std::max(1, hd == 0 ? a->sed_kernel_size : a->doa_kernel_size);
+            D.rate = hd == 0 ? a->sed_dropout : a->doa_dropout;
+            if (D.ks > 15 || !(D.rate >= 0.f && D.rate < 1.f)) { delete c; return fail(nullptr, SELD_ERR_UNSUPPORTED, "simple_dense_block: kernel_size 1..15, 0 <= dropout_rate < 1"); }
+            D.in_base = in; D.in = D.ks * in; D.drop_id = (unsigned)(16 * hd + j);
             char nm[64];
-            snprintf(nm, sizeof nm, "%s.dense%d.kernel", hn, j); D.w_off = off; add_var(c->tr, off, nm, {1, in, units[j]});
+            snprintf(nm, sizeof nm, "%s.dense%d.kernel", hn, j); D.w_off = off; add_var(c->tr, off, nm, {D.ks, in, units[j]});
             snprintf(nm, sizeof nm, "%s.dense%d.bias", hn, j);   D.b_off = off; add_var(c->tr, off, nm, {units[j]});
             c->heads[hd].layers.push_back(D);
             in = units[j];
         }
-        DenseL D; D.in = in; D.out = (hd == 0 ? 1 : 3) * a->n_classes;
+        DenseL D; D.in = D.in_base = in; D.out = (hd == 0 ? 1 : 3) * a->n_classes;
         char nm[64];
         snprintf(nm, sizeof nm, "%s.out.kernel", hn); D.w_off = off; add_var(c->tr, off, nm, {in, D.out});
         snprintf(nm, sizeof nm, "%s.out.bias", hn);   D.b_off = off; add_var(c->tr, off, nm, {D.out});
@@ -533,7 +545,17 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         }
     ALLOC(c->sync_buf, (resn ? 16 * 128 : 128) + 1);      // + this rank's element count, all-reduced with the sums
     for (int hd = 0; hd < 2; ++hd)
-        for (auto& D : c->heads[hd].layers) { ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out); }
+        for (auto& D : c->heads[hd].layers) {
+            ALLOC(D.y, rows * (size_t)D.out); ALLOC(D.dy, rows * (size_t)D.out);
+            if (D.ks > 1) ALLOC(D.xe, rows * (size_t)D.in);
+            if (D.rate > 0.f) ALLOC(D.yd, rows * (size_t)D.out);
+        }
+    {
+        size_t tmp = 0;
+        for (int hd = 0; hd < 2; ++hd) for (auto& D : c->heads[hd].layers) if (D.ks > 1) tmp = std::max(tmp, rows * (size_t)D.in);
+        if (tmp) ALLOC(c->head_tmp, tmp);
+        if (a->output_coupling) ALLOC(c->doa_v1, rows * (size_t)(3 * a->n_classes));
+    }
     {
         // pre-split bf16 planes: every GRU kernel and the heads' first layers, in the forward ([n][k]) and the
         // input-gradient ([in][out]) orientation
@@ -597,6 +619,8 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "heads_fused")) { c->heads_fused = value != 0; return SELD_OK; }
+    if (!strcmp(key, "dropout_seed")) { c->dropout_seed = 0x5e1d5e1d00000000ull ^ (uint64_t)(unsigned)value; return SELD_OK; }      // the masks are a function of (seed, step, layer, element)
+    if (!strcmp(key, "dropout_step")) { c->dropout_step = (unsigned)value; return SELD_OK; }                                         // the NEXT training forward's step counter
     if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
@@ -677,9 +701,17 @@ static void fork_side(seld_ctx* c) {
 // Which products run on the split-bf16 GEMM: shapes gemm_sb.hip handles (K % 32 == 0, N % 128 == 0); anything else stays
 // on the exact-fp32 MFMA GEMM.  The same predicates gate the forward product and its input gradient.
 static bool gru_sb(const seld_ctx* c, const GruL& G) { return c->gemm_split_bf16 && (G.in_feat % 128) == 0; }
+// simple_dense_block with kernel_size > 1 or dropout_rate > 0 on a hidden layer: the heads run layer by layer (no shared first product,
+// no W1 W2 fold)
+static bool heads_general(const seld_ctx* c) {
+    for (int hd = 0; hd < 2; ++hd)
+        for (const DenseL& D : c->heads[hd].layers) if (D.ks > 1 || D.rate > 0.f) return true;
+    return false;
+}
+
 static bool heads_sb(const seld_ctx* c) {
     const DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
-    return c->gemm_split_bf16 && c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out &&
+    return !heads_general(c) && c->gemm_split_bf16 && c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out &&
            (S0.in % 128) == 0 && (S0.out % 128) == 0;
 }
 
@@ -689,7 +721,7 @@ static bool heads_sb(const seld_ctx* c) {
 // F = feat^T dy and colsum(dy) (gemm.hip, heads_grad_kernel).  Same mathematics, different association of the fp32 sums.
 static bool heads_lin(const seld_ctx* c) {
     const Head &Hs = c->heads[0], &Hdo = c->heads[1];
-    if (!c->heads_fused || Hs.layers.size() != 2 || Hdo.layers.size() != 2 || Hs.hidden_act || Hdo.hidden_act) return false;   // W1 W2 folds only without an activation between them
+    if (!c->heads_fused || Hs.layers.size() != 2 || Hdo.layers.size() != 2 || Hs.hidden_act || Hdo.hidden_act || heads_general(c)) return false;   // W1 W2 folds only without an activation between them
     const DenseL &S0 = Hs.layers[0], &D0 = Hdo.layers[0];
     return S0.in == D0.in && S0.out == D0.out && Hs.layers[1].out + Hdo.layers[1].out <= 64 && (S0.in & 3) == 0 &&
            ((Hs.layers[1].out + Hdo.layers[1].out) & 3) == 0;
@@ -740,6 +772,13 @@ static int rn_c1_width(const RnBlock& R) { return R.c[1].w2 ? R.Wout / 2 : R.Wou
 static bool rn_c1_direct(const RnBlock& R) {
     const int W = rn_c1_width(R);
     return R.c[1].wsp9 && (!R.c[1].w2 || (R.Wout & 1) == 0) && (W == 16 || W == 8 || W == 4);
+}
+
+// models.seldnet_v1 (models.py:36-52): doa <- tanh(doa * [sed | sed | sed]) after the two heads; the plain model returns as it is
+static int heads_couple(seld_ctx* c, float* doa, int rows) {
+    if (c->arch.output_coupling)
+        launch_v1_couple_fwd(c->stream, c->heads[0].layers.back().y, c->heads[1].layers.back().y, c->doa_v1, doa, rows, c->arch.n_classes);
+    return check_launch(c, "forward");
 }
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
@@ -1041,13 +1080,35 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // the first layers of the two heads read the same features: one launch when their shapes agree (seldnet.json:
         // Conv1D(128) in both) and neither is the head's output layer
         DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
+        c->last_training = training;
         if (heads_lin(c)) {
             DenseL &S1 = c->heads[0].layers[1], &D1 = c->heads[1].layers[1];
             const int nt = S1.out + D1.out;
             if (launch_gemm_heads(st, feat, S0.in, c->weff, c->weff + (size_t)S0.in * nt, S1.y, D1.y, sed, doa, rows, S1.out, D1.out,
                                   S0.in, c->heads[0].act, c->heads[1].act))
                 return fail(c, SELD_ERR_UNSUPPORTED, "gemm_heads");
-            return check_launch(c, "forward");
+            return heads_couple(c, doa, rows);
+        }
+        if (heads_general(c)) {
+            // layer by layer: [rows laid side by side ->] product + bias + activation [-> dropout]
+            for (int hd = 0; hd < 2; ++hd) {
+                const float* a = feat;
+                Head& Hd = c->heads[hd];
+                float* outp = hd == 0 ? sed : doa;
+                for (size_t j = 0; j < Hd.layers.size(); ++j) {
+                    DenseL& D = Hd.layers[j];
+                    const bool lastl = (j + 1 == Hd.layers.size());
+                    if (D.ks > 1) { launch_time_expand(st, a, D.xe, c->B, c->S, D.in_base, D.ks); a = D.xe; }
+                    launch_gemm_mirror(st, a, D.in, c->params + D.w_off, D.out, c->params + D.b_off, D.y, lastl ? outp : nullptr, D.out,
+                                       rows, D.out, D.in, 0, lastl ? Hd.act : Hd.hidden_act);
+                    a = D.y;
+                    if (!lastl && D.rate > 0.f && training) {
+                        launch_dropout(st, D.y, D.yd, (int64_t)rows * D.out, D.rate, c->dropout_seed, D.drop_id, c->dropout_step);
+                        a = D.yd;
+                    }
+                }
+            }
+            return heads_couple(c, doa, rows);
         }
         const bool merged0 = c->heads[0].layers.size() > 1 && c->heads[1].layers.size() > 1 && S0.in == D0.in && S0.out == D0.out &&
                              c->heads[0].hidden_act == c->heads[1].hidden_act;      // one launch, one epilogue activation
@@ -1074,7 +1135,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             }
         }
     }
-    return check_launch(c, "forward");
+    return heads_couple(c, doa, rows);
 }
 
 int seld_forward(seld_ctx* c, const float* x, float* sed, float* doa, int training) {
@@ -1104,11 +1165,15 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
     // fused linear heads: both pre-activation gradients side by side in one [rows][n_sed + n_doa] buffer (the K axis of dfeat)
     const bool lin = heads_lin(c);
     const int n0 = c->heads[0].layers.back().out, nt = n0 + c->heads[1].layers.back().out;
-    launch_losses(st, c->heads[0].layers.back().y, c->heads[1].layers.back().y, y_sed, y_doa, cfg->doa_loss, cfg->w_sed,
+    launch_losses(st, c->heads[0].layers.back().y, c->arch.output_coupling ? c->doa_v1 : c->heads[1].layers.back().y, y_sed, y_doa, cfg->doa_loss, cfg->w_sed,
                   cfg->w_doa, cfg->sed_grad_scale, c->den_dev, sl, dl,
                   want_grads ? (lin ? c->dy_all : c->heads[0].layers.back().dy) : nullptr,
                   want_grads ? (lin ? c->dy_all + n0 : c->heads[1].layers.back().dy) : nullptr, c->loss_scratch, c->B, c->S, nc,
                   lin ? nt : 0, lin ? nt : 0, defer_finalize ? 1 : 0);
+    // seldnet_v1: the losses left d / d(doa sed) in the DOA slot; through the product to the two heads' pre-activations
+    if (want_grads && c->arch.output_coupling)
+        launch_v1_couple_bwd(st, c->heads[0].layers.back().y, c->heads[1].layers.back().y, lin ? c->dy_all : c->heads[0].layers.back().dy,
+                             lin ? nt : n0, lin ? c->dy_all + n0 : c->heads[1].layers.back().dy, lin ? nt : nt - n0, rows, nc);
     if (defer_finalize) { c->fin_sl = sl; c->fin_dl = dl; c->fin_doa_loss = cfg->doa_loss; }
     return check_launch(c, "losses");
 }
@@ -1219,6 +1284,38 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_gemm(st, c->dy_all, nt, c->weff, nt, nullptr, dfeat, K, rows, K, nt, 1, 0, 0);
             // their weight gradients (side stream) are enqueued behind the fork that follows the last GRU layer's BPTT: one
             // cross-stream event (a ~7 us bubble on the main stream) fewer
+        } else if (heads_general(c)) {
+            for (int hd = 0; hd < 2; ++hd) {
+                Head& Hd = c->heads[hd];
+                for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
+                    DenseL& D = Hd.layers[j];
+                    float* din = j == 0 ? dfeat : Hd.layers[j - 1].dy;
+                    const int accumulate = (j == 0 && hd == 1) ? 1 : 0;
+                    if (D.ks > 1) {
+                        launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, c->head_tmp, D.in, rows, D.in, D.out, 1, 0, 0);
+                        launch_time_fold(st, c->head_tmp, din, c->B, c->S, D.in_base, D.ks, accumulate);
+                    } else {
+                        launch_gemm(st, D.dy, D.out, c->params + D.w_off, D.out, nullptr, din, D.in, rows, D.in, D.out, 1, 0, accumulate);
+                    }
+                    if (j > 0) {
+                        const DenseL& P = Hd.layers[j - 1];
+                        const int64_t n = (int64_t)rows * P.out;
+                        // the previous layer's dropout (the mask recomputed from the counters of the forward pass), then its activation
+                        if (P.rate > 0.f && c->last_training) launch_dropout(st, din, din, n, P.rate, c->dropout_seed, P.drop_id, c->dropout_step);
+                        if (Hd.hidden_act) launch_act_bwd(st, P.y, din, n, Hd.hidden_act);
+                    }
+                }
+            }
+            fork_side(c);
+            for (int hd = 0; hd < 2; ++hd) {
+                Head& Hd = c->heads[hd];
+                for (int j = (int)Hd.layers.size() - 1; j >= 0; --j) {
+                    DenseL& D = Hd.layers[j];
+                    const float* ain = D.ks > 1 ? D.xe
+                                     : (j == 0 ? Glast.out : (Hd.layers[j - 1].rate > 0.f && c->last_training ? Hd.layers[j - 1].yd : Hd.layers[j - 1].y));
+                    wgrad_dense(c, c->side, c->tn_slab_side, ain, D.in, D.dy, D.out, rows, D.in, D.out, D.w_off, D.b_off, 0, 0);
+                }
+            }
         } else {
         // the gradient w.r.t. the shared features is the sum over the two heads' first layers: one product over the
         // concatenated K axis when their shapes agree (out % 32 == 0), otherwise two launches with accumulation
@@ -1551,6 +1648,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
     // join: the side stream's weight gradients must be complete before Adam / the DP all-reduce
     hipEventRecord(c->ev_join, c->side);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (c->last_training) ++c->dropout_step;          // the next training step draws new dropout masks
     return check_launch(c, "backward");
 }
 

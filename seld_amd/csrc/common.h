@@ -277,6 +277,13 @@ int launch_mul(hipStream_t st, const float* a, const float* b, float* out, int64
 
 struct seld_loss_cfg;
 int launch_act_bwd(hipStream_t st, const float* y, float* dy, int64_t n, int act);   // loss_adam.hip: dy *= act'(.) from y = act(.)
+// loss_adam.hip: Conv1D('same') over a clip's frames as a dense product (rows laid side by side), its transpose, and counter-based dropout
+int launch_time_expand(hipStream_t st, const float* x, float* xe, int B, int S, int C, int ks);
+int launch_time_fold(hipStream_t st, const float* dxe, float* dx, int B, int S, int C, int ks, int accumulate);
+int launch_dropout(hipStream_t st, const float* in, float* out, int64_t n, float rate, uint64_t seed, unsigned layer, unsigned step);
+// loss_adam.hip: models.seldnet_v1's output coupling tanh(doa * [sed | sed | sed]) and its gradient (in place on the losses' gradients)
+int launch_v1_couple_fwd(hipStream_t st, const float* sed, const float* doa1, float* out, float* out2, int rows, int nc);
+int launch_v1_couple_bwd(hipStream_t st, const float* sed, const float* doa1, float* dsed_pre, int ld_sed, float* ddoa_pre, int ld_doa, int rows, int nc);
 int launch_mmse_den(hipStream_t st, const float* y_doa, float* den, float* scratch, int rows, int nc);
 int launch_losses(hipStream_t st, const float* sed, const float* doa, const float* y_sed, const float* y_doa,
                   int doa_loss, float w_sed, float w_doa, float sed_grad_scale, const float* den_dev,

@@ -624,7 +624,6 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
     const uint4* __restrict__ dft_g, const uint4* __restrict__ mm_g, int n_mm, int mm_pmax, float* __restrict__ out, float* __restrict__ gmax,
     float* __restrict__ gmin, int wave_bytes) {
     constexpr int N = 1024, NB = 513, NBP = 516, NBI = 9, C_OUT = 7;
-    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* win = smem;                                             // [N]

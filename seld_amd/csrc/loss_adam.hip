@@ -255,3 +255,128 @@ int launch_act_bwd(hipStream_t st, const float* y, float* dy, int64_t n, int act
                        reinterpret_cast<float4*>(dy), n4, act);
     return 0;
 }
+
+// ---- models.seldnet_v1 (models.py:36-52): doa_out = tanh(doa * Concatenate([sed] * 3)) with sed = sigmoid(.), doa = tanh(.) of the two heads.
+// Forward: one thread per (row, class): the three DOA components of the class share its sed value; writes the library's copy (what the
+// losses read) and the caller's.
+__global__ __launch_bounds__(256) void v1_couple_fwd_kernel(const float* __restrict__ sed, const float* __restrict__ doa1, float* __restrict__ out,
+                                                            float* __restrict__ out2, int64_t n, int nc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over [rows][nc]
+    if (i >= n) return;
+    const int64_t r = i / nc;
+    const int j = (int)(i - r * nc);
+    const float s = sed[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t o = r * 3 * nc + k * nc + j;
+        const float v = tanhf(doa1[o] * s);
+        out[o] = v;
+        if (out2) out2[o] = v;
+    }
+}
+int launch_v1_couple_fwd(hipStream_t st, const float* sed, const float* doa1, float* out, float* out2, int rows, int nc) {
+    const int64_t n = (int64_t)rows * nc;
+    hipLaunchKernelGGL(v1_couple_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sed, doa1, out, out2, n, nc);
+    return 0;
+}
+// Backward: losses_kernel left du = dL/d(doa sed) (its tanh' factor used the coupled output) in the DOA slot and the BCE term's gradient
+// w.r.t. the SED pre-activation in the SED slot.  d doa_pre = du * sed * (1 - doa^2); d sed_pre += (sum_k du_k doa_k) * sed (1 - sed).
+__global__ __launch_bounds__(256) void v1_couple_bwd_kernel(const float* __restrict__ sed, const float* __restrict__ doa1, float* __restrict__ dsed_pre,
+                                                            int ld_sed, float* __restrict__ ddoa_pre, int ld_doa, int64_t n, int nc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / nc;
+    const int j = (int)(i - r * nc);
+    const float s = sed[i];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d1 = doa1[r * 3 * nc + k * nc + j];
+        float* g = ddoa_pre + r * ld_doa + k * nc + j;
+        const float du = *g;
+        acc += du * d1;
+        *g = du * s * (1.f - d1 * d1);
+    }
+    dsed_pre[r * ld_sed + j] += acc * s * (1.f - s);
+}
+int launch_v1_couple_bwd(hipStream_t st, const float* sed, const float* doa1, float* dsed_pre, int ld_sed, float* ddoa_pre, int ld_doa, int rows, int nc) {
+    const int64_t n = (int64_t)rows * nc;
+    hipLaunchKernelGGL(v1_couple_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sed, doa1, dsed_pre, ld_sed, ddoa_pre, ld_doa, n, nc);
+    return 0;
+}
+
+// ---- simple_dense_block with kernel_size > 1 (modules.py:355, 370-372: Conv1D(units, kernel_size, padding='same') over the frames of a clip)
+// The layer runs as the dense product it is once its input rows are laid side by side: xe[b, t, j * C + c] = x[b, t + j - (ks - 1) / 2, c]
+// (zero outside the clip; TensorFlow's 'same' puts the extra pad of an even kernel at the end), K = ks * C, and the Keras kernel
+// [ks, C, units] is that product's [K, units] matrix as stored.  C % 4 == 0.
+__global__ __launch_bounds__(256) void time_expand_kernel(const float4* __restrict__ x, float4* __restrict__ xe, int S, int C4, int ks, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over [B * S][ks][C4]
+    if (i >= n4) return;
+    const int c = (int)(i % C4), j = (int)((i / C4) % ks);
+    const int64_t row = i / ((int64_t)C4 * ks);
+    const int t = (int)(row % S), ts = t + j - (ks - 1) / 2;
+    xe[i] = (ts >= 0 && ts < S) ? x[(row + (ts - t)) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+int launch_time_expand(hipStream_t st, const float* x, float* xe, int B, int S, int C, int ks) {
+    if ((C & 3) || ks < 1) return -1;
+    const int64_t n4 = (int64_t)B * S * ks * (C / 4);
+    hipLaunchKernelGGL(time_expand_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<float4*>(xe), S, C / 4, ks, n4);
+    return 0;
+}
+// its transpose: dx[b, t, c] (+)= sum_j dxe[b, t - j + (ks - 1) / 2, j * C + c], taps in order (fixed summation order)
+__global__ __launch_bounds__(256) void time_fold_kernel(const float4* __restrict__ dxe, float4* __restrict__ dx, int S, int C4, int ks, int64_t n4, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over [B * S][C4]
+    if (i >= n4) return;
+    const int c = (int)(i % C4);
+    const int64_t row = i / C4;
+    const int t = (int)(row % S);
+    float4 a = accumulate ? dx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < ks; ++j) {
+        const int tr = t - j + (ks - 1) / 2;                        // the output row whose tap j read this input row
+        if (tr < 0 || tr >= S) continue;
+        const float4 v = dxe[((row + (tr - t)) * ks + j) * C4 + c];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    dx[i] = a;
+}
+int launch_time_fold(hipStream_t st, const float* dxe, float* dx, int B, int S, int C, int ks, int accumulate) {
+    if ((C & 3) || ks < 1) return -1;
+    const int64_t n4 = (int64_t)B * S * (C / 4);
+    hipLaunchKernelGGL(time_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(dxe),
+                       reinterpret_cast<float4*>(dx), S, C / 4, ks, n4, accumulate);
+    return 0;
+}
+
+// ---- Dropout (modules.py:373-374; Keras: kept where uniform >= rate, scaled by 1 / (1 - rate), training only).  The reference draws from
+// TensorFlow's generator, which no other program reproduces; here the uniforms are Philox4x32-10 words of the counter
+// (element / 4, layer, step, 0) under the key (seed lo, seed hi), u = (word >> 8) * 2^-24 — a pure function of (seed, step, layer, element)
+// that the oracle restates (oracle/seldnet_oracle.py::philox_uniform), so the backward pass recomputes the mask instead of storing it.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+// out = in * mask / (1 - rate)  (forward: in = the layer's activations; backward: in = out = the gradient, in place)
+__global__ __launch_bounds__(256) void dropout_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n4, float rate, float scale,
+                                                      unsigned seed_lo, unsigned seed_hi, unsigned layer, unsigned step) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint4 r = philox4x32_10(make_uint4((unsigned)i, layer, step, (unsigned)(i >> 32)), make_uint2(seed_lo, seed_hi));
+    const float4 v = in[i];
+    const float k = 1.f / 16777216.f;
+    out[i] = make_float4((float)(r.x >> 8) * k >= rate ? v.x * scale : 0.f, (float)(r.y >> 8) * k >= rate ? v.y * scale : 0.f,
+                         (float)(r.z >> 8) * k >= rate ? v.z * scale : 0.f, (float)(r.w >> 8) * k >= rate ? v.w * scale : 0.f);
+}
+int launch_dropout(hipStream_t st, const float* in, float* out, int64_t n, float rate, uint64_t seed, unsigned layer, unsigned step) {
+    if ((n & 3) || !(rate >= 0.f && rate < 1.f)) return -1;
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(in),
+                       reinterpret_cast<float4*>(out), n4, rate, 1.f / (1.f - rate), (unsigned)seed, (unsigned)(seed >> 32), layer, step);
+    return 0;
+}

@@ -22,7 +22,7 @@ SUPPORTED_SECOND = ("bidirectional_GRU_block",)
 SUPPORTED_HEAD = ("simple_dense_block",)
 
 
-def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
+def _arch_from_config(model_config: dict, in_ch: int, n_freq: int, output_coupling: bool = False) -> _lib.Arch:
     for key, ok in (("FIRST", SUPPORTED_FIRST), ("SECOND", SUPPORTED_SECOND), ("SED", SUPPORTED_HEAD), ("DOA", SUPPORTED_HEAD)):
         if model_config.get(key) not in ok:
             raise ValueError(f"model_config[{key!r}]={model_config.get(key)!r}: only {ok} has MI355X kernels")
@@ -48,18 +48,18 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
         raise ValueError("dropout_rate > 0 has no kernel (seldnet.json uses 0.0)")
     gru = list(model_config["SECOND_ARGS"]["units"])
     sed, doa = list(model_config["SED_ARGS"]["units"]), list(model_config["DOA_ARGS"]["units"])
-    # simple_dense_block honours these keys (modules.py:350-376); the head kernels are per-step layers (Conv1D with kernel_size 1) with
-    # `dense_activation` None (seldnet.json: what lets W1 W2 fold into one product), relu, tanh or sigmoid; anything else must fail loudly
-    # instead of training a different network.  `kernel_regularizer` is accepted: it only feeds model.losses, which
+    # simple_dense_block honours these keys (modules.py:350-376): `dense_activation` None (seldnet.json: what lets W1 W2 fold into one
+    # product), relu, tanh or sigmoid, `kernel_size` (Conv1D 'same' over the frames of a clip), `dropout_rate`; anything else must fail
+    # loudly instead of training a different network.  `kernel_regularizer` is accepted: it only feeds model.losses, which
     # train.trainstep (train.py:22-36) never adds to the objective.
     for key in ("SED_ARGS", "DOA_ARGS"):
         ha = model_config[key]
         if ha.get("dense_activation") not in _lib.SELD_ACT:
             raise ValueError(f"{key}['dense_activation']={ha.get('dense_activation')!r}: the head kernels implement {sorted(k for k in _lib.SELD_ACT if k)} and None")
-        if int(ha.get("kernel_size", 1)) != 1:
-            raise ValueError(f"{key}['kernel_size']={ha.get('kernel_size')!r}: the head kernels are per-step (kernel_size 1)")
-        if ha.get("dropout_rate", 0):
-            raise ValueError(f"{key}['dropout_rate'] > 0 has no kernel (seldnet.json uses none)")
+        if not 1 <= int(ha.get("kernel_size", 1)) <= 15:
+            raise ValueError(f"{key}['kernel_size']={ha.get('kernel_size')!r}: 1 .. 15")
+        if not 0.0 <= float(ha.get("dropout_rate", 0)) < 1.0:
+            raise ValueError(f"{key}['dropout_rate']={ha.get('dropout_rate')!r}: [0, 1)")
     for lst, name in ((filters, "filters"), (gru, "SECOND units"), (sed, "SED units"), (doa, "DOA units")):
         if len(lst) > _lib.MAX_LAYERS:
             raise ValueError(f"{name}: at most {_lib.MAX_LAYERS} layers")
@@ -80,6 +80,11 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int) -> _lib.Arch:
     a.n_classes = int(model_config.get("n_classes", 14))
     a.sed_dense_act = _lib.SELD_ACT[model_config["SED_ARGS"].get("dense_activation")]
     a.doa_dense_act = _lib.SELD_ACT[model_config["DOA_ARGS"].get("dense_activation")]
+    a.sed_kernel_size = int(model_config["SED_ARGS"].get("kernel_size", 1))
+    a.doa_kernel_size = int(model_config["DOA_ARGS"].get("kernel_size", 1))
+    a.sed_dropout = float(model_config["SED_ARGS"].get("dropout_rate", 0))
+    a.doa_dropout = float(model_config["DOA_ARGS"].get("dropout_rate", 0))
+    a.output_coupling = 1 if output_coupling else 0
     a.first_kind = 2 if resnet else (1 if xception else 0)
     a.xc_blocks = int(fa["block_num"]) if xception else 0
     if resnet:
@@ -100,7 +105,8 @@ class SeldNet:
     """The object `models.seldnet` returns: `model(x, training)`, `trainable_variables`,
     `get_weights/set_weights`, `summary()`, `save_weights/load_weights`."""
 
-    def __init__(self, input_shape: Sequence[int], model_config: dict, device: int | None = None, dtype: str = "float32"):
+    def __init__(self, input_shape: Sequence[int], model_config: dict, device: int | None = None, dtype: str = "float32",
+                 output_coupling: bool = False):
         if len(input_shape) != 4 or input_shape[0] is None:
             raise ValueError("input_shape must be [B, T, F, C] with a concrete batch size")
         B, T, F, Cc = (int(v) for v in input_shape)
@@ -108,7 +114,7 @@ class SeldNet:
         if not torch.cuda.is_available():
             raise _lib.SeldLibraryError("no HIP device visible: seld_amd has no CPU fallback")
         self.device = torch.cuda.current_device() if device is None else int(device)
-        self.arch = _arch_from_config(model_config, Cc, F)
+        self.arch = _arch_from_config(model_config, Cc, F, output_coupling)
         self.input_shape = (B, T, F, Cc)
         self.model_config = model_config
         ctx = C.c_void_p()
@@ -245,6 +251,12 @@ class SeldNet:
 def seldnet(input_shape, model_config, device=None, dtype: str = "float32") -> SeldNet:
     """reference models.seldnet (models.py:18-32).  `dtype="bfloat16"`: bf16 single-product mode (SELD_DTYPE_BF16)."""
     return SeldNet(input_shape, model_config, device, dtype)
+
+
+def seldnet_v1(input_shape, model_config, device=None, dtype: str = "float32") -> SeldNet:
+    """reference models.seldnet_v1 (models.py:36-52; model_config/seldnet_v1.json): seldnet whose DOA output is coupled to the SED
+    output, doa_out = tanh(doa * Concatenate([sed] * 3)) (seld_arch.output_coupling)."""
+    return SeldNet(input_shape, model_config, device, dtype, output_coupling=True)
 
 
 # ---------------------------------------------------------------------- Keras initialisers

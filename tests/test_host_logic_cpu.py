@@ -93,22 +93,25 @@ def test_synthetic_batch_matches_the_oracles_generator():
 
 
 def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
-    """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376); the HIP heads are per-step layers
-    with dense_activation None / linear / relu / tanh / sigmoid (config_sampler.py:216-218 samples None and relu), so any other value
-    must raise instead of silently training a different network."""
+    """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376): the HIP heads take
+    dense_activation None / linear / relu / tanh / sigmoid (config_sampler.py:216-218 samples None and relu), kernel_size 1 .. 15 and
+    dropout_rate in [0, 1); any other value must raise instead of silently training a different network."""
     import copy
     from seld_amd import models
     a = models._arch_from_config(seldnet_config, 7, 64)
     assert (a.n_sed_dense, a.n_doa_dense, a.n_classes) == (1, 1, 12)
+    assert (a.sed_kernel_size, a.doa_kernel_size, a.sed_dropout, a.doa_dropout, a.output_coupling) == (1, 1, 0.0, 0.0, 0)
     ok = copy.deepcopy(seldnet_config)
     ok["SED_ARGS"].update(dense_activation="linear", kernel_size=1, dropout_rate=0, kernel_regularizer={"l1": 0.0, "l2": 1e-3})
     models._arch_from_config(ok, 7, 64)      # the regulariser only feeds model.losses, which train.trainstep never adds
     for head in ("SED_ARGS", "DOA_ARGS"):
         good = copy.deepcopy(seldnet_config)
-        good[head]["dense_activation"] = "relu"
-        ar = models._arch_from_config(good, 7, 64)
+        good[head].update(dense_activation="relu", kernel_size=3, dropout_rate=0.25)
+        ar = models._arch_from_config(good, 7, 64, output_coupling=True)
         assert (ar.sed_dense_act, ar.doa_dense_act) == ((3, 0) if head == "SED_ARGS" else (0, 3))
-        for key, val in (("dense_activation", "swish"), ("kernel_size", 3), ("dropout_rate", 0.2)):
+        assert (ar.sed_kernel_size, ar.doa_kernel_size) == ((3, 1) if head == "SED_ARGS" else (1, 3))
+        assert (ar.sed_dropout, ar.doa_dropout) == ((0.25, 0.0) if head == "SED_ARGS" else (0.0, 0.25)) and ar.output_coupling == 1
+        for key, val in (("dense_activation", "swish"), ("kernel_size", 0), ("kernel_size", 16), ("dropout_rate", 1.0), ("dropout_rate", -0.1)):
             bad = copy.deepcopy(seldnet_config)
             bad[head][key] = val
             with pytest.raises(ValueError):

@@ -115,6 +115,85 @@ def test_train_step_dense_activation(seldnet_config, sed_act, doa_act, opts):
     _per_var(model, "dense_activation grad", model.get_grads(), ref["grad"])
 
 
+@pytest.mark.parametrize("doa_loss", ["MSE", "MMSE"])
+@pytest.mark.parametrize("opts", [{}, {"heads_fused": 0}])
+def test_train_step_seldnet_v1(seldnet_config, doa_loss, opts):
+    """models.seldnet_v1 (models.py:36-52; model_config/seldnet_v1.json): doa_out = tanh(doa * Concatenate([sed] * 3)) — outputs, losses
+    and every gradient (the DOA loss now reaches the SED head through the product) against the fp64 oracle, through the folded heads
+    and through the layer-by-layer ones."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    B, T = 3, 100
+    spec = O.Spec.from_config(seldnet_config)
+    spec.output_coupling = True
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    model = models.seldnet_v1((B, T, 64, 7), copy.deepcopy(seldnet_config))
+    for k, v in opts.items():
+        model.set_option(k, v)
+    model.set_weights(w, st)
+    fn = losses.MSE if doa_loss == "MSE" else losses.MMSE
+    ref_t = O.test_step(spec, w, st, x, ys, yd, doa_loss, dtype=torch.float64)
+    y_t, _, dl_t = train.teststep(model, x, (ys, yd), losses.BinaryCrossentropy(), fn)
+    check("seldnet_v1 teststep sed", y_t[0].cpu().numpy(), ref_t["sed"])
+    check("seldnet_v1 teststep doa", y_t[1].cpu().numpy(), ref_t["doa"])
+    check("seldnet_v1 teststep dloss", dl_t.cpu().numpy(), ref_t["dloss"])
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss=doa_loss, loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), fn, (1.0, 1000.0), train.Adam(1e-3))
+    check("seldnet_v1 trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("seldnet_v1 trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("seldnet_v1 trainstep dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "seldnet_v1 grad", model.get_grads(), ref["grad"])
+
+
+@pytest.mark.parametrize("sed_args,doa_args,v1", [
+    (dict(kernel_size=3), dict(kernel_size=3), False),
+    (dict(kernel_size=3, dense_activation="relu", dropout_rate=0.25), dict(kernel_size=2, dropout_rate=0.5), False),
+    (dict(dropout_rate=0.3, dense_activation="tanh"), dict(), True),
+    (dict(kernel_size=5, units=[64, 32], dropout_rate=0.1, dense_activation="relu"), dict(kernel_size=1), False),
+])
+def test_train_step_dense_kernel_size_and_dropout(seldnet_config, sed_args, doa_args, v1):
+    """simple_dense_block's `kernel_size` (modules.py:355, 370-372: Conv1D 'same' over a clip's frames; an even kernel pads behind) and
+    `dropout_rate` (modules.py:357, 373-374): forward, losses and every gradient against the fp64 oracle, which restates the library's
+    counter-based dropout draws (the reference's come from TensorFlow's generator: same distribution, other draws).  The masks are
+    those of training step 5 (option dropout_step); inference applies none."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["SED_ARGS"].update(sed_args)
+    cfg["DOA_ARGS"].update(doa_args)
+    B, T = 3, 100
+    spec = O.Spec.from_config(cfg)
+    spec.output_coupling = v1
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    model = (models.seldnet_v1 if v1 else models.seldnet)((B, T, 64, 7), cfg)
+    assert [tuple(s_) for n_, _, s_ in model.variables if n_ == "sed.dense0.kernel"] == [(int(sed_args.get("kernel_size", 1)), 128, cfg["SED_ARGS"]["units"][0])]
+    model.set_weights(w, st)
+    ref_t = O.test_step(spec, w, st, x, ys, yd, "MSE", dtype=torch.float64)
+    y_t, _, _ = train.teststep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE)
+    check("teststep sed", y_t[0].cpu().numpy(), ref_t["sed"])
+    check("teststep doa", y_t[1].cpu().numpy(), ref_t["doa"])
+    model.set_option("dropout_step", 5)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64, dropout_step=5)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    check("trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("trainstep dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "kernel_size / dropout grad", model.get_grads(), ref["grad"])
+    if sed_args.get("dropout_rate") or doa_args.get("dropout_rate"):
+        # the next step draws other masks (the counter moved on), a rewound counter the same ones again
+        model.set_weights(w, st)
+        y_n, _, _ = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+        assert np.abs(y_n[0].cpu().numpy() - y_p[0].cpu().numpy()).max() > 1e-4
+        model.set_weights(w, st)
+        model.set_option("dropout_step", 5)
+        y_r, _, _ = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+        np.testing.assert_array_equal(y_r[0].cpu().numpy(), y_p[0].cpu().numpy())
+
+
 def test_two_steps_and_short_batch(seldnet_config):
     """Second Adam step (bias correction t=2, non-zero slots) and a batch smaller than the ctx's."""
     O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, 3, 50)

@@ -189,3 +189,49 @@ def test_metrics_oracle_hand_worked_case():
     ER, F, DE, DE_F = m.result()
     np.testing.assert_allclose([ER, F, DE, DE_F], [0.5, 0.5, 10.0, 0.5], atol=1e-9)
     np.testing.assert_allclose(MO.calculate_seld_score((ER, F, DE, DE_F)), (0.5 + 0.5 + 10 / 180 + 0.5) / 4)
+
+
+def test_philox_known_answers_and_dropout_uniforms():
+    """The dropout draws (oracle philox_uniform = loss_adam.hip::dropout_kernel) are Philox4x32-10: the three known-answer vectors
+    Random123 publishes (kat_vectors: philox4x32 10), and the counter layout (element / 4, layer, step, 0) the kernel uses."""
+    kat = (((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)))
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(*[np.array([c], np.uint64) for c in ctr], *key)
+        assert tuple(int(v[0]) for v in got) == want
+    seed = 0x5e1d5e1d5e1d5e1d
+    u = O.philox_uniform(10, seed, 3, 7)
+    w = O.philox4x32_10(np.array([1], np.uint64), np.array([3], np.uint64), np.array([7], np.uint64), np.array([0], np.uint64), seed, seed >> 32)
+    assert u.shape == (10,) and u[4] == (int(w[0][0]) >> 8) * 2.0 ** -24 and u[7] == (int(w[3][0]) >> 8) * 2.0 ** -24
+    big = O.philox_uniform(200000, seed, 0, 0)
+    assert 0.0 <= big.min() and big.max() < 1.0 and abs(big.mean() - 0.5) < 5e-3 and abs((big >= 0.25).mean() - 0.75) < 5e-3
+
+
+def test_conv1d_same_matches_torch_conv1d_and_tensorflow_padding():
+    """simple_dense_block's Conv1D(units, kernel_size, padding='same') (modules.py:370-372): odd kernels against torch's conv1d
+    ('same' is symmetric then), an even kernel against TensorFlow's rule (the extra frame of padding goes behind)."""
+    rng = np.random.default_rng(0)
+    a = torch.as_tensor(rng.standard_normal((2, 9, 4)))
+    for ks in (1, 3, 5):
+        k = torch.as_tensor(rng.standard_normal((ks, 4, 6)))
+        b = torch.as_tensor(rng.standard_normal(6))
+        want = torch.nn.functional.conv1d(a.transpose(1, 2), k.permute(2, 1, 0), b, padding=ks // 2).transpose(1, 2)
+        assert torch.allclose(O.conv1d_same(a, k, b), want, atol=1e-12)
+    k = torch.as_tensor(rng.standard_normal((2, 4, 6)))
+    got = O.conv1d_same(a, k, torch.zeros(6, dtype=torch.float64))
+    want = a @ k[0] + torch.cat([a[:, 1:], torch.zeros(2, 1, 4, dtype=torch.float64)], dim=1) @ k[1]      # pad 0 in front, 1 behind
+    assert torch.allclose(got, want, atol=1e-12)
+
+
+def test_seldnet_v1_output_coupling(spec):
+    """models.seldnet_v1 (models.py:36-52): the same network with doa_out = tanh(doa * Concatenate([sed] * 3))."""
+    import copy
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(2, 50)
+    a = O.test_step(spec, w, st, x, ys, yd, "MSE", dtype=torch.float64)
+    sp1 = copy.deepcopy(spec)
+    sp1.output_coupling = True
+    b = O.test_step(sp1, w, st, x, ys, yd, "MSE", dtype=torch.float64)
+    np.testing.assert_array_equal(a["sed"], b["sed"])
+    np.testing.assert_allclose(b["doa"], np.tanh(a["doa"] * np.concatenate([a["sed"]] * 3, axis=-1)), rtol=0, atol=1e-15)
