@@ -124,7 +124,8 @@ int seld_sync(seld_ctx* ctx);
  * the heads' first Conv1D and their input gradients (gemm_sb.hip) where K % 32 == 0 and N % 128 == 0; 0 keeps them on
  * the f32-input MFMA GEMM.  "conv1_split_bf16" (default 1): the same scheme for the first
  * block's forward whenever its pre-BN tensor is not stored (conv_pool_sb.hip).  "conv1_pool_fused" / "conv1_gram" (default 1): first block's pooling inside the conv
- * epilogue / its kernel gradient from the patch Gram matrix. */
+ * epilogue / its kernel gradient from the patch Gram matrix.  "dropout_seed" / "dropout_step" (values): the key of the heads' dropout
+ * draws and the step counter of the next training forward (seld_arch.sed_dropout / doa_dropout; INTEGRATION.md section 6 lists every key). */
 int seld_set_option(seld_ctx* ctx, const char* key, int value);
 
 /* ---- variables: replaces model.trainable_variables / get_weights / set_weights

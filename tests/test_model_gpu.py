@@ -1,5 +1,7 @@
 """End-to-end parity of the HIP train/test step (through seld_amd -> C ABI) against the CPU oracle
 on the same seeded inputs.  Tolerance 1e-4 relative (north_star), written per check."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -192,6 +194,52 @@ def test_train_step_dense_kernel_size_and_dropout(seldnet_config, sed_args, doa_
         model.set_option("dropout_step", 5)
         y_r, _, _ = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
         np.testing.assert_array_equal(y_r[0].cpu().numpy(), y_p[0].cpu().numpy())
+
+
+def test_c_host_drives_the_train_step(seldnet_config, tmp_path):
+    """The drop-in boundary without Python in the process: examples/c_host_train_step.c (C99, gcc) includes include/seld_hip.h, links
+    libseld_hip.so and the HIP runtime, builds model_config/seldnet.json's seld_arch, loads weights and a batch from a file and runs
+    seld_train_step (train.py:22-36).  Its outputs, losses, gradient and Adam-updated weights against the fp64 oracle."""
+    import subprocess
+    from conftest import ROOT
+    from oracle import seldnet_oracle as O
+    spec = O.Spec.from_config(seldnet_config)
+    B, T = 2, 100
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    src = os.path.join(ROOT, "examples", "c_host_train_step.c")
+    exe = str(tmp_path / "c_host_train_step")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    src, "-L", os.path.join(ROOT, "seld_amd"), "-lseld_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + os.path.join(ROOT, "seld_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in (w, st, x, ys, yd)]).tofile(tmp_path / "in.bin")
+    r = subprocess.run([exe, str(B), str(T), "1", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+    out = np.fromfile(tmp_path / "out.bin", np.float32)
+    S, nc, n = T // 5, 12, w.size
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    o = 0
+    sed = out[o:o + B * S * nc].reshape(B, S, nc); o += B * S * nc
+    doa = out[o:o + B * S * 3 * nc].reshape(B, S, 3 * nc); o += B * S * 3 * nc
+    sloss = out[o]; o += 1
+    dloss = out[o:o + B * S].reshape(B, S); o += B * S
+    new_w = out[o:o + n]; o += n
+    grad = out[o:o + n]; o += n
+    assert o == out.size
+    check("c host sed", sed, ref["sed"])
+    check("c host doa", doa, ref["doa"])
+    check("c host sloss", sloss, ref["sloss"])
+    check("c host dloss", dloss, ref["dloss"])
+    tr, _ = O.variable_specs(spec)
+    off = 0
+    for name, shape in tr:
+        k = int(np.prod(shape))
+        if not (name.startswith("conv") and name.endswith("bias")):      # (exactly zero in exact arithmetic: see _per_var)
+            check(f"c host grad {name}", grad[off:off + k], ref["grad"][off:off + k])
+        off += k
+    mask = np.abs(ref["grad"]) > 1e-3 * np.abs(ref["grad"]).max()
+    check("c host adam update (|g| above noise)", (new_w - w)[mask], (ref["new_w"] - w)[mask], tol=2e-3)
 
 
 def test_two_steps_and_short_batch(seldnet_config):
