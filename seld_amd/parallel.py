@@ -64,6 +64,9 @@ def init_library_dp(model, group=None, force: bool = False) -> bool:
     torch.cuda.synchronize(model._dev)
     _lib.check(model.lib.seld_dp_init(model.ctx, rank, world, host), model.ctx)
     model._lib_dp = True
+    # the heads' dropout draws are a function of (seed, step, layer, element): every rank gets its own key, or all replicas would drop
+    # the same elements of their different clips
+    model.set_option("dropout_seed", 0x5e1d + rank)
     return True
 
 
