@@ -185,6 +185,12 @@ def test_train_step_dense_kernel_size_and_dropout(seldnet_config, sed_args, doa_
     check("trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
     check("trainstep dloss", dl.cpu().numpy(), ref["dloss"])
     _per_var(model, "kernel_size / dropout grad", model.get_grads(), ref["grad"])
+    # a short last batch (data_loader.batch(drop_remainder=False)) through the same context: the rows laid side by side follow the batch
+    model.set_weights(w, st)
+    ref_s = O.test_step(spec, w, st, x[:2], ys[:2], yd[:2], "MSE", dtype=torch.float64)
+    y_s, _, _ = train.teststep(model, x[:2], (ys[:2], yd[:2]), losses.BinaryCrossentropy(), losses.MSE)
+    check("short batch sed", y_s[0].cpu().numpy(), ref_s["sed"])
+    check("short batch doa", y_s[1].cpu().numpy(), ref_s["doa"])
     if sed_args.get("dropout_rate") or doa_args.get("dropout_rate"):
         # the next step draws other masks (the counter moved on), a rewound counter the same ones again
         model.set_weights(w, st)
