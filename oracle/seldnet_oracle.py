@@ -81,6 +81,20 @@ class Spec:
 
     @staticmethod
     def from_config(model_config: dict, in_ch: int = 7, n_freq: int = 64) -> "Spec":
+        import copy
+        model_config = copy.deepcopy(model_config)
+        # the reference's stage wrappers build the blocks restated here: bidirectional_GRU_stage (modules.py:46-61), simple_dense_stage
+        # (modules.py:86-103: `activation` becomes dense_activation), identity_block (modules.py:639-642)
+        if model_config.get("SECOND") == "bidirectional_GRU_stage":
+            model_config["SECOND"] = "bidirectional_GRU_block"
+            model_config["SECOND_ARGS"]["units"] = [int(model_config["SECOND_ARGS"]["units"])] * int(model_config["SECOND_ARGS"]["depth"])
+        for key in ("SED", "DOA"):
+            args = model_config.setdefault(key + "_ARGS", {})
+            if model_config.get(key) == "simple_dense_stage":
+                args["units"] = [int(args["units"])] * int(args["depth"])
+                args["dense_activation"] = args.get("activation", None)
+            elif model_config.get(key) == "identity_block":
+                args["units"] = []
         sp = Spec._from_config(model_config, in_ch, n_freq)
         sp.sed_dense_act = model_config["SED_ARGS"].get("dense_activation")
         sp.doa_dense_act = model_config["DOA_ARGS"].get("dense_activation")

@@ -22,7 +22,26 @@ SUPPORTED_SECOND = ("bidirectional_GRU_block",)
 SUPPORTED_HEAD = ("simple_dense_block",)
 
 
+def canonical_config(model_config: dict) -> dict:
+    """The reference's stage wrappers and identity_block as the blocks they build: `bidirectional_GRU_stage` (modules.py:46-61: depth x
+    [units]) -> bidirectional_GRU_block, `simple_dense_stage` (modules.py:86-103: depth x [units], `activation` -> dense_activation) ->
+    simple_dense_block, `identity_block` (modules.py:639-642) as a head -> simple_dense_block without hidden layers."""
+    import copy
+    cfg = copy.deepcopy(model_config)
+    if cfg.get("SECOND") == "bidirectional_GRU_stage":
+        a = cfg["SECOND_ARGS"]
+        cfg["SECOND"], a["units"] = "bidirectional_GRU_block", [int(a["units"])] * int(a["depth"])
+    for key in ("SED", "DOA"):
+        a = cfg.setdefault(key + "_ARGS", {})
+        if cfg.get(key) == "simple_dense_stage":
+            cfg[key], a["units"], a["dense_activation"] = "simple_dense_block", [int(a["units"])] * int(a["depth"]), a.get("activation", None)
+        elif cfg.get(key) == "identity_block":
+            cfg[key], a["units"] = "simple_dense_block", []
+    return cfg
+
+
 def _arch_from_config(model_config: dict, in_ch: int, n_freq: int, output_coupling: bool = False) -> _lib.Arch:
+    model_config = canonical_config(model_config)
     for key, ok in (("FIRST", SUPPORTED_FIRST), ("SECOND", SUPPORTED_SECOND), ("SED", SUPPORTED_HEAD), ("DOA", SUPPORTED_HEAD)):
         if model_config.get(key) not in ok:
             raise ValueError(f"model_config[{key!r}]={model_config.get(key)!r}: only {ok} has MI355X kernels")

@@ -118,6 +118,26 @@ def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
                 models._arch_from_config(bad, 7, 64)
 
 
+def test_stage_wrappers_and_identity_heads_map_to_the_blocks_they_build(seldnet_config):
+    """bidirectional_GRU_stage (modules.py:46-61), simple_dense_stage (modules.py:86-103: `activation` -> dense_activation) and
+    identity_block (modules.py:639-642) as SECOND / SED / DOA: the arch the wrappers' blocks have."""
+    import copy
+    from seld_amd import models
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["SECOND"], cfg["SECOND_ARGS"] = "bidirectional_GRU_stage", {"depth": 2, "units": 128, "dropout_rate": 0.0}
+    cfg["SED"], cfg["SED_ARGS"] = "simple_dense_stage", {"depth": 2, "units": 64, "activation": "relu"}
+    cfg["DOA"], cfg["DOA_ARGS"] = "identity_block", {}
+    a = models._arch_from_config(cfg, 7, 64)
+    assert (a.n_gru, list(a.gru_units)[:2]) == (2, [128, 128])
+    assert (a.n_sed_dense, list(a.sed_units)[:2], a.sed_dense_act) == (2, [64, 64], 3)
+    assert (a.n_doa_dense, a.doa_dense_act) == (0, 0)
+    assert cfg["SED"] == "simple_dense_stage"                      # the caller's dict is left alone
+    bad = copy.deepcopy(cfg)
+    bad["SECOND"] = "RNN_stage"
+    with pytest.raises(ValueError):
+        models._arch_from_config(bad, 7, 64)
+
+
 def test_keras_h5_name_mapping_on_a_hand_built_name_list():
     """tools/keras_h5_to_npz.py (reference seams train.py:372-380 / :322-331 / evaluator.py:57): the Keras-variable -> seld_amd
     mapping is a pure function of names and shapes, tested here on the names Keras gives model_config/seldnet.json's layers

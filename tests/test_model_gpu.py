@@ -202,6 +202,32 @@ def test_train_step_dense_kernel_size_and_dropout(seldnet_config, sed_args, doa_
         np.testing.assert_array_equal(y_r[0].cpu().numpy(), y_p[0].cpu().numpy())
 
 
+def test_train_step_stage_wrappers_and_identity_head(seldnet_config):
+    """SECOND = bidirectional_GRU_stage (modules.py:46-61), SED = simple_dense_stage (depth 2, relu; modules.py:86-103), DOA =
+    identity_block (modules.py:639-642: the output Dense straight on the recurrent features): train step against the fp64 oracle."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["SECOND"], cfg["SECOND_ARGS"] = "bidirectional_GRU_stage", {"depth": 2, "units": 128, "dropout_rate": 0.0}
+    cfg["SED"], cfg["SED_ARGS"] = "simple_dense_stage", {"depth": 2, "units": 64, "activation": "relu"}
+    cfg["DOA"], cfg["DOA_ARGS"] = "identity_block", {}
+    B, T = 3, 100
+    spec = O.Spec.from_config(cfg)
+    assert (spec.sed_units, spec.doa_units, spec.sed_dense_act) == ([64, 64], [], "relu")
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    assert [n for n, _, _ in model.variables if n.startswith("doa.")] == ["doa.out.kernel", "doa.out.bias"]
+    model.set_weights(w, st)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    check("stage wrappers sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("stage wrappers doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("stage wrappers dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "stage wrappers grad", model.get_grads(), ref["grad"])
+
+
 def test_c_host_drives_the_train_step(seldnet_config, tmp_path):
     """The drop-in boundary without Python in the process: examples/c_host_train_step.c (C99, gcc) includes include/seld_hip.h, links
     libseld_hip.so and the HIP runtime, builds model_config/seldnet.json's seld_arch, loads weights and a batch from a file and runs
