@@ -571,7 +571,11 @@ __global__ __launch_bounds__(64 * FEAT_WAVES_OF(MODE, LOGN), 1) void feat_wave_k
 // the constant fragments, the twiddles and — as in feat_wave_kernel, whose second half this kernel shares — the per-bin planes of the
 // sparse mel projection.  A lane ends with bins k = (lane & 31) + 32 k2, k2 = mfma_row(i, lane >> 5), i < 8 (+ bin 512 on lane 0).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-#define DFT_WAVES 12
+#define DFT_WAVES 12                                           // foa; the mic form keeps all four spectra in registers: 8 waves (256 VGPRs)
+#define DFT_WAVES_MIC 8
+#define DFT_WAVES_OF(MODE_) ((MODE_) == 0 ? DFT_WAVES : DFT_WAVES_MIC)
+// mic: the constants of the GCC-PHAT inverse transform (see the kernel): F [re | im | -im][hi | lo][64] x 16 B, then the outer stage's [16][64] float4
+#define GCC_TAB_BYTES (6 * 1024 + 16 * 1024)
 #define DFT_TAB_BYTES (8 * 1024 + 4 * 1024 + 8 * 1024)        // f1 [2][re|im][hi|lo][64] x 16 B | a3 [2][hi|lo][64] x 16 B | tw2 [16][64] float2
 
 // wave-wide maximum without LDS traffic: two quad permutes and two row rotations leave every lane of a 16-lane row with the row's
@@ -605,7 +609,7 @@ __device__ __forceinline__ int dft_bin(int i, int lane) {      // NB (= out of r
 // -DFEAT_TRACE (diagnostic build, tools/trace_feat.py): s_memtime stamps of every wave of workgroup (0, 0) over its frames 2 and 3:
 // frame start | after channels 0..3 | after the intensity normalisation | log-mel rows | intensity rows | frame stored.
 #ifdef FEAT_TRACE
-__device__ unsigned long long g_feat_trace[DFT_WAVES][2][10];
+__device__ unsigned long long g_feat_trace[DFT_WAVES][2][10];      // (foa form: 12 waves)
 #define FEAT_TR(k_)                                                                                      \
     if (blockIdx.x == 0 && blockIdx.y == 0 && (trace_it == 2 || trace_it == 3)) {                        \
         unsigned long long t_;                                                                           \
@@ -618,12 +622,12 @@ __device__ unsigned long long g_feat_trace[DFT_WAVES][2][10];
 #define FEAT_TR(k_)
 #endif
 
-template <int QSEQ>
-__global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
+template <int QSEQ, int MODE>
+__global__ __launch_bounds__(64 * DFT_WAVES_OF(MODE), 1) void feat_dft_kernel(
     const float* __restrict__ wav, int64_t n_samples, int64_t T, int hop, int n_mels, const float* __restrict__ win_g,
     const uint4* __restrict__ dft_g, const uint4* __restrict__ mm_g, int n_mm, int mm_pmax, float* __restrict__ out, float* __restrict__ gmax,
     float* __restrict__ gmin, int wave_bytes) {
-    constexpr int N = 1024, NB = 513, NBP = 516, NBI = 9, C_OUT = 7;
+    constexpr int N = 1024, NB = 513, NBP = 516, NBI = 9, C_OUT = MODE == 0 ? 7 : 10, WAVES = DFT_WAVES_OF(MODE);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* win = smem;                                             // [N]
@@ -635,11 +639,12 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
     const float2* tw2 = reinterpret_cast<const float2*>(dtab + 12 * 1024);        // [r][lane]
     const int tid = threadIdx.x, lane_id = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (size_t)wave * wave_bytes);      // the wave's four per-bin planes [4][NBP]
+    const char* gtab = dtab + DFT_TAB_BYTES;                                                       // mic: GCC_TAB_BYTES of inverse-transform constants
+    float* val = reinterpret_cast<float*>(dtab + DFT_TAB_BYTES + (MODE == 1 ? GCC_TAB_BYTES : 0) + (size_t)wave * wave_bytes);      // the wave's four per-bin planes [4][NBP]
     float* stage = val + 4 * NBP;                                  // [n_mels][7] (+ 8 floats the idle blocks add into): the frame's outputs, stored as ONE contiguous run
-    for (int i = tid; i < N; i += 64 * DFT_WAVES) win[i] = win_g[i];
-    for (int i = tid; i < n_mm; i += 64 * DFT_WAVES) mm[i] = mm_g[i];
-    for (int i = tid; i < DFT_TAB_BYTES / 16; i += 64 * DFT_WAVES) reinterpret_cast<uint4*>(dtab)[i] = dft_g[i];
+    for (int i = tid; i < N; i += 64 * WAVES) win[i] = win_g[i];
+    for (int i = tid; i < n_mm; i += 64 * WAVES) mm[i] = mm_g[i];
+    for (int i = tid; i < (DFT_TAB_BYTES + (MODE == 1 ? GCC_TAB_BYTES : 0)) / 16; i += 64 * WAVES) reinterpret_cast<uint4*>(dtab)[i] = dft_g[i];
     __syncthreads();
     float lmax = -INFINITY, lmin = INFINITY;
     wav += (size_t)blockIdx.y * 4 * n_samples;                     // blockIdx.y = clip of a batch
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
     float xr[16];                                                  // the samples the next channel iteration works on
     bool first_frame = true;
     int trace_it = -1;
-    for (int64_t t = (int64_t)blockIdx.x * DFT_WAVES + wave; t < T; t += (int64_t)gridDim.x * DFT_WAVES) {
+    for (int64_t t = (int64_t)blockIdx.x * WAVES + wave; t < T; t += (int64_t)gridDim.x * WAVES) {
         ++trace_it;
         FEAT_TR(0)
         int lane = lane_id;
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
         const int li = lane & 31, g = lane >> 5;
         float2 X0[NBI];
         float IV[3][NBI];
+        float2 XS[MODE == 1 ? 3 : 1][NBI];                        // mic: the spectra of channels 1 .. 3 at this lane's bins (channel 0 in X0)
         // the window at this lane's 16 sample slots (slot u -> n1 = 16 (u >> 3) + 8 g + (u & 7), n = 32 n1 + li): the same for the four channels
         const float* wn = win + 256 * g + li;                    // slot u at offset 512 (u >> 3) + 32 (u & 7): re-read per channel (16 registers fewer)
         // raw samples of (frame, channel) in A-operand order; channel c + 1 is requested before channel c is processed, so that a wave
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
                 }
             }
         };
-        const int64_t t_next = t + (int64_t)gridDim.x * DFT_WAVES < T ? t + (int64_t)gridDim.x * DFT_WAVES : t;
+        const int64_t t_next = t + (int64_t)gridDim.x * WAVES < T ? t + (int64_t)gridDim.x * WAVES : t;
         float xn[16];
         if (first_frame) { load16(xr, t, 0); first_frame = false; }
 #pragma unroll
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
                 const int k = dft_bin(i, lane);
                 if (i < 8 || k < NB) val[c * NBP + k] = xc.x * xc.x + xc.y * xc.y;
                 if (c == 0) X0[i] = xc;
+                else if (MODE == 1) XS[c - 1][i] = xc;
                 else IV[c == 3 ? 0 : c][i] = X0[i].x * xc.x + X0[i].y * xc.y;      // IVx <- ch3, IVy <- ch1, IVz <- ch2: Re(conj(W) X_c)
             }
 #pragma unroll
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             FEAT_TR(1 + c)
         }
 #pragma unroll
-        for (int i = 0; i < NBI; ++i) {
+        for (int i = 0; MODE == 0 && i < NBI; ++i) {
             const float ivx = IV[0][i], ivy = IV[1][i], ivz = IV[2][i];
             const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ivx * ivx + ivy * ivy + ivz * ivz), 1e-8f));
             IV[0][i] = ivx * inv; IV[1][i] = ivy * inv; IV[2][i] = ivz * inv;
@@ -831,6 +838,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             }
         }
         FEAT_TR(6)
+        if constexpr (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
             const int k = dft_bin(i, lane);
@@ -848,6 +856,78 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
             }
         }
         WAVE_LDS_FENCE();
+        } else {
+        // ---- GCC-PHAT (feature_extractor.py:196-214): cc = irfft(exp(i angle(conj(Xa) Xb))), lags -n_mels/2 .. n_mels/2 - 1, for the six pairs.
+        // The inverse transform as 32 x 32 products too, PRUNED to the 64 lags that are kept.  With k = k1 + 32 k2 and n = n2 + 32 n1:
+        //     cc[n] = (1/N) [ R[0] + (-1)^n R[512] + 2 Re sum_{k1 < 32} e^(2 pi i k1 n2 / 1024) e^(2 pi i k1 n1 / 32) T[k1][n2] ],
+        //     T[k1][n2] = sum_{k2 < 16} R[k1 + 32 k2] e^(2 pi i k2 n2 / 32)      (bins 1 .. 511 and, at half weight, bin 0)
+        // T is ONE matrix-core step per real product (K = 16 = the k2 of the kept half-spectrum): the A operand is R exactly where the
+        // forward transform left the spectra — lane (k1, g) holds k2 = mfma_row(j, g), j < 8, and the constant B operand is built in that
+        // order —, hi / lo f16 terms as everywhere (R has unit modulus: scale 2^14).  The lags kept are n1 = 0 (lag n2) and n1 = 31 (lag
+        // n2 - 32): the outer sum is 16 complex multiply-adds per lane on the accumulators it holds (k1 = mfma_row(r, g)), the two halves
+        // of the wave meet in one v_permlane32_swap, and lane l ends with the lag of output row (l + n_mels / 2) mod 64.
+        // (Before: three packed 1 024-point inverse FFTs through LDS per frame: 0.077 ms per clip against the foa form's 0.022.)
+        const h16x8* gf = reinterpret_cast<const h16x8*>(gtab);                       // [(re | im | -im) * 2 + (hi | lo)][lane]
+        const float4* go = reinterpret_cast<const float4*>(gtab + 6 * 1024);         // [r][lane]: {Re c0, -Im c0, Re c31, -Im c31} x 2 / N x 2^-24
+        const h16x8 frh = gf[0 * 64 + lane], frl = gf[1 * 64 + lane], fih = gf[2 * 64 + lane], fil = gf[3 * 64 + lane];
+        const h16x8 fnh = gf[4 * 64 + lane], fnl = gf[5 * 64 + lane];
+        const int half = n_mels >> 1;
+        // lower lanes: lag n2 -> row n2 + half (valid for n2 < half); upper lanes: lag n2 - 32 -> row n2 - (32 - half) (valid for n2 >= 32 - half)
+        const int orow = lane < 32 ? lane + half : (lane - 32) - (32 - half);
+        const bool ook = lane < 32 ? lane < half : orow >= 0;
+        const float sgn = (lane & 1) ? -1.f / (float)N : 1.f / (float)N;             // (-1)^n2 / N
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {                           // pair order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+            const int ca = pr < 3 ? 0 : (pr < 5 ? 1 : 2), cb = pr == 0 ? 1 : ((pr == 1 || pr == 3) ? 2 : 3);
+            unsigned rrh[4], rrl[4], rih[4], ril[4];
+            float r512 = 1.f;
+#pragma unroll
+            for (int i = 0; i < NBI; i += 2) {
+                float pr_[2], pi_[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ii = i + h < NBI ? i + h : 0;
+                    const float2 xa = ca == 0 ? X0[ii] : XS[ca - 1][ii], xb = XS[cb - 1][ii];
+                    const float rr = xa.x * xb.x + xa.y * xb.y, ri = xa.x * xb.y - xa.y * xb.x;
+                    const float m2 = rr * rr + ri * ri, inv = __builtin_amdgcn_rsqf(m2) * 16384.f;
+                    pr_[h] = m2 > 0.f ? rr * inv : 16384.f;        // angle(0) = 0
+                    pi_[h] = m2 > 0.f ? ri * inv : 0.f;
+                    if (i + h == 0 && lane == 0) { pr_[h] = rr < 0.f ? -8192.f : 8192.f; pi_[h] = 0.f; }      // bin 0: real, half weight
+                    if (i + h == 8) r512 = rr < 0.f ? -1.f : 1.f;                                              // bin 512: real, added below
+                }
+                if (i < 8) {
+                    dft_split_pair(pr_[0], pr_[1], rrh[i >> 1], rrl[i >> 1]);
+                    dft_split_pair(pi_[0], pi_[1], rih[i >> 1], ril[i >> 1]);
+                }
+            }
+            const h16x8 arh = dft_frag(rrh), arl = dft_frag(rrl), aih = dft_frag(rih), ail = dft_frag(ril);
+            f32x16 tr = zero16(), ti = zero16();
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, frh, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, fih, ti, 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, fnh, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, frh, ti, 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, frh, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, fih, ti, 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, fnh, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, frh, ti, 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, frl, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, fil, ti, 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, fnl, tr, 0, 0, 0);
+            ti = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, frl, ti, 0, 0, 0);
+            float p0 = 0.f, p31 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 cc = go[r * 64 + lane];
+                p0 = fmaf(tr[r], cc.x, fmaf(ti[r], cc.y, p0));
+                p31 = fmaf(tr[r], cc.z, fmaf(ti[r], cc.w, p31));
+            }
+            // lower lanes keep lag n2 (n1 = 0), upper lanes lag n2 - 32 (n1 = 31): [p0 low | p31 low] + [p0 high | p31 high]
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p31), false, false);
+            const float cc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + sgn * r512;
+            if (ook) stage[orow * C_OUT + 4 + pr] = cc;
+        }
+        WAVE_LDS_FENCE();
+        }
         FEAT_TR(7)
         for (int j = lane; j < n_mels * C_OUT / 4; j += 64) reinterpret_cast<float4*>(frame_out)[j] = reinterpret_cast<const float4*>(stage)[j];
         WAVE_LDS_FENCE();
@@ -860,7 +940,7 @@ __global__ __launch_bounds__(64 * DFT_WAVES, 1) void feat_dft_kernel(
     __syncthreads();
     if (tid == 0) {
         float m = -INFINITY, n = INFINITY;
-        for (int w = 0; w < DFT_WAVES; ++w) { m = fmaxf(m, red[w]); n = fminf(n, red[16 + w]); }
+        for (int w = 0; w < WAVES; ++w) { m = fmaxf(m, red[w]); n = fminf(n, red[16 + w]); }
         gmax[blockIdx.x] = m;
         gmin[blockIdx.x] = n;
     }
@@ -1059,9 +1139,9 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
     hipMemcpy(f->mel_cnt4, mcnt4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_off4, moff4.data(), n_mels * sizeof(int), hipMemcpyHostToDevice);
     hipMemcpy(f->mel_w4, mw4.data(), mw4.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (mode == 0 && n_fft == 1024) {
+    if (n_fft == 1024) {
         // feat_dft_kernel's constants, in the lane order of the MFMA operands (see the kernel's header comment)
-        std::vector<unsigned short> tab(DFT_TAB_BYTES / 2, 0);
+        std::vector<unsigned short> tab((DFT_TAB_BYTES + (mode == 1 ? GCC_TAB_BYTES : 0)) / 2, 0);
         auto mrow = [](int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; };
         for (int sidx = 0; sidx < 2; ++sidx)
             for (int lane = 0; lane < 64; ++lane) {
@@ -1090,10 +1170,36 @@ int seld_feat_create(int sample_rate, int n_fft, int win_length, int hop_length,
                 tw2[(r * 64 + lane) * 2] = (float)(cos(ang) / 32768.0);
                 tw2[(r * 64 + lane) * 2 + 1] = (float)(sin(ang) / 32768.0);
             }
-        if (hipMalloc(&f->dft_tab, DFT_TAB_BYTES) != hipSuccess) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
-        hipMemcpy(f->dft_tab, tab.data(), DFT_TAB_BYTES, hipMemcpyHostToDevice);
+        if (mode == 1) {
+            // mic: the pruned inverse transform of GCC-PHAT (see the kernel).  B operand of T = R F: column n2 = lane & 31, K slot (g, j) = k2 =
+            // mfma_row(j, g): F = exp(+2 pi i k2 n2 / 32) x 2^10 as re | im | -im, hi | lo; then the outer stage's constants per accumulator
+            // register r and lane: k1 = mfma_row(r, g), c0 = exp(2 pi i k1 n2 / 1024), c31 = c0 exp(-2 pi i k1 / 32), as {Re, -Im} x 2 / N x 2^-24
+            unsigned short* gt = tab.data() + DFT_TAB_BYTES / 2;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k2 = mrow(j, lane >> 5), n2 = lane & 31;
+                    const double ang = 2.0 * PI * (double)((k2 * n2) & 31) / 32.0;
+                    const double v[3] = {cos(ang) * 1024.0, sin(ang) * 1024.0, -sin(ang) * 1024.0};
+                    for (int q = 0; q < 3; ++q) {
+                        unsigned short h, l;
+                        feat_split_h(v[q], h, l);
+                        gt[((q * 2 + 0) * 64 + lane) * 8 + j] = h; gt[((q * 2 + 1) * 64 + lane) * 8 + j] = l;
+                    }
+                }
+            float* go = reinterpret_cast<float*>(gt + 6 * 512);
+            const double sc = 2.0 / 1024.0 / 16777216.0;
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k1 = mrow(r, lane >> 5), n2 = lane & 31;
+                    const double a0 = 2.0 * PI * (double)(k1 * n2) / 1024.0, a31 = a0 - 2.0 * PI * (double)k1 / 32.0;
+                    float* e = go + (r * 64 + lane) * 4;
+                    e[0] = (float)(cos(a0) * sc); e[1] = (float)(-sin(a0) * sc); e[2] = (float)(cos(a31) * sc); e[3] = (float)(-sin(a31) * sc);
+                }
+        }
+        if (hipMalloc(&f->dft_tab, tab.size() * 2) != hipSuccess) { seld_feat_destroy(f); return ffail(nullptr, SELD_ERR_NOMEM, "hipMalloc failed"); }
+        hipMemcpy(f->dft_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
     }
-    if (mode == 0 && n_fft == 1024 && n_mels <= 64) {
+    if (n_fft == 1024 && n_mels <= 64) {
         // the mel projection as 4 x 4 x 4 blocks (see feat_dft_kernel's mel_round): group g = mels 4 g .. 4 g + 3 runs over bins
         // [gs, ge), gs a multiple of 4, cut into slots of four steps of four bins; slot v goes to block v & 15 of sequence v >> 4
         struct Slot { int g, bin; };
@@ -1194,26 +1300,31 @@ int seld_feat_extract_batch(seld_feat* f, const float* wav, int n_clips, int n_c
     int nparts = 0;
     bool launched = false, have_min = false;
     // wave-per-frame kernel: n_fft 256 .. 1024 (2048 spills registers: the workgroup kernel serves it), n_mels <= 128
-    // foa, n_fft 1024, n_mels <= 64: the transform AND the mel projection on the matrix cores (feat_dft_kernel)
-    const size_t dft_tables = (size_t)N * sizeof(float) + 32 * sizeof(float) + (size_t)f->n_mel_mm * 16 + DFT_TAB_BYTES;
-    const size_t dft_wb = (((size_t)4 * (N / 2 + 4) + (size_t)f->n_mels * 7 + 8) * sizeof(float) + 15) & ~(size_t)15;      // (+ 8: where idle blocks add their zeros)
+    // n_fft 1024, n_mels <= 64: the transform(s) AND the mel projection on the matrix cores (feat_dft_kernel; foa 12 waves, mic 8)
+    const int dft_waves = DFT_WAVES_OF(f->mode), dft_cout = f->mode == 0 ? 7 : 10;
+    const size_t dft_tables = (size_t)N * sizeof(float) + 32 * sizeof(float) + (size_t)f->n_mel_mm * 16 + DFT_TAB_BYTES + (f->mode == 1 ? GCC_TAB_BYTES : 0);
+    const size_t dft_wb = (((size_t)4 * (N / 2 + 4) + (size_t)f->n_mels * dft_cout + 8) * sizeof(float) + 15) & ~(size_t)15;
     if (f->dft_tab && f->mel_mm && f->use_dft && f->use_wave_kernel && (f->n_mels & 3) == 0 && n_samples < (int64_t)1 << 30 &&
-        dft_tables + DFT_WAVES * dft_wb <= 160 * 1024) {
+        dft_tables + dft_waves * dft_wb <= 160 * 1024) {
         const size_t tables = dft_tables;
         const size_t wb = dft_wb;                                   // the four per-bin planes of a wave + its staged output frame
-        const size_t smem = tables + DFT_WAVES * wb;
-        // persistent workgroups: one per CU over the whole batch (a workgroup loads 30 KB of tables; a wave that walks several frames
+        const size_t smem = tables + dft_waves * wb;
+        // persistent workgroups: one per CU over the whole batch (a workgroup loads its tables once; a wave that walks several frames
         // has the next frame's first channel in flight while it finishes the current one)
-        int64_t blocks = (T + DFT_WAVES - 1) / DFT_WAVES;
+        int64_t blocks = (T + dft_waves - 1) / dft_waves;
         const int64_t per_clip = std::max<int64_t>(1, (256 + n_clips - 1) / n_clips);
         if (blocks > per_clip) blocks = per_clip;
-#define FEAT_DFT_CASE(Q_)                                                                                                       \
+#define FEAT_DFT_CASE(Q_, M_)                                                                                                   \
         {                                                                                                                       \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(feat_dft_kernel<Q_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);       \
-            hipLaunchKernelGGL(feat_dft_kernel<Q_>, dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * DFT_WAVES), smem, st, wav, n_samples, T, f->hop, \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(feat_dft_kernel<Q_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+            hipLaunchKernelGGL((feat_dft_kernel<Q_, M_>), dim3((unsigned)blocks, (unsigned)n_clips), dim3(64 * DFT_WAVES_OF(M_)), smem, st, wav, n_samples, T, f->hop, \
                                f->n_mels, f->win, f->dft_tab, f->mel_mm, f->n_mel_mm, f->mel_mm_pmax, out, f->gmax, f->gmax + (size_t)f->gmax_clips * FEAT_MAX_PARTS, (int)wb); \
         }
-        if (f->mel_mm_seq == 1) FEAT_DFT_CASE(1) else if (f->mel_mm_seq == 2) FEAT_DFT_CASE(2) else if (f->mel_mm_seq == 3) FEAT_DFT_CASE(3) else FEAT_DFT_CASE(4)
+        if (f->mode == 0) {
+            if (f->mel_mm_seq == 1) FEAT_DFT_CASE(1, 0) else if (f->mel_mm_seq == 2) FEAT_DFT_CASE(2, 0) else if (f->mel_mm_seq == 3) FEAT_DFT_CASE(3, 0) else FEAT_DFT_CASE(4, 0)
+        } else {
+            if (f->mel_mm_seq == 1) FEAT_DFT_CASE(1, 1) else if (f->mel_mm_seq == 2) FEAT_DFT_CASE(2, 1) else if (f->mel_mm_seq == 3) FEAT_DFT_CASE(3, 1) else FEAT_DFT_CASE(4, 1)
+        }
 #undef FEAT_DFT_CASE
         launched = true; nparts = (int)blocks; have_min = true;
     }

@@ -44,19 +44,42 @@ def test_extract_features(seld_lib, mode, sr, kw, wave_kernel):
     check(f"{mode} spatial channels [{sr}]", got[..., 4:], ref[..., 4:])
 
 
+@pytest.mark.parametrize("mode", ["foa", "mic"])
 @pytest.mark.parametrize("n_mels", [32, 40, 64])
-def test_matrix_core_mel_projection_other_bank_sizes(seld_lib, n_mels):
-    """foa, n_fft 1024: the mel projection runs as 4 x 4 x 1 matrix-core blocks whose slot table is built from the filter bank
-    (features.hip, mel_round): banks that leave blocks idle (32, 40 mels) against the fp64 oracle as well."""
+def test_matrix_core_mel_projection_other_bank_sizes(seld_lib, n_mels, mode):
+    """n_fft 1024: the mel projection runs as 4 x 4 x 1 matrix-core blocks whose slot table is built from the filter bank
+    (features.hip, mel_round): banks that leave blocks idle (32, 40 mels) against the fp64 oracle as well; in mic mode n_mels is also
+    the number of GCC-PHAT lags kept (-n_mels/2 .. n_mels/2 - 1: which lanes of the pruned inverse transform store)."""
     from oracle import features_oracle as FO
     from seld_amd import feature_extractor as FE
     kw = dict(win_length=960, hop_length=480, n_fft=1024)
     wav = _wav(24000 * 2 + 55, seed=11)
-    ref = FO.extract_features(wav, 24000, mode="foa", n_mels=n_mels, dtype=torch.float64, **kw)
-    got = FE.FeatureExtractor(24000, "foa", n_mels, **kw)(wav).cpu().numpy()
+    ref = FO.extract_features(wav, 24000, mode=mode, n_mels=n_mels, dtype=torch.float64, **kw)
+    got = FE.FeatureExtractor(24000, mode, n_mels, **kw)(wav).cpu().numpy()
     assert got.shape == ref.shape
-    check(f"log-mel [{n_mels} mels]", got[..., :4], ref[..., :4])
-    check(f"intensity [{n_mels} mels]", got[..., 4:], ref[..., 4:])
+    check(f"{mode} log-mel [{n_mels} mels]", got[..., :4], ref[..., :4])
+    check(f"{mode} spatial channels [{n_mels} mels]", got[..., 4:], ref[..., 4:])
+
+
+@pytest.mark.parametrize("dft", [1, 0])
+def test_mic_long_clip_gcc_phat(seld_lib, dft):
+    """mic mode at the dataset's transform size on a 20-s clip with a silent second (bins where angle(0) = 0 applies,
+    feature_extractor.py:196-214): dft 1 = the matrix-core kernel (forward transforms and the pruned inverse transform of GCC-PHAT as
+    32 x 32 products), dft 0 = the radix-4 wave kernel it replaced as the default — both against the fp64 oracle."""
+    from oracle import features_oracle as FO
+    from seld_amd import feature_extractor as FE
+    kw = dict(win_length=960, hop_length=480, n_fft=1024)
+    n = 24000 * 20 + 311
+    wav = _wav(n, seed=9, scale=0.05)
+    wav[:, n // 2: n // 2 + 24000] = 0.0
+    ref = FO.extract_features(wav, 24000, mode="mic", dtype=torch.float64, **kw)
+    fx = FE.FeatureExtractor(24000, "mic", 64, **kw)
+    fx.set_option("dft", dft)
+    got = fx(wav).cpu().numpy()
+    assert got.shape == ref.shape == (1 + n // 480, 64, 10)
+    check(f"mic log-mel [dft {dft}]", got[..., :4], ref[..., :4])
+    check(f"mic gcc-phat [dft {dft}]", got[..., 4:], ref[..., 4:])
+    assert np.abs(ref[..., 4:]).max() > 0.5          # (the zero-lag peak of a correlated pair: the comparison is not against noise)
 
 
 def test_zeros_like_reference_smoke(seld_lib):
