@@ -232,7 +232,14 @@ def features_leg(dev, clips=8, reps=6):
     bytes_clip = 4 * n * 4 + 3000 * 64 * 7 * 4
     assert tuple(out.shape) == (clips, 3001, 64, 7) and bool(torch.isfinite(out).all()) and bool(torch.equal(out[-1], out1))
     ach = bytes_clip / per / 1e9
-    return {"stage": f"feature_extractor foa n_fft 1024 / win 960 / hop 480 -> [3001,64,7], 60-s clips resident in HBM, {clips} clips per launch pair",
+    # the other mode of extract_features (feature_extractor.py:196-214: four log-mel channels + six GCC-PHAT pairs -> [3001,64,10]), same clips
+    fm = FE.FeatureExtractor(24000, "mic", 64, win_length=960, hop_length=480, n_fft=1024, device=dev.index)
+    per_m, out_m = timed(lambda: fm.batch(wavs), clips)
+    bytes_mic = 4 * n * 4 + 3000 * 64 * 10 * 4
+    assert tuple(out_m.shape) == (clips, 3001, 64, 10) and bool(torch.isfinite(out_m).all())
+    mic = {"clips_per_s": round(1 / per_m, 1), "ms_per_clip": round(per_m * 1e3, 4), "algorithmic_bytes_per_clip": bytes_mic,
+           "achieved_GBps": round(bytes_mic / per_m / 1e9, 1)}
+    return {"stage": f"feature_extractor foa n_fft 1024 / win 960 / hop 480 -> [3001,64,7], 60-s clips resident in HBM, {clips} clips per launch pair", "mic_mode": mic,
             "clips_per_s": round(1 / per, 1), "ms_per_clip": round(per * 1e3, 4), "algorithmic_bytes_per_clip": bytes_clip,
             "clip_by_clip": {"clips_per_s": round(1 / per1, 1), "ms_per_clip": round(per1 * 1e3, 4)},
             "roofline": {"kernel": "feat_frame", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
