@@ -246,6 +246,32 @@ def features_leg(dev, clips=8, reps=6):
                          "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None}}
 
 
+def inference_leg(dev, local, files=4, reps=3, batch=271):
+    """The reference's inference path (trainv2.ensemble_outputs, trainv2.py:158-192 = evaluator.py:16-50) on normalised 60-s feature files
+    [3000,64,7] resident in HBM: 541 windows of 300 frames (step 5) through seldnet.json's forward in batches, overlap-averaged to
+    [600, 12 | 36] — files/s and windows/s, timed with HIP events on the stream the calls go to."""
+    from seld_amd import evaluator, models
+    model = models.seldnet((batch, 300, 64, 7), model_config_of("seldnet"), device=local)
+    rng = np.random.default_rng(1)
+    xs = [torch.as_tensor(rng.standard_normal((3000, 64, 7)).astype(np.float32)).to(dev) for _ in range(files)]
+    st = torch.cuda.current_stream(dev)
+    for _ in range(2):
+        out = evaluator.ensemble_outputs(model, xs, win_size=300, step_size=5, batch_size=batch)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.synchronize()
+    e0.record(st)
+    for _ in range(reps):
+        out = evaluator.ensemble_outputs(model, xs, win_size=300, step_size=5, batch_size=batch)
+    e1.record(st)
+    st.synchronize()
+    per = e0.elapsed_time(e1) / 1e3 / (reps * files)
+    assert tuple(out[0][0].shape) == (600, 12) and tuple(out[0][1].shape) == (600, 36) and bool(torch.isfinite(out[-1][1]).all())
+    model.close()
+    return {"stage": f"ensemble_outputs: 60-s file [3000,64,7] -> 541 windows x 300 frames (step 5), batches of {batch}, overlap average -> [600,12|36]",
+            "files_per_s": round(1 / per, 1), "ms_per_file": round(per * 1e3, 3), "windows_per_s": round(541 / per, 1),
+            "clip_equivalents_per_s": round(54.1 / per, 1)}
+
+
 def model_config_of(name):
     import copy
     cfg = copy.deepcopy(SELDNET_CONFIG)
@@ -476,6 +502,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="cpu_baseline at the GPU batch: fewer than --cpu-steps steps are timed (never fewer than 3) if they would exceed this")
     ap.add_argument("--no-features", action="store_true", help="skip the feature-stage leg")
+    ap.add_argument("--no-inference", action="store_true", help="skip the sliding-window inference leg")
     ap.add_argument("--no-configs", action="store_true",
                     help="N=1, --model seldnet only: skip the `configs` sub-records (BASELINE configs[3] xception_gru and configs[4] resnet50_gru "
                          "with in-step features, each timed like the headline after it)")
@@ -541,6 +568,8 @@ def main():
             out["features"]["roofline"]["kernel"] = "feat_dft" if "feat_dft" in traffic_tab else "feat_frame"
         del model
         res["model"] = None
+        if world == 1 and args.model == "seldnet" and not args.no_inference and not args.opt:
+            out["inference"] = inference_leg(dev, local)
         if world == 1 and args.model == "seldnet" and not args.no_configs and not args.opt and T == 3000:
             # BASELINE.json configs[3] and configs[4] as sub-records of the same driver-timed run: each its own model, warm-ups, barrier-
             # bracketed timed steps and rooflines (configs[4] = the per-GPU share, 16 clips, of the batch-128 DP-8 job, features in the step)
