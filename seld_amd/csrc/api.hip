@@ -106,13 +106,6 @@ struct seld_ctx {
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
-    // simple_conv_block backward: the kernel gradients of blocks 2.. run on a second side stream beside the input-gradient chain (both read
-    // the block's dz; each alone leaves matrix-core time unused: conv3 0.32-0.34, conv2 0.55-0.61 of the cycles) — their own slabs, ev_dz:
-    // dz is written, ev_wg: the kernel gradient has read it (the next block's dz may overwrite the buffer), ev_join2 at the end of the pass
-    hipStream_t side2 = nullptr;
-    hipEvent_t ev_dz = nullptr, ev_wg = nullptr, ev_join2 = nullptr;
-    float* wgrad_slab2 = nullptr;
-    int conv_wgrad_side = 1;
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
     unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
@@ -203,16 +196,15 @@ void add_var(std::vector<Var>& v, int64_t& off, const std::string& name, std::in
 
 struct ProfScope {
     seld_ctx* c; int idx;
-    hipStream_t s;             // the stream the scope's kernels go to (default: the context's)
-    ProfScope(seld_ctx* c_, const char* name, int level = 1, hipStream_t s_ = nullptr) : c(c_), idx(-1), s(s_ ? s_ : c_->stream) {
+    ProfScope(seld_ctx* c_, const char* name, int level = 1) : c(c_), idx(-1) {
         if (c->prof < level) return;
         for (size_t i = 0; i < c->timers.size(); ++i) if (c->timers[i].name == name) idx = (int)i;
         if (idx < 0) { Timer t; t.name = name; c->timers.push_back(t); idx = (int)c->timers.size() - 1; }
-        hipEvent_t e = take(c); hipEventRecord(e, s); c->timers[idx].ev.push_back(e);
+        hipEvent_t e = take(c); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
     }
     ~ProfScope() {
         if (idx < 0) return;
-        hipEvent_t e = take(c); hipEventRecord(e, s); c->timers[idx].ev.push_back(e);
+        hipEvent_t e = take(c); hipEventRecord(e, c->stream); c->timers[idx].ev.push_back(e);
         c->timers[idx].launches++;
     }
     static hipEvent_t take(seld_ctx* c) {
@@ -512,7 +504,6 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
     ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
-    ALLOC(c->wgrad_slab2, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
     ALLOC(c->tn_slab, (size_t)tn_slab_capacity());
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
@@ -543,11 +534,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         // ev_join and the bucket events cross to a caller's communication stream (RCCL reads the gradients there and writes
         // them to peers): they keep the default system-scope release
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_dz, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_wg, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
     }
@@ -616,10 +603,6 @@ void seld_destroy(seld_ctx* c) {
     for (auto e : c->ev_bucket) if (e) hipEventDestroy(e);
     seld_dp_destroy(c);
     if (c->side) hipStreamDestroy(c->side);
-    if (c->side2) hipStreamDestroy(c->side2);
-    if (c->ev_dz) hipEventDestroy(c->ev_dz);
-    if (c->ev_wg) hipEventDestroy(c->ev_wg);
-    if (c->ev_join2) hipEventDestroy(c->ev_join2);
     for (void* p : c->allocs) hipFree(p);
     delete c;
 }
@@ -636,7 +619,6 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv64_split_bf16")) { c->conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_split_bf16")) { c->gemm_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "heads_fused")) { c->heads_fused = value != 0; return SELD_OK; }
-    if (!strcmp(key, "conv_wgrad_side")) { c->conv_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "dropout_seed")) { c->dropout_seed = 0x5e1d5e1d00000000ull ^ (uint64_t)(unsigned)value; return SELD_OK; }      // the masks are a function of (seed, step, layer, element)
     if (!strcmp(key, "dropout_step")) { c->dropout_step = (unsigned)value; return SELD_OK; }                                         // the NEXT training forward's step counter
     if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
@@ -1586,7 +1568,6 @@ static int backward_impl(seld_ctx* c, const float* x) {
             if (busy[k]) hipStreamWaitEvent(st, c->ev_rn_free[k], 0);
         dp = c->conv[0].dp;
     }
-    bool wg_pending = false;      // a kernel gradient on the second side stream still reads dzbuf
     for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
         ConvL& L = c->conv[i];
         int np = 0;
@@ -1608,7 +1589,6 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
         int ns = 0;
         const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
-        if (wg_pending && !(i == 0 && c->gram_active)) { hipStreamWaitEvent(st, c->ev_wg, 0); wg_pending = false; }     // the previous block's kernel gradient has read dzbuf
         if (!fused_first) {
             snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
             PROF2(c, tn);
@@ -1639,21 +1619,15 @@ static int backward_impl(seld_ctx* c, const float* x) {
         } else {
             const float* lin = c->conv[i - 1].p;
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
-            // the kernel gradient beside the input gradient: second side stream, its own slabs
-            const bool ws = c->conv_wgrad_side && c->side2;
-            hipStream_t sw = ws ? c->side2 : st;
-            float* slab = ws ? c->wgrad_slab2 : c->wgrad_slab;
-            if (ws) { hipEventRecord(c->ev_dz, st); hipStreamWaitEvent(sw, c->ev_dz, 0); }
             {
-                ProfScope wscope(c, tn, 2, sw);
+                PROF2(c, tn);
                 if (c->conv64_split_bf16 && conv64_wgrad_sb_usable(L.W)) {
-                    if (launch_conv64_wgrad_sb(sw, lin, c->dzbuf, slab, &ns, B, L.H, L.W))
+                    if (launch_conv64_wgrad_sb(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
                         return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad_sb");
-                } else if (launch_conv64_wgrad(sw, lin, c->dzbuf, slab, &ns, B, L.H, L.W))
+                } else if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
             }
-            launch_reduce_slabs(sw, slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
-            if (ws) { hipEventRecord(c->ev_wg, sw); wg_pending = true; }
+            launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
                 PROF2(c, tn);
@@ -1671,10 +1645,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
     if (c->fin_sl)
         launch_losses_finalize(c->side, c->fin_doa_loss, c->den_dev, c->fin_sl, c->fin_dl, c->loss_scratch, c->B, c->S, c->arch.n_classes);
     c->fin_sl = nullptr;
-    // join: the side streams' weight gradients must be complete before Adam / the DP all-reduce
+    // join: the side stream's weight gradients must be complete before Adam / the DP all-reduce
     hipEventRecord(c->ev_join, c->side);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (c->side2) { hipEventRecord(c->ev_join2, c->side2); hipStreamWaitEvent(c->stream, c->ev_join2, 0); }
     if (c->last_training) ++c->dropout_step;          // the next training step draws new dropout masks
     return check_launch(c, "backward");
 }
