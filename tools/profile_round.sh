@@ -10,13 +10,13 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd "$root"
 timeout -k 10 400 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-features --no-configs --timing-level 2 > "$out/bench_l2.json" 2>> "$out/bench.err"
+timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-features --no-inference --no-configs --timing-level 2 > "$out/bench_l2.json" 2>> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- \
-    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-configs > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.log"
+    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-inference --no-configs > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o pmc -- \
-        python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-features --no-kernel-timing --no-configs > /dev/null 2> "$out/rocprof_$c.log"
+        python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-features --no-inference --no-kernel-timing --no-configs > /dev/null 2> "$out/rocprof_$c.log"
 done
 f=$(find "$out/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 w=$(find "$out/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
@@ -36,7 +36,7 @@ find "$out/feat_stats" -name '*kernel_trace.csv' -delete
 # seldnet.json in bf16 single-product mode (BASELINE configs[1]'s literal wording): kernel stats
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bf16_stats" -o bf16 -- \
-    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-configs --no-kernel-timing --opt bf16_single=1 > "$out/bench_bf16_under_rocprof.json" 2> "$out/rocprof_bf16.log"
+    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-inference --no-configs --no-kernel-timing --opt bf16_single=1 > "$out/bench_bf16_under_rocprof.json" 2> "$out/rocprof_bf16.log"
 find "$out/bf16_stats" -name '*kernel_trace.csv' -delete
 # BASELINE config 4 (xception_gru.json; FIRST block per spec/XCEPTION_BLOCK.md): bench line + kernel stats
 cd "$root"
