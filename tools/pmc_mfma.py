@@ -17,6 +17,8 @@ GROUPS = {  # group -> (kernel-name substring, fp32-equivalent GFLOP per launch 
     "gemm_sb (4-wave: GRU in-projections, dX)": "gemm_sb_kernel", "gemm_sb16 (16-wave)": "gemm_sb16_kernel",
     "gemm_tn_sb (GRU kernel gradients)": "gemm_tn_sb", "gemm_f32 (heads)": "gemm_f32_kernel",
     "gru_fwd": "gru_fwd_kernel", "gru_bwd": "gru_bwd_kernel",
+    # feature stage (tools/profile_mfma_features.sh): the transforms, the mel projection and (mic) GCC-PHAT's inverse transform on the matrix cores
+    "feat_dft (foa, n_fft 1024)": "feat_dft_kernel<3, 0>", "feat_dft (mic, n_fft 1024)": "feat_dft_kernel<3, 1>",
 }
 
 
