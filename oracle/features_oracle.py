@@ -89,6 +89,29 @@ def gcc_features(spec, n_mels: int):
     return torch.stack(out, 0)
 
 
+def gcc_pruned_inverse_model(R: np.ndarray, n_lags: int = 64) -> np.ndarray:
+    """Index model of the inverse transform features.hip's mic kernel uses for GCC-PHAT (n_fft 1024): irfft of the half spectrum R[0..512]
+    evaluated ONLY at the n_lags kept lags, as two stages of 32-point sums.  With k = k1 + 32 k2 (k2 < 16: bins 0 .. 511) and n = n2 + 32 n1,
+        T[k1][n2] = sum_k2 R[k1 + 32 k2] exp(2 pi i k2 n2 / 32)                 (bin 0 at half weight; one matrix-core step per real product)
+        cc[n]     = (1/N) [ 2 Re sum_k1 exp(2 pi i k1 n2 / 1024) exp(2 pi i k1 n1 / 32) T[k1][n2] + (-1)^n Re R[512] ]
+    and only n1 = 0 (lags 0 .. 31) and n1 = 31 (lags -32 .. -1) are formed.  Returns cc[-n_lags/2 :] || cc[: n_lags/2] like gcc_features.
+    tests/test_features_cpu.py holds it against numpy's irfft."""
+    N = 1024
+    R = np.asarray(R, np.complex128).copy()
+    assert R.shape == (N // 2 + 1,)
+    r512 = R[512].real
+    R[0] = 0.5 * R[0].real                                  # irfft ignores the imaginary parts of bins 0 and N/2
+    k1, k2, n2 = np.arange(32), np.arange(16), np.arange(32)
+    Rm = R[:512].reshape(16, 32).T                          # [k1][k2] = R[k1 + 32 k2]
+    T = Rm @ np.exp(2j * np.pi * np.outer(k2, n2) / 32)     # [k1][n2]
+    out = {}
+    for n1 in (0, 31):
+        c = np.exp(2j * np.pi * np.outer(k1, n2) / N) * np.exp(2j * np.pi * k1 * n1 / 32)[:, None]
+        out[n1] = (2.0 * (c * T).sum(0).real + (-1.0) ** n2 * r512) / N
+    h = n_lags // 2
+    return np.concatenate([out[31][32 - h:], out[0][:h]])
+
+
 def extract_features(wav, sample_rate, mode="foa", n_mels=64, dtype=torch.float32, **kwargs) -> np.ndarray:
     """reference feature_extractor.extract_features (53-88) -> [time, n_mels, 7|10]"""
     wav = torch.as_tensor(np.asarray(wav)).to(dtype)

@@ -63,3 +63,17 @@ def test_radix4_stockham_model_matches_numpy_fft():
     for n in (256, 512, 1024, 2048):
         x = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
         np.testing.assert_allclose(FO.stockham_fft_radix4(x), np.fft.fft(x), atol=1e-10)
+
+
+def test_pruned_inverse_transform_model_matches_irfft():
+    """The mic kernel's GCC-PHAT inverse transform (two stages of 32-point sums, only the kept lags: features_oracle.gcc_pruned_inverse_model)
+    against numpy's irfft on unit-modulus half spectra, as feature_extractor.gcc_features forms them (feature_extractor.py:196-214)."""
+    rng = np.random.default_rng(0)
+    for n_lags in (64, 40, 32):
+        ph = rng.uniform(-np.pi, np.pi, 513)
+        ph[0], ph[512] = 0.0, np.pi                          # real end bins (+1 and -1), as the spectra of real signals have
+        R = np.exp(1j * ph)
+        cc = np.fft.irfft(R, 1024)
+        want = np.concatenate([cc[-n_lags // 2:], cc[:n_lags // 2]])
+        got = FO.gcc_pruned_inverse_model(R, n_lags)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-13
