@@ -27,7 +27,15 @@ __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __res
     const int d = (int)(i % D), t = (int)(i / D);
     const int wlo = max(0, t - L + 1), whi = min(n_win - 1, t);
     float s = 0.f;
-    for (int w = wlo; w <= whi; ++w) s += y[((size_t)w * L + (t - w)) * D + d];
+    int w = wlo;
+    for (; w + 7 <= whi; w += 8) {           // eight loads in flight, added in window order (one dependent load per window took 28 us for 21 600 outputs)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = y[((size_t)(w + k) * L + (t - w - k)) * D + d];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; w <= whi; ++w) s += y[((size_t)w * L + (t - w)) * D + d];
     out[i] = s / (float)(whi - wlo + 1);
 }
 
