@@ -334,8 +334,11 @@ def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_
                      "frac_of_fp32_peak_of_used_cus": round(floor / cyc, 4),
                      "clock_MHz": round(valu_clock_mhz), "phase_split": "profiles/r03_gru_experiments.txt (in-kernel timeline: the two waves of a SIMD "
                      "queue; gate tail = a chain of ~20 dependent VALU ops at 8.3-17.6 cycles each)"}
+        tr = traffic_tab.get(name, {}).get("hbm_bytes_per_launch")
+        if tr is not None:      # a STORED counter pass (another run of the build named in the table), never this run's
+            extra["traffic_source"] = "profiles/traffic.json: " + str(traffic_tab.get("_provenance", ""))[:90]
         return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                "frac": round(ach / peak, 4), "traffic": traffic_tab.get(name, {}).get("hbm_bytes_per_launch"),
+                "frac": round(ach / peak, 4), "traffic": tr,
                 "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // steps, "ms_per_step": round(ms / steps, 4),
                 **({"mfma_path": path} if path else {}), **extra}
 
@@ -367,11 +370,15 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
         # RCCL process group: the LIBRARY owns the communicator, the communication stream and the two gradient buckets (seld_dp_*);
         # over gloo (the one-GPU rehearsal) the torch.distributed path stays
         from seld_amd import parallel
-        if os.environ.get("SELD_DP", "library") != "torch":      # SELD_DP=torch: round 2's torch.distributed collectives on the library's buckets
-            try:
-                parallel.init_library_dp(model)
-            except Exception as e:      # an RCCL that cannot be bound / initialised: the torch.distributed path is a HIP path too
-                print(f"[bench] rank {rank}: library-owned RCCL communicator unavailable ({e}); gradients go through torch.distributed", file=sys.stderr)
+        # SELD_DP=torch selects round 2's torch.distributed collectives on the library's buckets ON EVERY RANK (an environment
+        # variable, the same for all ranks of a torch.distributed.run job).  There is no silent per-rank fallback: init_library_dp
+        # raises on ALL ranks if RCCL cannot be bound / initialised on any of them, and the job ends.
+        if os.environ.get("SELD_DP", "library") != "torch":
+            dp_backend = "library-rccl" if parallel.init_library_dp(model) else f"torch-{dist.get_backend()}"
+        else:
+            dp_backend = f"torch-{dist.get_backend()}"
+    else:
+        dp_backend = "none"
     x, ys, yd = synthetic_batch(B, T, seed=1234 + rank)
     x, ys, yd = (torch.as_tensor(a).to(dev) for a in (x, ys, yd))  # inputs resident in HBM before timing
     opt = train.Adam(1e-3)
@@ -428,7 +435,7 @@ def run_workload(name, B, T, steps, warmup, world, rank, local, dev, *, opts=(),
         elapsed = float(t.item())
     assert np.isfinite(float(sl.item())), "non-finite loss"
     kernels = read_timers(model)
-    res = {"model": model, "elapsed": elapsed, "kernels": kernels, "comm": None, "profile": None}
+    res = {"model": model, "elapsed": elapsed, "kernels": kernels, "comm": None, "profile": None, "dp_backend": dp_backend}
     if world > 1 and allreduce_ablation:
         # exposed communication per step and rank: the same steps again without the gradient all-reduce (timing aid only:
         # replicas then drift apart, nothing is reported from them but the time)
@@ -474,7 +481,7 @@ def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_
         "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": workload_text(name, B, T, with_features) + (" — bf16 single-product mode (SELD_DTYPE_BF16): conv / GEMM operands rounded to "
                                                                              "bf16, fp32 accumulation and tensors; NOT within 1e-4 (DESIGN.md section 3c)" if bf16 else ""),
-                   "global_batch": world * B, "parallelism": f"dp{world}",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "dp_backend": res.get("dp_backend", "none"),
                    "doa_loss": "MSE", "loss_weight": "1,1000"},
         "roofline": roofline, "roofline_by_kernel": per_kernel, "kernel_ms_per_step": breakdown,
     }
@@ -482,6 +489,72 @@ def record(name, B, T, steps, warmup, world, res, opts, traffic_tab, valu_clock_
         out["roofline_pass"] = {"what": "per-kernel HIP-event scopes in a second pass of the same steps (not the pass timed for `value`)",
                                 "ms_per_step_with_events": res["profile"]["ms_per_step_with_events"]}
     return out
+
+
+COMPACT_LIMIT = 3072      # bytes: the driver keeps an 8 KB tail of stdout; the record must fit it with room to spare
+
+
+def compact_record(out, detail_path=None):
+    """The LAST stdout line: the contract's fields + the dominant kernel's roofline + cpu_baseline + three scalars for the
+    sub-configs.  Everything else (per-kernel rooflines, sub-records, peaks read on the box, comm ablation) is the DETAIL record,
+    printed on an earlier line (prefix `BENCH_DETAIL `) and written to `detail_path`.  tests/test_host_logic_cpu.py holds the
+    size bound on a canned full record."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    c = {k: out.get(k) for k in keep}
+    cfg = out.get("config", {})
+    c["config"] = {k: cfg.get(k) for k in ("workload", "global_batch", "parallelism", "dp_backend") if k in cfg}
+    r = out.get("roofline")
+    if r:
+        rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms", "launches_per_step",
+              "ms_per_step", "cycles_per_step", "fp32_floor_cycles_per_step", "frac_of_fp32_peak_of_used_cus", "cus_used")
+        c["roofline"] = {k: r[k] for k in rk if k in r}
+    else:
+        c["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:260]
+        if isinstance(cb.get("b2"), dict):
+            c["cpu_baseline"]["b2_clips_s"] = cb["b2"].get("value")
+        if cb.get("value"):
+            c["gpu_over_cpu"] = round(out["value"] / cb["value"], 1)
+    for key in ("seldnet_bf16", "xception_gru", "resnet50_gru"):
+        sub = out.get("configs", {}).get(key)
+        if sub:
+            c[f"{key}_clips_s"] = sub.get("value")
+    if out.get("features"):
+        c["features_clips_s"] = out["features"].get("clips_per_s")
+        fr = out["features"].get("roofline") or {}
+        c["features_hbm_frac"] = fr.get("frac")
+    if out.get("inference"):
+        c["inference_files_s"] = out["inference"].get("files_per_s")
+    if out.get("conv_stack_mfma"):
+        c["conv_stack_mfma"] = out["conv_stack_mfma"]
+    if detail_path:
+        c["detail"] = detail_path
+    line = json.dumps(c)
+    if len(line) > COMPACT_LIMIT:        # never let optional fields push the record out of the driver's tail
+        for k in ("conv_stack_mfma", "features_hbm_frac", "detail", "gpu_over_cpu"):
+            c.pop(k, None)
+        c["config"]["workload"] = c["config"]["workload"][:200]
+        if c.get("cpu_baseline"):
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:120]
+        line = json.dumps(c)
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def conv_stack_mfma(per_kernel):
+    """FLOP-weighted useful fraction of the conv stack's MFMA ceiling in THIS run (HIP-event times; the counter-based busy
+    fraction is a separate rocprofv3 --pmc pass, profiles/*_mfma_util.json)."""
+    rows = [r for k, r in per_kernel.items() if k.startswith("conv") and r["bound"] == "mfma"]
+    if not rows:
+        return None
+    t = sum(r["ms_per_step"] for r in rows)
+    fl = sum(r["achieved"] * r["ms_per_step"] for r in rows)        # TFLOP/s x ms
+    pk = sum(r["peak"] * r["ms_per_step"] for r in rows)
+    return {"useful_frac_of_ceiling": round(fl / pk, 4), "TFLOPs_fp32_equivalent": round(fl / t, 1), "ms_per_step": round(t, 4)}
 
 
 def main():
@@ -510,6 +583,9 @@ def main():
                     help="model_config of the reference: seldnet.json (the headline, BASELINE configs[1]), xception_gru.json "
                          "(configs[3]) or resnet50_gru.json (configs[4]); the FIRST blocks of the latter two are defined by "
                          "spec/XCEPTION_BLOCK.md / spec/RESNET50_BLOCK.md: absent from the reference snapshot")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the DETAIL record (per-kernel rooflines, sub-records, peaks read on the box) is written; it is also printed "
+                         "on the line before the compact record, prefixed BENCH_DETAIL")
     ap.add_argument("--with-features", action="store_true",
                     help="configs[4]'s 'on-device STFT feature_extractor': every timed step first extracts and normalises the features of "
                          "its clips from 60-s FOA waveforms resident in HBM (feature_extractor.py:53-88, data_loader.py:117-149,226-234)")
@@ -554,9 +630,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
         out = record(args.model, B, T, args.steps, args.warmup, world, res, args.opt, traffic_tab, valu_clock_mhz, args.with_features)
-        mu = os.path.join(ROOT, "profiles", "mfma_util.json")
-        if os.path.exists(mu):
-            out["mfma_util"] = json.load(open(mu))       # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES pass (tools/pmc_mfma.py)
+        out["conv_stack_mfma"] = conv_stack_mfma(out["roofline_by_kernel"])
         out["peaks_on_box"] = box_peaks(model.lib, local)
         if res["comm"]:
             out["comm"] = res["comm"]
@@ -588,7 +662,16 @@ def main():
                 del r
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config_of(args.model))
-        print(json.dumps(out), flush=True)
+        # DETAIL first (one long line + a file), the compact record LAST: the driver parses the last stdout line from an 8 KB tail
+        detail_path = args.detail_out
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f)
+        except OSError:
+            detail_path = None
+        print("BENCH_DETAIL " + json.dumps(out), flush=True)
+        print(compact_record(out, os.path.relpath(detail_path, ROOT) if detail_path else None), flush=True)
     if res.get("model") is not None:
         res["model"].close()       # every rank: the library's communicator goes before the host's process group does
         res["model"] = None

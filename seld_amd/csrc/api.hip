@@ -144,7 +144,7 @@ struct seld_ctx {
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *doa_v1 = nullptr;                   // models.seldnet_v1 (models.py:36-52): tanh(doa * [sed | sed | sed]), the prediction the losses see
     float *head_tmp = nullptr;                 // [rows][max ks * in_base]: a Conv1D head layer's input gradient before it is folded back over the taps
-    uint64_t dropout_seed = 0x5e1d5e1d5e1d5e1dull; unsigned dropout_step = 0; int last_training = 0;
+    uint64_t dropout_seed = 0x5e1d5e1d5e1d5e1dull; unsigned dropout_step = 0, dropout_cur = 0; int last_training = 0;   // dropout_cur: the counter the LAST training forward drew its masks with (its backward recomputes them)
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
     int fin_doa_loss = 0;
@@ -1081,6 +1081,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // Conv1D(128) in both) and neither is the head's output layer
         DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
         c->last_training = training;
+        if (training) c->dropout_cur = c->dropout_step++;      // every training forward draws new masks (Keras), backward or not
         if (heads_lin(c)) {
             DenseL &S1 = c->heads[0].layers[1], &D1 = c->heads[1].layers[1];
             const int nt = S1.out + D1.out;
@@ -1103,7 +1104,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                                        rows, D.out, D.in, 0, lastl ? Hd.act : Hd.hidden_act);
                     a = D.y;
                     if (!lastl && D.rate > 0.f && training) {
-                        launch_dropout(st, D.y, D.yd, (int64_t)rows * D.out, D.rate, c->dropout_seed, D.drop_id, c->dropout_step);
+                        launch_dropout(st, D.y, D.yd, (int64_t)rows * D.out, D.rate, c->dropout_seed, D.drop_id, c->dropout_cur);
                         a = D.yd;
                     }
                 }
@@ -1157,7 +1158,9 @@ static int run_losses(seld_ctx* c, const float* y_sed, const float* y_doa, const
         } else {
             launch_mmse_den(st, y_doa, c->den_dev, c->loss_scratch, rows, nc);
             // data parallel (seld_dp_init): the mask count of the GLOBAL batch, summed in place on this stream — no host round trip
-            if (c->dp_comm && c->dp_world > 1 && dp_allreduce(c, c->den_dev, 1, SELD_DTYPE_F32, st)) return fail(c, SELD_ERR_HIP, "RCCL all-reduce of the MMSE denominator failed");
+            // TRAINING path only (want_grads): seld_test_step is not a collective — train.teststep knows nothing about process groups, a
+            // validation loop may run on one rank or with unequal batch counts, and its loss is this rank's own num / den
+            if (want_grads && c->dp_comm && c->dp_world > 1 && dp_allreduce(c, c->den_dev, 1, SELD_DTYPE_F32, st)) return fail(c, SELD_ERR_HIP, "RCCL all-reduce of the MMSE denominator failed");
         }
     }
     float* sl = sloss ? sloss : c->loss_out;
@@ -1301,7 +1304,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         const DenseL& P = Hd.layers[j - 1];
                         const int64_t n = (int64_t)rows * P.out;
                         // the previous layer's dropout (the mask recomputed from the counters of the forward pass), then its activation
-                        if (P.rate > 0.f && c->last_training) launch_dropout(st, din, din, n, P.rate, c->dropout_seed, P.drop_id, c->dropout_step);
+                        if (P.rate > 0.f && c->last_training) launch_dropout(st, din, din, n, P.rate, c->dropout_seed, P.drop_id, c->dropout_cur);
                         if (Hd.hidden_act) launch_act_bwd(st, P.y, din, n, Hd.hidden_act);
                     }
                 }
@@ -1648,7 +1651,6 @@ static int backward_impl(seld_ctx* c, const float* x) {
     // join: the side stream's weight gradients must be complete before Adam / the DP all-reduce
     hipEventRecord(c->ev_join, c->side);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (c->last_training) ++c->dropout_step;          // the next training step draws new dropout masks
     return check_launch(c, "backward");
 }
 

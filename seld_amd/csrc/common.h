@@ -53,17 +53,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // bf16 single-product mode (SELD_DTYPE_BF16 / option "bf16_single"): the split-bf16 kernels that implement it take ONE bf16 MFMA product per
 // fp32 product, operands rounded to nearest-even bf16 (fp32 accumulation), instead of the six products of the exact 3-way split.  Set by
 // api.hip from the ctx before it enqueues a pass (process-wide: contexts of different modes must not enqueue concurrently from different
-// host threads); kernels without a single-product form keep the exact six (more accurate, never less).
+// host threads); kernels without a single-product form keep the exact six products: the weight pre-split writes ALL three planes in both
+// modes (plane 0 = the rounded value in this mode, planes 1-2 the exact split of the rest, prep.h), so they compute with exact weights.
 extern int g_mfma_one;
-// round-to-nearest-even bf16 of an fp32 value, as its 16 high bits (finite inputs)
+// round-to-nearest-even bf16 of an fp32 value, as its 16 high bits (NaN stays a quiet NaN)
 __host__ __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
     unsigned u;
     __builtin_memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN (quiet): the carry below would turn 0x7fff.... into -0
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 struct GemmSplitJobs {
     int njobs;
-    int one;       // 1: plane 0 = round-to-nearest bf16 (the other planes are not read)
+    int one;       // 1: plane 0 = round-to-nearest bf16 (planes 1, 2 = the exact split of x - plane 0, for consumers without a ONE form)
     const float* src[GSB_MAX_JOBS];
     unsigned short* dst[GSB_MAX_JOBS];
     int ldb[GSB_MAX_JOBS], transb[GSB_MAX_JOBS], K[GSB_MAX_JOBS], N[GSB_MAX_JOBS];

@@ -47,9 +47,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     if (idx >= 9 * 4096) return;
     const int tap = idx >> 12, rem = idx & 4095, out = rem >> 6, in = rem & 63;
     const float x = w[tap * 4096 + in * 64 + out];
-    if (one) { wsp[(size_t)tap * 3 * 4096 + out * 64 + in] = (unsigned short)bf16_rne_bits(x); return; }
-    const unsigned u = __float_as_uint(x);
-    const float r = x - __uint_as_float(u & 0xffff0000u);
+    const unsigned u = one ? bf16_rne_bits(x) << 16 : __float_as_uint(x) & 0xffff0000u;      // all three planes in both modes: prep.h
+    const float r = x - __uint_as_float(u);
     const unsigned v = __float_as_uint(r);
     const float s = r - __uint_as_float(v & 0xffff0000u);
     unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;

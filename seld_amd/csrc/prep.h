@@ -20,13 +20,16 @@ __device__ __forceinline__ void gemm_split_b_body(const GemmSplitJobs& jobs, int
             x = src[((size_t)(8 - tap) * N + n) * ldb + co];
         } else
             x = transb ? src[(size_t)n * ldb + k] : src[(size_t)k * ldb + n];
-        const unsigned u = __float_as_uint(x);
-        const float r = x - __uint_as_float(u & 0xffff0000u);
+        // plane 0: the truncated high part — in bf16 single-product mode the value ROUNDED to nearest bf16, which is all a ONE-form
+        // consumer reads.  Planes 1, 2 split the residual x - plane0 exactly either way (|residual| <= an ulp of plane 0: 16
+        // significant bits, 8 + 8), so a consumer WITHOUT a ONE form (six products over all three planes) computes with the exact
+        // weights in both modes — it never reads an unwritten plane.
+        const unsigned u = jobs.one ? bf16_rne_bits(x) << 16 : __float_as_uint(x) & 0xffff0000u;
+        const float r = x - __uint_as_float(u);
         const unsigned v = __float_as_uint(r);
         const float s = r - __uint_as_float(v & 0xffff0000u);
         const int c = k >> 5, kk = k & 31, piece = (kk >> 3) ^ ((n >> 2) & 3);
         unsigned short* o = dst + ((size_t)c * 3 * N + n) * 32 + piece * 8 + (kk & 7);
-        if (jobs.one) { o[0] = (unsigned short)bf16_rne_bits(x); continue; }
         o[0] = (unsigned short)(u >> 16);
         o[(size_t)N * 32] = (unsigned short)(v >> 16);
         o[(size_t)2 * N * 32] = (unsigned short)(__float_as_uint(s) >> 16);
@@ -41,12 +44,11 @@ __device__ __forceinline__ void split_weights_body(const SplitWeightJobs& jobs, 
     if (idx >= 9 * 4096) return;
     const int tap = idx >> 12, rem = idx & 4095, out = rem >> 6, in = rem & 63;
     const float x = jobs.flip[job] ? w[(8 - tap) * 4096 + out * 64 + in] : w[tap * 4096 + in * 64 + out];
-    const unsigned u = __float_as_uint(x);
-    const float r = x - __uint_as_float(u & 0xffff0000u);
+    const unsigned u = jobs.one ? bf16_rne_bits(x) << 16 : __float_as_uint(x) & 0xffff0000u;      // see gemm_split_b_body
+    const float r = x - __uint_as_float(u);
     const unsigned v = __float_as_uint(r);
     const float s = r - __uint_as_float(v & 0xffff0000u);
     unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;
-    if (jobs.one) { o[0] = (unsigned short)bf16_rne_bits(x); return; }
     o[0] = (unsigned short)(u >> 16);
     o[4096] = (unsigned short)(v >> 16);
     o[2 * 4096] = (unsigned short)(__float_as_uint(s) >> 16);

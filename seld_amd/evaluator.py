@@ -28,22 +28,30 @@ def ensemble_outputs(model: SeldNet, xs: list, win_size: int = 300, step_size: i
     if L * step_size != win_size:
         raise ValueError("win_size // step_size must equal the model's label frames per window")
     out = []
+    # work buffers live with the model (one set per (windows, batch) geometry): a file costs its kernels, not three allocations and
+    # two device-to-device copies per batch
+    cache = model.__dict__.setdefault("_infer_bufs", {})
+    _lib.check(lib.seld_set_stream(model.ctx, st()), model.ctx)
     for x in xs:
         x = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x).to(dev, torch.float32).contiguous()
         T = int(x.shape[0])
         n_win = 1 + (T - win_size) // step_size          # tf.signal.frame(pad_end=False)
         if n_win < 1 or tuple(x.shape[1:]) != (F, Cc):
             raise ValueError(f"clip shape {tuple(x.shape)} does not fit {win_size}-frame windows of [{F},{Cc}]")
-        seds = torch.empty((n_win, L, model.n_classes), dtype=torch.float32, device=dev)
-        doas = torch.empty((n_win, L, 3 * model.n_classes), dtype=torch.float32, device=dev)
-        win = torch.empty((batch_size, win_size, F, Cc), dtype=torch.float32, device=dev)
+        key = (n_win, batch_size)
+        if key not in cache:
+            cache.clear()
+            cache[key] = (torch.empty((n_win, L, model.n_classes), dtype=torch.float32, device=dev),
+                          torch.empty((n_win, L, 3 * model.n_classes), dtype=torch.float32, device=dev),
+                          torch.empty((batch_size, win_size, F, Cc), dtype=torch.float32, device=dev))
+        seds, doas, win = cache[key]
         for i in range(math.ceil(n_win / batch_size)):
             w0 = i * batch_size
             n = min(batch_size, n_win - w0)
             _lib.check(lib.seld_frame_windows(x.data_ptr(), win.data_ptr(), T, F * Cc, win_size, step_size, w0, n, st()))
-            s, d = model(win[:n], training=False)
-            seds[w0:w0 + n] = s
-            doas[w0:w0 + n] = d
+            _lib.check(lib.seld_set_batch(model.ctx, n), model.ctx)
+            # the forward writes its outputs straight into rows [w0, w0 + n) of the per-window tensors
+            _lib.check(lib.seld_forward(model.ctx, win.data_ptr(), seds[w0:].data_ptr(), doas[w0:].data_ptr(), 0), model.ctx)
         T_out = n_win - 1 + L
         sed = torch.empty((T_out, model.n_classes), dtype=torch.float32, device=dev)
         doa = torch.empty((T_out, 3 * model.n_classes), dtype=torch.float32, device=dev)

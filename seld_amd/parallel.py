@@ -41,7 +41,8 @@ def init_library_dp(model, group=None, force: bool = False) -> bool:
     communication stream), the MMSE mask count is all-reduced on the device (no `.item()`), and `enable_sync_batchnorm` routes
     through the same communicator.  Returns False (and leaves the torch.distributed path in charge) when the group's backend is not
     RCCL — the two-ranks-on-one-GPU rehearsal over gloo — or the group has one rank and `force` is not set (tests force a one-rank
-    communicator)."""
+    communicator).  Failure is COLLECTIVE: if binding RCCL or ncclCommInitRank fails on any rank, every rank raises RuntimeError
+    (and none has the library path enabled), so that a caller's fallback is taken by all ranks or none."""
     import ctypes as C
     from . import _lib
     d = torch.distributed
@@ -52,17 +53,49 @@ def init_library_dp(model, group=None, force: bool = False) -> bool:
         return False
     if world > 1 and d.get_backend(group) != "nccl":
         return False
-    ident = torch.zeros(128, dtype=torch.uint8, device=model._dev)
     rank = d.get_rank(group) if world > 1 else 0
-    if rank == 0:
-        buf = (C.c_ubyte * 128)()
+
+    def agree(ok: bool, what: str, err):
+        """Every rank learns whether EVERY rank succeeded (MIN all-reduce of a flag) before anyone acts on the outcome: a rank that
+        raised on its own while its peers sat in the next collective would leave the job in mixed library / torch.distributed code
+        paths (a hang, or a gradient all-reduce matched against a broadcast)."""
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=model._dev)
+            d.all_reduce(flag, op=d.ReduceOp.MIN, group=group)
+            all_ok = bool(int(flag.item()))
+        else:
+            all_ok = ok
+        if not all_ok:
+            raise RuntimeError(f"library-owned RCCL communicator: {what} failed on "
+                               + (f"this rank ({err})" if not ok else "another rank") + "; no rank enables the library path")
+
+    # 1. every rank binds RCCL and draws an id (rank 0's is the one that is used): the availability check happens BEFORE the broadcast
+    buf = (C.c_ubyte * 128)()
+    err = None
+    try:
         _lib.check(model.lib.seld_dp_unique_id(buf), model.ctx)
+    except Exception as e:      # noqa: BLE001 - reported collectively below
+        err = e
+    agree(err is None, "seld_dp_unique_id (binding RCCL)", err)
+    ident = torch.zeros(128, dtype=torch.uint8, device=model._dev)
+    if rank == 0:
         ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
     if world > 1:
         d.broadcast(ident, src=d.get_global_rank(group, 0) if group is not None else 0, group=group)
     host = ident.cpu().numpy().tobytes()
     torch.cuda.synchronize(model._dev)
-    _lib.check(model.lib.seld_dp_init(model.ctx, rank, world, host), model.ctx)
+    # 2. the communicator itself: again agreed on by all ranks; a rank that succeeded alone gives its communicator back
+    err = None
+    try:
+        _lib.check(model.lib.seld_dp_init(model.ctx, rank, world, host), model.ctx)
+    except Exception as e:      # noqa: BLE001
+        err = e
+    try:
+        agree(err is None, "seld_dp_init", err)
+    except RuntimeError:
+        if err is None:
+            model.lib.seld_dp_destroy(model.ctx)
+        raise
     model._lib_dp = True
     # the heads' dropout draws are a function of (seed, step, layer, element): every rank gets its own key, or all replicas would drop
     # the same elements of their different clips

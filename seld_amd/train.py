@@ -55,6 +55,11 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     world = parallel.world_size(process_group)
     is_mmse = isinstance(doa_loss, losses._MMSE)
     lib_dp = getattr(model, "_lib_dp", False)        # parallel.init_library_dp: the library owns the RCCL communicator
+    if world > 1 and not lib_dp and not getattr(model, "_dp_seeded", False):
+        # torch.distributed path: every replica needs its own dropout key too (init_library_dp sets it on the library path), or all
+        # ranks would drop the same elements of their different clips
+        model.set_option("dropout_seed", 0x5e1d + torch.distributed.get_rank(process_group))
+        model._dp_seeded = True
     dent = None
     if lib_dp:
         pass            # the mask count is all-reduced on the device inside seld_train_fwd_bwd (cfg.mmse_den = 0)

@@ -189,3 +189,32 @@ def test_seldnet_v1_json_is_the_same_network(seldnet_config):
     del v1["DOA_ARGS"]["activation"]
     a, b = models._arch_from_config(seldnet_config, 7, 64), models._arch_from_config(v1, 7, 64)
     assert bytes(C.string_at(C.addressof(a), C.sizeof(a))) == bytes(C.string_at(C.addressof(b), C.sizeof(b)))
+
+
+def test_bench_last_line_is_a_compact_record():
+    """The driver parses bench.py's LAST stdout line out of an 8 KB tail (round 3's single 28 KB line left `parsed: null`).  The
+    formatter, run on a canned FULL record of that size (round 3's own line), must give a line under 3 KB that round-trips through
+    json and keeps the contract's fields, the dominant kernel's roofline and cpu_baseline."""
+    import json
+    import bench
+    from conftest import ROOT
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_f_bench_11475clips.json")))
+    assert len(json.dumps(full)) > 20000
+    full["config"]["dp_backend"] = "none"
+    line = bench.compact_record(full, "gpurun_out/bench_detail.json")
+    assert len(line) < 3072 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == full[k], k
+    assert d["config"]["workload"] == full["config"]["workload"] and d["config"]["dp_backend"] == "none"
+    assert d["roofline"]["kernel"] == full["roofline"]["kernel"] and d["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(("bound", "achieved", "peak", "unit", "traffic")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and d["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["sample"]
+    assert d["xception_gru_clips_s"] == full["configs"]["xception_gru"]["value"]
+    assert d["resnet50_gru_clips_s"] == full["configs"]["resnet50_gru"]["value"]
+    assert d["seldnet_bf16_clips_s"] == full["configs"]["seldnet_bf16"]["value"]
+    # a pathological record (very long free-text fields) still fits: optional fields go first
+    full["config"]["workload"] = "w" * 2500
+    full["cpu_baseline"]["sample"] = "s" * 2500
+    assert len(bench.compact_record(full, "x" * 200)) < 3072

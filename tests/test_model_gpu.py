@@ -1386,3 +1386,58 @@ def test_bf16_single_product_mode_train_step(seldnet_config):
     model.set_option("bf16_single", 0)                               # the same ctx back in fp32-equivalent mode
     step()
     _per_var(model, "bf16 ctx switched back to fp32-equivalent", model.get_grads(), ref["grad"])
+
+
+@pytest.mark.parametrize("which", ["resnet50_gru", "xception_gru"])
+def test_bf16_single_product_mode_block_models(xception_config, resnet50_config, which):
+    """bf16 single-product mode on the block models: several of their consumers (the 36 / 16 / 12 / 8-column-group and im2col products of
+    gemm_sb, rn_conv3, the generic conv64 kernel) have NO single-product form and keep the six products over all three weight planes.
+    The weight pre-split therefore writes all three planes in this mode too (plane 0 = the rounded value the ONE kernels read, planes
+    1-2 = the exact split of the rest, prep.h): such a consumer computes with the EXACT weights.  Round 3 wrote plane 0 only and those
+    kernels read never-written planes.  Asserted: the step is finite, bitwise repeatable — from a FRESH ctx as well,
+    whose plane buffers hold different stale bytes — and within bf16-rounding distance of the fp64 oracle (outputs 2e-2, every
+    variable's gradient l2 norm 10 %): garbage planes fail every one of these."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(resnet50_config if which == "resnet50_gru" else xception_config)
+    if which == "resnet50_gru":
+        cfg["FIRST_ARGS"]["block_num"] = [1, 1, 1, 1]
+    else:
+        cfg["FIRST_ARGS"]["block_num"] = 2
+    B, T = 2, 300
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 7)
+    x, ys, yd = O.synthetic_batch(B, T, seed=19)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+
+    def run():
+        model = models.seldnet((B, T, 64, 7), cfg, dtype="bfloat16")
+        model.set_weights(w, st)
+        y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+        out = (y_p[0].cpu().numpy().copy(), y_p[1].cpu().numpy().copy(), model.get_grads().copy())
+        variables = list(model.variables)
+        model.close()
+        return out, variables
+
+    (sed, doa, g), variables = run()
+    assert np.isfinite(g).all()
+    check(f"bf16 {which} sed", sed, ref["sed"], tol=2e-2)
+    check(f"bf16 {which} doa", doa, ref["doa"], tol=2e-2)
+    for n, off, sh in variables:
+        k = int(np.prod(sh))
+        if n.startswith("conv") and n.endswith("bias") or "bias" in n and "conv" in n:
+            continue
+        a, r = g[off:off + k].astype(np.float64), ref["grad"][off:off + k]
+        nr = np.linalg.norm(r)
+        if nr < 1e-6 * np.linalg.norm(ref["grad"]):
+            continue        # a bias in front of training-mode BatchNorm: rounding noise on both sides
+        en = np.linalg.norm(a - r) / nr
+        print(f"[bf16 {which}] grad {n:36s} l2 error {en:.2e}")
+        assert en < 0.10, (n, en)
+    # a scratch allocation between the two contexts so that the second one's plane buffers land on different (dirty) memory
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")
+    del junk
+    (sed2, doa2, g2), _ = run()
+    np.testing.assert_array_equal(g2, g)
+    np.testing.assert_array_equal(sed2, sed)
