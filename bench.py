@@ -549,7 +549,7 @@ def conv_stack_mfma(per_kernel):
     """FLOP-weighted useful fraction of the conv stack's MFMA ceiling in THIS run (HIP-event times; the counter-based busy
     fraction is a separate rocprofv3 --pmc pass, profiles/*_mfma_util.json)."""
     rows = [r for k, r in per_kernel.items() if k.startswith("conv") and r["bound"] == "mfma"]
-    if not rows:
+    if len(rows) < 7:       # conv1 fwd + conv2/3 fwd, dgrad, wgrad: only a timing-level-2 pass has them all
         return None
     t = sum(r["ms_per_step"] for r in rows)
     fl = sum(r["achieved"] * r["ms_per_step"] for r in rows)        # TFLOP/s x ms
@@ -621,7 +621,10 @@ def main():
     torch.cuda.set_stream(run_stream)
     timing = 0 if args.no_kernel_timing else args.timing_level
     res = run_workload(args.model, B, T, args.steps, args.warmup, world, rank, local, dev, opts=args.opt, timing_level=timing,
-                       with_features=args.with_features, allreduce_ablation=True)
+                       with_features=args.with_features, allreduce_ablation=True,
+                       # N = 1: a SECOND pass of the same steps with every kernel group timed (never the pass timed for `value`): the
+                       # per-kernel rooflines of the detail record and the conv stack's MFMA figure of the compact one
+                       profile_level=2 if (world == 1 and timing == 1) else 0)
     if rank == 0:
         import ctypes as C
         model = res["model"]

@@ -71,6 +71,13 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// VAR 0: round 3's step body.  VAR 1 (round 4, profiles/r04_gru_experiments.txt): the same layout with the step body re-ordered —
+//   * odd lanes of a quad hold U's z and r columns SWAPPED, so "mine" / "other" partial sums need no per-lane select before the fold;
+//   * the whole K-quarter of h is read up front (8 ds_read_b128), then the z | r chains run FIRST and their fold + sigmoid are issued
+//     among the candidate gate's 16 packed FMAs (two sub-chains), instead of every gate finishing together behind the last FMA;
+//   * log2(e) factors folded into fma operands: sigmoid = rcp(1 + exp2(fma(s, -log2e, pre))), tanh through exp2(fma(r', gh, gx')),
+//     and the blend is ONE fma behind the last rcp: h' = fma(-2(1-z), rc, z h + (1-z)).
+template <int VAR, bool SAVE>
 __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_b,
                                                       const float* __restrict__ U_f, const float* __restrict__ U_b,
                                                       const float* __restrict__ brec_f, const float* __restrict__ brec_b,
@@ -87,19 +94,21 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float gxl[2][GRUF_CH * GRU_G];
     // padded h vector: index k lives at k + 4*(k>>5) so the 4 quarters start in different bank groups
     __shared__ __attribute__((aligned(16))) float hl[2][144];
-    f32x2 u[3][16];   // u[g][p] = (U[32q+2p][g*128+j], U[32q+2p+1][g*128+j])
+    const bool odd = q & 1;
+    f32x2 u[3][16];   // u[g][p] = (U[32q+2p][g*128+j], U[32q+2p+1][g*128+j]); VAR 1: gates 0 / 1 swapped in odd lanes (mine | other)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            u[g][p].x = U[(size_t)(32 * q + 2 * p) * GRU_G + g * GRU_U + j];
-            u[g][p].y = U[(size_t)(32 * q + 2 * p + 1) * GRU_G + g * GRU_U + j];
+            const int gs = (VAR == 1 && g < 2 && odd) ? 1 - g : g;
+            u[g][p].x = U[(size_t)(32 * q + 2 * p) * GRU_G + gs * GRU_U + j];
+            u[g][p].y = U[(size_t)(32 * q + 2 * p + 1) * GRU_G + gs * GRU_U + j];
         }
-    const bool odd = q & 1;
     const int zr_off = (odd ? GRU_U : 0) + j;
     const float bzr = brec[zr_off], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
-    float h_own = 0.f;
+    float h_own = 0.f, pre_n = 0.f, gxh2_n = 0.f;
+    const unsigned h_off = 4u * j, sv_off = 4u * (4 * j + q);
     const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
     // staged chunk: three float4 per thread held in NAMED registers (an array captured by a lambda was
     // demoted to scratch memory by the compiler, which put a vmcnt wait right behind the loads)
@@ -196,14 +205,78 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 #endif
             ++step;
         };
+        // VAR 1.  The step's two input terms are read from the staged chunk a step AHEAD (before the barrier that ends the previous
+        // step), so the reads queued behind the barrier are the eight of h alone and the first FMA waits for ONE of them.
+        auto load_gx = [&](int i) {
+            constexpr float L2E = 1.4426950408889634f;
+            const int row = dir ? n - 1 - i : i;
+            const float gxzr = gb[row * GRU_G + zr_off], gxh = gb[row * GRU_G + 2 * GRU_U + j];
+            pre_n = (gxzr + bzr) * -L2E;
+            gxh2_n = gxh * (2.f * L2E);
+        };
+        auto do_step1 = [&](int i, bool prefetch) {
+            constexpr float L2E = 1.4426950408889634f;
+            const int row = dir ? n - 1 - i : i;
+            const int t = tlo + row;
+            const float* hp = &hl[step & 1][36 * q];
+            const float pre = pre_n, gxh2 = gxh2_n;
+            float4 hv[8];
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) hv[k4] = *reinterpret_cast<const float4*>(hp + 4 * k4);
+            f32x2 am2 = {0.f, 0.f}, ao2 = {0.f, 0.f};   // mine (z in even lanes, r in odd lanes) | other
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const f32x2 h01 = {hv[k4].x, hv[k4].y}, h23 = {hv[k4].z, hv[k4].w};
+                am2 = pk_fma(h01, u[0][2 * k4], am2); ao2 = pk_fma(h01, u[1][2 * k4], ao2);
+                am2 = pk_fma(h23, u[0][2 * k4 + 1], am2); ao2 = pk_fma(h23, u[1][2 * k4 + 1], ao2);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // nothing of the candidate gate's chain moves up among the z | r chains
+            // fold: a lane adds its xor-1 neighbour's OTHER sum (that neighbour's other gate is this lane's own), then the xor-2 half
+            float zr = (am2.x + am2.y) +
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ao2.x + ao2.y), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+            zr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zr), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+            const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zr, -L2E, pre)));
+            const float z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xA0 /*quad_perm [0,0,2,2]*/, 0xF, 0xF, true));
+            const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, true));
+            const float r2 = r * (2.f * L2E), omz = 1.f - z;
+            const float ba = fmaf(z, h_own, omz), bb = -2.f * omz;
+            f32x2 aha = {0.f, 0.f}, ahb = {0.f, 0.f};
+#pragma unroll
+            for (int k4 = 0; k4 < 8; k4 += 2) {
+                const f32x2 h01 = {hv[k4].x, hv[k4].y}, h23 = {hv[k4].z, hv[k4].w};
+                const f32x2 g01 = {hv[k4 + 1].x, hv[k4 + 1].y}, g23 = {hv[k4 + 1].z, hv[k4 + 1].w};
+                aha = pk_fma(h01, u[2][2 * k4], aha); ahb = pk_fma(g01, u[2][2 * k4 + 2], ahb);
+                aha = pk_fma(h23, u[2][2 * k4 + 1], aha); ahb = pk_fma(g23, u[2][2 * k4 + 3], ahb);
+            }
+            const f32x2 ah2 = aha + ahb;
+            const float ghh = quad_sum(ah2.x + ah2.y) + bh;
+            const float rc = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(r2, ghh, gxh2)));
+            const float hn = fmaf(bb, rc, ba);      // z h + (1 - z) (1 - 2 rc)
+            h_own = hn;
+            // all four lanes of a quad hold the same hn and store it to the same word (LDS: a same-address 4-way write costs at most 4
+            // array cycles; memory: one dword per quad either way): no exec-mask region, the step body stays ONE basic block
+            hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
+            __builtin_amdgcn_sched_barrier(0);      // the exchange write leaves first; output stores and the next step's input terms follow
+            // uniform row base + 32-bit lane offset: the stores take the SGPR-base form, no 64-bit vector address arithmetic per step
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(H) + ((unsigned)t * (GRU_U * 4u) + h_off)) = hn;
+            if (prefetch) load_gx(i + 1);
+            if constexpr (SAVE) {
+                const float hh = fmaf(rc, -2.f, 1.f);
+                const float hi2 = q == 2 ? hh : ghh;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(sv) + ((unsigned)t * (GRU_U * 16u) + sv_off)) = q < 2 ? sg : hi2;      // saved gates: [t][unit][z r hh gh]
+            }
+            ++step;
+        };
+#define GRUF_STEP(i_, pf_) { if constexpr (VAR == 1) do_step1(i_, pf_); else do_step(i_); }
+        if constexpr (VAR == 1) load_gx(0);
         for (int i = 0; i < n - 1; ++i) {
-            do_step(i);
+            GRUF_STEP(i, true)
             lds_barrier();   // LDS-only: __syncthreads() would also drain vmcnt, i.e. wait for this step's global stores
 #ifdef GRU_TIMING
             { unsigned long long tb; GRU_STAMP(tb) tm_bar += tb - tm_last; }
 #endif
         }
-        do_step(n - 1);
+        GRUF_STEP(n - 1, false)
         GRUF_COMMIT((c + 1) & 1)  // the only wait on the staged loads: one chunk after their issue
         lds_barrier();
 #ifdef GRU_TIMING
@@ -219,11 +292,15 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 }
 
 
+int g_gru_var = 0;      // kernel choice (process-wide, option "gru_var"): bit 0 = forward step body VAR 1, bit 1 = backward
+
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
                    int B, int S) {
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b,
-                       sv_f, sv_b, S);
+#define GRUF_GO(V_, SV_) hipLaunchKernelGGL((gru_fwd_kernel<V_, SV_>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S)
+    const bool save = sv_f != nullptr;
+    if (g_gru_var & 1) { if (save) GRUF_GO(1, true); else GRUF_GO(1, false); }
+    else { if (save) GRUF_GO(0, true); else GRUF_GO(0, false); }
     return 0;
 }
 
@@ -248,6 +325,11 @@ __device__ __forceinline__ float row16_allsum(float v) {
 
 #define GRUB_GL 448   // padded gate-gradient vector: column c lives at 28*(c/24) + c%24 (16 parts, conflict-free b128 reads)
 
+// VAR 1 (round 4): (a) lane cp keeps U^T's four rows in the order a ^ (cp & 3), so that accumulator 0 is always the output the lane ends
+// up owning and the fold over the quad is three DPP adds with NO per-lane selects (VAR 0: six v_cndmask on the carry's critical path);
+// (b) the idle quarter of the lanes (role 3) repeats role 0's gate gradient — same value, same address — so the gate stage has no exec-mask
+// region and the step is one basic block; (c) the exchange write is pinned ahead of the output stores.
+template <int VAR>
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ h_f,
                                                       const float* __restrict__ h_b, const float* __restrict__ sv_f,
                                                       const float* __restrict__ sv_b, const float* __restrict__ U_f,
@@ -275,8 +357,9 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int p = 0; p < 12; ++p) {
-            ut[a][p].x = U[(size_t)(j0 + a) * GRU_G + 24 * cp + 2 * p];
-            ut[a][p].y = U[(size_t)(j0 + a) * GRU_G + 24 * cp + 2 * p + 1];
+            const int ar = VAR == 1 ? a ^ (cp & 3) : a;
+            ut[a][p].x = U[(size_t)(j0 + ar) * GRU_G + 24 * cp + 2 * p];
+            ut[a][p].y = U[(size_t)(j0 + ar) * GRU_G + 24 * cp + 2 * p + 1];
         }
     // the forward pass consumed t = 0..S-1 (dir 0) / S-1..0 (dir 1); BPTT walks that order backwards:
     // BPTT step s is time t = S-1-s (dir 0) or s (dir 1); h_prev(t) = H[t-1] (dir 0) / H[t+1] (dir 1)
@@ -339,7 +422,9 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     // while the current step's mat-vec runs; the chain behind the carry is then one add and two multiplies.
     const int cidx = (qr < 3 ? qr : 0) * GRU_U + jm;
     const int gl_slot = 28 * (cidx / 24) + cidx % 24;
+    const unsigned c_off = 4u * cidx;
     float k_do = 0.f, k_x = 0.f, k_h = 0.f, k_z = 0.f, c_zs = 0.f;
+    const float m_z = (qr == 0 || qr == 3) ? 1.f : 0.f, m_r = qr == 1 ? 1.f : 0.f, m_h = qr == 2 ? 1.f : 0.f;
     auto pre = [&](const float* sbuf, int row) {
         const float* rp = sbuf + row * GRUB_ROW + jm;
         k_do = rp[0] * rp[128];
@@ -348,8 +433,16 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         const float kh = (1.f - c_z) * (1.f - c_hh * c_hh);
         const float kz = (hp - c_hh) * c_z * (1.f - c_z);
         const float kr = kh * c_gh * c_r * (1.f - c_r);
-        k_x = qr == 0 ? kz : (qr == 1 ? kr : kh);
-        k_h = qr == 0 ? kz : (qr == 1 ? kr : kh * c_r);
+        if constexpr (VAR == 1) {
+            // role by 0 / 1 lane masks (role 3 repeats role 0): plain multiply-adds — the compiler turned the nested selects into exec-mask
+            // branches inside the step
+            const float base = fmaf(m_z, kz, m_r * kr);
+            k_x = fmaf(m_h, kh, base);
+            k_h = fmaf(m_h, kh * c_r, base);
+        } else {
+            k_x = qr == 0 ? kz : (qr == 1 ? kr : kh);
+            k_h = qr == 0 ? kz : (qr == 1 ? kr : kh * c_r);
+        }
         k_z = c_z;
     };
     {
@@ -370,7 +463,15 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             dh = k_do + carry;
             c_zs = k_z;
             gw = gl + (step & 1) * GRUB_GL;
-            if (qr < 3) {
+            if constexpr (VAR == 1) {
+                const float vx = dh * k_x, vh = dh * k_h;
+                gw[gl_slot] = vh;
+                __builtin_amdgcn_sched_barrier(0);
+                // uniform base + 32-bit byte offset (S x 1536 B < 4 GB): SGPR-base stores, one v_add per step for both
+                const unsigned off = (unsigned)t * (GRU_G * 4u) + c_off;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dgx) + off) = vx;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dgh) + off) = vh;
+            } else if (qr < 3) {
                 const float vx = dh * k_x, vh = dh * k_h;
                 gw[gl_slot] = vh;
                 dgx[(size_t)t * GRU_G + cidx] = vx;
@@ -395,6 +496,17 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             // remaining foreign one (1 add), then the quads of the row are summed (2 adds): 5 cross-lane adds + 6 selects
             // where four 16-lane all-reduces took 16 + the final select chain.
             const float s0 = s2[0].x + s2[0].y, s1 = s2[1].x + s2[1].y, s2_ = s2[2].x + s2[2].y, s3 = s2[3].x + s2[3].y;
+            if constexpr (VAR == 1) {
+                // accumulator a holds output (cp & 3) ^ a: the xor-1 neighbour owns what this lane holds in slots 1 and 3, the xor-2 one slot 2
+                const float a0 = s0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+                const float a2 = s2_ + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s3), 0xB1, 0xF, 0xF, true));
+                float mine = a0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a2), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+                mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
+                mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
+                carry = dh * c_zs + mine;
+                ++step;
+                return;
+            }
             const float k1 = b0 ? s1 : s0, g1 = b0 ? s0 : s1, k2 = b0 ? s3 : s2_, g2 = b0 ? s2_ : s3;
             const float a01 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g1), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
             const float a23 = k2 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g2), 0xB1, 0xF, 0xF, true));
@@ -451,7 +563,7 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S) {
     const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * GRUB_GL) * sizeof(float);
-    auto kern = gru_bwd_kernel;
+    auto kern = (g_gru_var & 2) ? gru_bwd_kernel<1> : gru_bwd_kernel<0>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);

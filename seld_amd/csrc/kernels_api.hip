@@ -36,6 +36,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!key) return SELD_ERR_INVALID;
     if (!strcmp(key, "conv64_split_bf16")) { g_conv64_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_split_bf16")) { g_conv1_split_bf16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gru_var")) { g_gru_var = value; return SELD_OK; }
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "bf16_single")) { g_mfma_one = value != 0; return SELD_OK; }

@@ -48,5 +48,26 @@ def bwd():
     assert rc == 0, rc
 
 
+import numpy as np  # noqa: E402
+
+# step-body variants (option "gru_var": bit 0 forward, bit 1 backward; gru.hip): outputs against variant 0's, then same-box timings
+lib.seld_k_set_option(b"gru_var", 0)
+fwd(1)
+bwd()
+torch.cuda.synchronize()
+ref = [t.clone() for t in (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1])]
+lib.seld_k_set_option(b"gru_var", 3)
+for t in (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]):
+    t.zero_()
+fwd(1)
+bwd()
+torch.cuda.synchronize()
+for name, a, b in zip(("h_f", "h_b", "sv_f", "sv_b", "dgx_f", "dgx_b", "dgh_f", "dgh_b"), (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]), ref):
+    e = float((a - b).abs().max() / b.abs().max())
+    print(f"gru_var=3 vs 0: {name:6s} max rel diff {e:.2e}")
+    assert e < 2e-5, (name, e)
 for rep in range(3):
-    print(f"gru_fwd {timed(lambda: fwd(1)):.4f} ms (saving gates), {timed(lambda: fwd(0)):.4f} ms (inference), gru_bwd {timed(bwd):.4f} ms   [B={B}, S={S}]")
+    for var in (0, 3):
+        lib.seld_k_set_option(b"gru_var", var)
+        print(f"gru_var={var}: gru_fwd {timed(lambda: fwd(1)):.4f} ms (saving gates), {timed(lambda: fwd(0)):.4f} ms (inference), gru_bwd {timed(bwd):.4f} ms   [B={B}, S={S}]")
+lib.seld_k_set_option(b"gru_var", 0)
