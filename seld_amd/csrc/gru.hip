@@ -55,6 +55,30 @@ __device__ unsigned long long g_gru_trace[2][8][8][4];    // [fwd | bwd][wave][s
 #define GRU_TR(w_, k_)
 #endif
 
+// -DGRU_TRACE2 (diagnostic build, tools/trace_gru2.py): near-free stamps of the VAR 1 kernels — s_memtime into SGPR pairs with NO wait
+// of their own (the barrier's lgkmcnt(0) collects them; an outstanding s_memtime only makes the compiler's counted LDS waits one more
+// conservative), stored after the barrier for every wave of workgroup 0 over steps 100..107.
+#ifdef GRU_TRACE2
+__device__ unsigned long long g_gru_trace2[2][8][8][6];    // [fwd | bwd][wave][step - 100][stamp]
+#define TR2(k_) asm volatile("s_memtime %0" : "=s"(tr2[k_]));
+#define TR2_DECL unsigned long long tr2[6] = {0, 0, 0, 0, 0, 0};
+// an s_memtime result arrives LATE: its SGPR pair must stay allocated until a wait has collected it, or the returning value lands in
+// whatever the allocator put there next (an address: a memory fault).  Wherever stamps are not followed by a barrier + TR2_STORE:
+#define TR2_DRAIN asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(tr2[0]), "s"(tr2[1]), "s"(tr2[2]), "s"(tr2[3]), "s"(tr2[4]), "s"(tr2[5]) : "memory");
+// after a barrier (lgkmcnt(0) has collected every stamp): stamps [k0_, k1_) of step ts_
+#define TR2_STORE(w_, ts_, k0_, k1_)                                                                                    \
+    {                                                                                                                   \
+        TR2_DRAIN                                                                                                       \
+        if (blockIdx.x == 0 && (ts_) >= 100 && (ts_) < 108 && (threadIdx.x & 63) == 0)                                  \
+            for (int k_ = k0_; k_ < k1_; ++k_) g_gru_trace2[w_][threadIdx.x >> 6][(ts_) - 100][k_] = tr2[k_];           \
+    }
+#else
+#define TR2(k_)
+#define TR2_DRAIN
+#define TR2_DECL
+#define TR2_STORE(w_, ts_, k0_, k1_)
+#endif
+
 #define GRU_U 128
 #define GRU_G 384
 #define GRUF_CH 16   // forward: steps per staged chunk
@@ -77,7 +101,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 //     among the candidate gate's 16 packed FMAs (two sub-chains), instead of every gate finishing together behind the last FMA;
 //   * log2(e) factors folded into fma operands: sigmoid = rcp(1 + exp2(fma(s, -log2e, pre))), tanh through exp2(fma(r', gh, gx')),
 //     and the blend is ONE fma behind the last rcp: h' = fma(-2(1-z), rc, z h + (1-z)).
-template <int VAR, bool SAVE>
+template <int VAR, bool SAVE, bool PRIO = false>
 __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_b,
                                                       const float* __restrict__ U_f, const float* __restrict__ U_b,
                                                       const float* __restrict__ brec_f, const float* __restrict__ brec_b,
@@ -108,6 +132,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const float bzr = brec[zr_off], bh = brec[2 * GRU_U + j];
     if (tid < 144) { hl[0][tid] = 0.f; hl[1][tid] = 0.f; }
     float h_own = 0.f, pre_n = 0.f, gxh2_n = 0.f;
+    TR2_DECL
     const unsigned h_off = 4u * j, sv_off = 4u * (4 * j + q);
     const int nchunks = (S + GRUF_CH - 1) / GRUF_CH;
     // staged chunk: three float4 per thread held in NAMED registers (an array captured by a lambda was
@@ -220,17 +245,25 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const int t = tlo + row;
             const float* hp = &hl[step & 1][36 * q];
             const float pre = pre_n, gxh2 = gxh2_n;
+            TR2(0)
             float4 hv[8];
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) hv[k4] = *reinterpret_cast<const float4*>(hp + 4 * k4);
             f32x2 am2 = {0.f, 0.f}, ao2 = {0.f, 0.f};   // mine (z in even lanes, r in odd lanes) | other
+            // PRIO: a wave's issue priority FALLS as it advances through its 48 FMAs (3, 2, 1, 0 per dozen), so of the two waves of a
+            // SIMD the one that is behind wins the arbitration: round-robin at a dozen-FMA grain instead of oldest-first (under which
+            // the older wave runs ahead and the younger one finishes its FMAs and its whole dependent tail alone on the SIMD)
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) {
                 const f32x2 h01 = {hv[k4].x, hv[k4].y}, h23 = {hv[k4].z, hv[k4].w};
                 am2 = pk_fma(h01, u[0][2 * k4], am2); ao2 = pk_fma(h01, u[1][2 * k4], ao2);
                 am2 = pk_fma(h23, u[0][2 * k4 + 1], am2); ao2 = pk_fma(h23, u[1][2 * k4 + 1], ao2);
+                if constexpr (PRIO) { if (k4 == 2) __builtin_amdgcn_s_setprio(2); if (k4 == 5) __builtin_amdgcn_s_setprio(1); }
             }
             __builtin_amdgcn_sched_barrier(0);      // nothing of the candidate gate's chain moves up among the z | r chains
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            TR2(1)
             // fold: a lane adds its xor-1 neighbour's OTHER sum (that neighbour's other gate is this lane's own), then the xor-2 half
             float zr = (am2.x + am2.y) +
                        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ao2.x + ao2.y), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
@@ -248,11 +281,19 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 aha = pk_fma(h01, u[2][2 * k4], aha); ahb = pk_fma(g01, u[2][2 * k4 + 2], ahb);
                 aha = pk_fma(h23, u[2][2 * k4 + 1], aha); ahb = pk_fma(g23, u[2][2 * k4 + 3], ahb);
             }
+#ifdef GRU_TRACE2
+            __builtin_amdgcn_sched_barrier(0);
+            TR2(2)
+#endif
             const f32x2 ah2 = aha + ahb;
             const float ghh = quad_sum(ah2.x + ah2.y) + bh;
             const float rc = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(r2, ghh, gxh2)));
             const float hn = fmaf(bb, rc, ba);      // z h + (1 - z) (1 - 2 rc)
             h_own = hn;
+#ifdef GRU_TRACE2
+            __builtin_amdgcn_sched_barrier(0);
+            TR2(3)
+#endif
             // all four lanes of a quad hold the same hn and store it to the same word (LDS: a same-address 4-way write costs at most 4
             // array cycles; memory: one dword per quad either way): no exec-mask region, the step body stays ONE basic block
             hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
@@ -265,6 +306,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 const float hi2 = q == 2 ? hh : ghh;
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(sv) + ((unsigned)t * (GRU_U * 16u) + sv_off)) = q < 2 ? sg : hi2;      // saved gates: [t][unit][z r hh gh]
             }
+            TR2(4)
             ++step;
         };
 #define GRUF_STEP(i_, pf_) { if constexpr (VAR == 1) do_step1(i_, pf_); else do_step(i_); }
@@ -272,11 +314,13 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         for (int i = 0; i < n - 1; ++i) {
             GRUF_STEP(i, true)
             lds_barrier();   // LDS-only: __syncthreads() would also drain vmcnt, i.e. wait for this step's global stores
+            TR2_STORE(0, step - 1, 0, 5)
 #ifdef GRU_TIMING
             { unsigned long long tb; GRU_STAMP(tb) tm_bar += tb - tm_last; }
 #endif
         }
         GRUF_STEP(n - 1, false)
+        TR2_DRAIN
         GRUF_COMMIT((c + 1) & 1)  // the only wait on the staged loads: one chunk after their issue
         lds_barrier();
 #ifdef GRU_TIMING
@@ -292,13 +336,20 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 }
 
 
-int g_gru_var = 0;      // kernel choice (process-wide, option "gru_var"): bit 0 = forward step body VAR 1, bit 1 = backward
+
+int g_gru_var = 11;     // kernel choice (process-wide, option "gru_var"): bit 0 = forward step body VAR 1, bit 1 = backward VAR 1, bit 3 = falling
+                        // issue priority through the FMAs (with bits 0 / 1); 0 = round 3's kernels (same-box A/B: tools/tune_gru.py)
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
                    int B, int S) {
 #define GRUF_GO(V_, SV_) hipLaunchKernelGGL((gru_fwd_kernel<V_, SV_>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S)
     const bool save = sv_f != nullptr;
+    if ((g_gru_var & 9) == 9) {
+        if (save) hipLaunchKernelGGL((gru_fwd_kernel<1, true, true>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S);
+        else hipLaunchKernelGGL((gru_fwd_kernel<1, false, true>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S);
+        return 0;
+    }
     if (g_gru_var & 1) { if (save) GRUF_GO(1, true); else GRUF_GO(1, false); }
     else { if (save) GRUF_GO(0, true); else GRUF_GO(0, false); }
     return 0;
@@ -329,7 +380,7 @@ __device__ __forceinline__ float row16_allsum(float v) {
 // up owning and the fold over the quad is three DPP adds with NO per-lane selects (VAR 0: six v_cndmask on the carry's critical path);
 // (b) the idle quarter of the lanes (role 3) repeats role 0's gate gradient — same value, same address — so the gate stage has no exec-mask
 // region and the step is one basic block; (c) the exchange write is pinned ahead of the output stores.
-template <int VAR>
+template <int VAR, bool PRIO = false>
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ h_f,
                                                       const float* __restrict__ h_b, const float* __restrict__ sv_f,
                                                       const float* __restrict__ sv_b, const float* __restrict__ U_f,
@@ -412,6 +463,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     commit(0);
     __syncthreads();
     float carry = 0.f;    // carry of unit jm
+    TR2_DECL
 #ifdef GRU_TIMING
     unsigned long long tm_p1 = 0, tm_bar = 0, tm_p2 = 0;
 #endif
@@ -483,6 +535,13 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             f32x2 s2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int c4 = 0; c4 < 6; ++c4) {
+                // PRIO: falling issue priority through the 48 FMAs (see gru_fwd_kernel)
+                // (tied to the four accumulator chains: a bare s_setprio is not held in place among the FMAs)
+                if constexpr (PRIO) {
+                    if (c4 == 0) __builtin_amdgcn_s_setprio(3);
+                    if (c4 == 2) asm volatile("s_setprio 2" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]));
+                    if (c4 == 4) asm volatile("s_setprio 1" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]));
+                }
                 const float4 gv = *reinterpret_cast<const float4*>(gp + 4 * c4);
                 const f32x2 g01 = {gv.x, gv.y}, g23 = {gv.z, gv.w};
 #pragma unroll
@@ -495,6 +554,11 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             // its xor-1 neighbour a lane trades the two outputs of the other parity (2 adds), with its xor-2 neighbour the
             // remaining foreign one (1 add), then the quads of the row are summed (2 adds): 5 cross-lane adds + 6 selects
             // where four 16-lane all-reduces took 16 + the final select chain.
+            if constexpr (PRIO) asm volatile("s_setprio 0" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]));
+#ifdef GRU_TRACE2
+            __builtin_amdgcn_sched_barrier(0);
+            TR2(3)
+#endif
             const float s0 = s2[0].x + s2[0].y, s1 = s2[1].x + s2[1].y, s2_ = s2[2].x + s2[2].y, s3 = s2[3].x + s2[3].y;
             if constexpr (VAR == 1) {
                 // accumulator a holds output (cp & 3) ^ a: the xor-1 neighbour owns what this lane holds in slots 1 and 3, the xor-2 one slot 2
@@ -504,6 +568,10 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
                 mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
                 carry = dh * c_zs + mine;
+#ifdef GRU_TRACE2
+                __builtin_amdgcn_sched_barrier(0);
+                TR2(4)
+#endif
                 ++step;
                 return;
             }
@@ -523,12 +591,17 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             GRU_STAMP(tb0)
 #endif
             GRU_TR(1, 0)
+            TR2(0)
             part1(i);
+            TR2(1)
             GRU_TR(1, 1)
 #ifdef GRU_TIMING
             GRU_STAMP(tb1)
 #endif
             lds_barrier();   // LDS-only barrier: never wait for the dgx/dgh stores
+            TR2_STORE(1, step, 0, 2)
+            TR2_STORE(1, step - 1, 2, 5)
+            TR2(2)
 #ifdef GRU_TIMING
             GRU_STAMP(tb2)
 #endif
@@ -541,6 +614,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
 #endif
         }
         part1(n - 1);
+        TR2_DRAIN
         commit((c + 1) & 1);  // the only wait on the staged loads
         lds_barrier();
         {
@@ -550,6 +624,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             pre(stage + ((c + 1) & 1) * GRUB_CH * GRUB_ROW, dir ? 0 : n2 - 1);
         }
         part2();
+        TR2_DRAIN
     }
 #ifdef GRU_TIMING
     if (tid == 0 && blockIdx.x < 512) {
@@ -563,7 +638,7 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S) {
     const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * GRUB_GL) * sizeof(float);
-    auto kern = (g_gru_var & 2) ? gru_bwd_kernel<1> : gru_bwd_kernel<0>;
+    auto kern = (g_gru_var & 2) ? ((g_gru_var & 8) ? gru_bwd_kernel<1, true> : gru_bwd_kernel<1, false>) : gru_bwd_kernel<0, false>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
                        dgh_f, dgh_b, S);
@@ -572,6 +647,13 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
 
 // per-phase cycle sums of the last gru_fwd (which = 0) / gru_bwd (1) launch: out[blocks][4]; -2 unless built with -DGRU_TIMING
 int gru_timing_read(int which, unsigned long long* out, int blocks) {
+#ifdef GRU_TRACE2
+    if ((which == 4 || which == 5) && blocks == 64) {    // trace2 of workgroup 0: [wave][step][stamp 0..5]
+        hipDeviceSynchronize();
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gru_trace2), 8 * 8 * 6 * sizeof(unsigned long long),
+                                   (size_t)(which - 4) * 8 * 8 * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    }
+#endif
 #ifdef GRU_TRACE
     if ((which == 2 || which == 3) && blocks == 64) {    // trace of workgroup 0: [wave][step][stamp]
         hipDeviceSynchronize();

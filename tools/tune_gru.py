@@ -50,24 +50,49 @@ def bwd():
 
 import numpy as np  # noqa: E402
 
-# step-body variants (option "gru_var": bit 0 forward, bit 1 backward; gru.hip): outputs against variant 0's, then same-box timings
-lib.seld_k_set_option(b"gru_var", 0)
+# step-body variants (option "gru_var": bit 0 forward VAR 1, bit 1 backward VAR 1, bit 3 falling priority; 0 = round 3; gru.hip): outputs against variant 0's, then same-box timings
+lib.seld_k_set_option(b"gru_var", 11)
 fwd(1)
 bwd()
 torch.cuda.synchronize()
 ref = [t.clone() for t in (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1])]
-lib.seld_k_set_option(b"gru_var", 3)
-for t in (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]):
-    t.zero_()
-fwd(1)
-bwd()
-torch.cuda.synchronize()
-for name, a, b in zip(("h_f", "h_b", "sv_f", "sv_b", "dgx_f", "dgx_b", "dgh_f", "dgh_b"), (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]), ref):
-    e = float((a - b).abs().max() / b.abs().max())
-    print(f"gru_var=3 vs 0: {name:6s} max rel diff {e:.2e}")
-    assert e < 2e-5, (name, e)
+names = ("h_f", "h_b", "sv_f", "sv_b", "dgx_f", "dgx_b", "dgh_f", "dgh_b")
+variants = [int(v) for v in sys.argv[1:]] or [3, 11]
+for var in variants:
+    lib.seld_k_set_option(b"gru_var", var)
+    for t in (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]):
+        t.zero_()
+    fwd(1)
+    bwd()
+    torch.cuda.synchronize()
+    for name, a, b in zip(names, (h[0], h[1], sv[0], sv[1], dgx[0], dgx[1], dgh[0], dgh[1]), ref):
+        e = float((a - b).abs().max() / b.abs().max())
+        print(f"gru_var={var} vs 0: {name:6s} max rel diff {e:.2e}")
+        assert e < 2e-5, (name, e)
+    # inference form (no saved gates) must give the same h
+    hk = h[0].clone()
+    h[0].zero_()
+    fwd(0)
+    torch.cuda.synchronize()
+    assert torch.equal(hk, h[0]), "h differs between the saving and the inference form"
 for rep in range(3):
-    for var in (0, 3):
+    for var in [0] + variants:
         lib.seld_k_set_option(b"gru_var", var)
         print(f"gru_var={var}: gru_fwd {timed(lambda: fwd(1)):.4f} ms (saving gates), {timed(lambda: fwd(0)):.4f} ms (inference), gru_bwd {timed(bwd):.4f} ms   [B={B}, S={S}]")
-lib.seld_k_set_option(b"gru_var", 0)
+# odd sequence lengths / short chunks through the same kernels
+for S2 in (1, 7, 17, 33):
+    for var in [0] + variants:
+        lib.seld_k_set_option(b"gru_var", var)
+        hh = [torch.zeros(B, S2, 128, device="cuda") for _ in range(2)]
+        ss = [torch.zeros(B, S2, 4, 128, device="cuda") for _ in range(2)]
+        gg = [gx[k][:, :S2].contiguous() for k in range(2)]
+        assert lib.seld_k_gru_fwd(P(gg[0]), P(gg[1]), P(U[0]), P(U[1]), P(br[0]), P(br[1]), P(hh[0]), P(hh[1]), P(ss[0]), P(ss[1]), None, B, S2, 128) == 0
+        torch.cuda.synchronize()
+        if var == 0:
+            r2 = [t.clone() for t in hh + ss]
+        else:
+            for a, b in zip(hh + ss, r2):
+                e = float((a - b).abs().max() / b.abs().max())
+                assert e < 2e-5, (S2, var, e)
+print("short sequences ok")
+lib.seld_k_set_option(b"gru_var", 11)
