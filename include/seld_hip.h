@@ -381,6 +381,19 @@ int seld_debug_pool_routing(seld_ctx* ctx, int block, unsigned char* pos, unsign
  * device buffer `dst` (capacity floats); *count = its size, [B, T/5, W_block, w or 4w].  output > 0 is the gate the backward pass
  * used.  Synchronises the ctx stream. */
 int seld_debug_relu_output(seld_ctx* ctx, int block, int which, float* dst, int64_t capacity, int64_t* count);
+/* Test aids, the inverse of the two above (tests/test_model_gpu.py::test_full_size_parity_given_fp64_decisions): make every LATER backward
+ * pass of this ctx take GIVEN decisions at a list of elements — host arrays of n flat indices into the decision tensor ([B, H/pt, W/pf,
+ * 64] of conv block `block`; the ReLU output of seld_debug_relu_output(block, which)) and n values (routing: 0 = the window passes 0,
+ * 1 + pos = it passes the element at window position pos; gate: 0 | 1).  n = 0 clears the list of that tensor.  MaxPoolGrad / ReluGrad of
+ * the reference (layers.py:33-37) take these decisions from their own values; among the ~10^7..10^8 decisions of a full-size step a few
+ * dozen (conv blocks) to a few thousand (the 16-bottleneck resnet) sit within fp32 rounding of a tie and decide differently in ANY two
+ * evaluations.  With the fp64 oracle's decisions injected at exactly those elements (the fixtures carry them:
+ * tests/golden/make_golden_*.py), the step's gradients are comparable with the free-running fp64 oracle's at the parity bar itself.
+ * Implementation: the stored tensors the backward kernels read a decision from are edited by the smallest amount that makes them
+ * decide as told (an ulp walk on one pre-BN value, the recorded argmax byte, a 1e-35 in place of a 0), after the forward pass has
+ * finished with them.  Not for production use; calls synchronise the ctx stream. */
+int seld_debug_set_routing(seld_ctx* ctx, int block, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
+int seld_debug_set_relu_gates(seld_ctx* ctx, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
 /* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */

@@ -142,6 +142,8 @@ SIGNATURES = {
     "seld_k_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L]),
     "seld_debug_pool_routing": (_I, [_P, _I, _P, _P]),
     "seld_debug_relu_output": (_I, [_P, _I, _I, _P, _L, C.POINTER(C.c_int64)]),
+    "seld_debug_set_routing": (_I, [_P, _I, _L, _P, _P]),
+    "seld_debug_set_relu_gates": (_I, [_P, _I, _I, _L, _P, _P]),
     "seld_k_gru_timing": (_I, [_I, _P, _I]),
     "seld_k_rn_conv": (_I, [_P, _P, _P] + [_I] * 7),
     "seld_k_rn_conv_bwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 7),

@@ -84,6 +84,9 @@ struct seld_ctx {
     int64_t adam_step = 0;
     std::vector<ConvL> conv;
     std::vector<GruL> gru;
+    // test aid (seld_debug_set_routing / seld_debug_set_relu_gates): decisions the NEXT backward passes are told to take
+    struct Override { int kind, block, which; int64_t n; int64_t* idx; unsigned char* val; };
+    std::vector<Override> overrides;
     Head heads[2];
     // xception_block (arch.first_kind == SELD_FIRST_XCEPTION): conv[0] is the entry block, then 3 * xc_blocks units on [B,S,16,64]
     std::vector<XcUnit> xc;
@@ -1273,6 +1276,18 @@ static void heads_lin_side(seld_ctx* c, int rows) {
 static int backward_impl(seld_ctx* c, const float* x) {
     g_mfma_one = c->bf16_single;
     hipStream_t st = c->stream;
+    // test aid: injected routing decisions edit the tensors the backward kernels read their decisions from (the forward is done with them)
+    for (const auto& o : c->overrides) {
+        if (o.kind == 0) {
+            ConvL& L = c->conv[o.block];
+            const bool recorded = o.block == 0 && L.amax && (c->gram_active || (L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1)));
+            if (!recorded && !L.z) return fail(c, SELD_ERR_UNSUPPORTED, "seld_debug_set_routing: this block keeps neither recorded positions nor its pre-BN tensor");
+            launch_pool_routing_patch(st, L.z, L.p, recorded ? L.amax : nullptr, L.scale, L.shift, o.idx, o.val, o.n, L.H, L.W, L.pt, L.pf);
+        } else {
+            RnBlock& R = c->rn[o.block];
+            launch_relu_gate_patch(st, o.which == 0 ? R.y0 : (o.which == 1 ? R.y1 : R.out), o.which == 2 ? R.gate : nullptr, o.idx, o.val, o.n);
+        }
+    }
     const int B = c->B, S = c->S, rows = B * S;
     GruL& Glast = c->gru.back();
     // ---- heads: the input-gradient chain runs on the main stream; the weight/bias gradients only
@@ -1819,6 +1834,41 @@ int seld_debug_pool_routing(seld_ctx* c, int block, unsigned char* pos, unsigned
         return fail(c, SELD_ERR_UNSUPPORTED, "pool_routing");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "pool_routing");
+}
+
+static int set_override(seld_ctx* c, int kind, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host, int64_t limit) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->overrides.size();)      // replace an earlier list for the same decision tensor (its buffers stay with the ctx)
+        if (c->overrides[i].kind == kind && c->overrides[i].block == block && c->overrides[i].which == which) c->overrides.erase(c->overrides.begin() + i);
+        else ++i;
+    if (n <= 0) return SELD_OK;
+    if (!idx_host || !val_host) return SELD_ERR_INVALID;
+    for (int64_t k = 0; k < n; ++k)
+        if (idx_host[k] < 0 || idx_host[k] >= limit) return fail(c, SELD_ERR_INVALID, "injected decision index out of range");
+    seld_ctx::Override o{kind, block, which, n, nullptr, nullptr};
+    if (dalloc(c, &o.idx, (size_t)n) || dalloc(c, &o.val, (size_t)n)) return SELD_ERR_NOMEM;
+    HIPCHK(c, hipMemcpy(o.idx, idx_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(o.val, val_host, (size_t)n, hipMemcpyHostToDevice));
+    c->overrides.push_back(o);
+    return SELD_OK;
+}
+
+int seld_debug_set_routing(seld_ctx* c, int block, int64_t n, const int64_t* idx_host, const unsigned char* val_host) {
+    if (!c || block < 0 || block >= (int)c->conv.size()) return SELD_ERR_INVALID;
+    const ConvL& L = c->conv[block];
+    const int64_t limit = (int64_t)c->Bmax * (L.H / L.pt) * (L.W / L.pf) * 64;
+    for (int64_t k = 0; k < n && val_host; ++k)
+        if (val_host[k] > L.pt * L.pf) return fail(c, SELD_ERR_INVALID, "injected routing value exceeds 1 + the window size");
+    return set_override(c, 0, block, 0, n, idx_host, val_host, limit);
+}
+
+int seld_debug_set_relu_gates(seld_ctx* c, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host) {
+    if (!c || which < 0 || which > 2) return SELD_ERR_INVALID;
+    if (c->arch.first_kind != SELD_FIRST_RESNET50 || block < 0 || block >= (int)c->rn.size()) return SELD_ERR_INVALID;
+    const RnBlock& R = c->rn[block];
+    const int64_t limit = (int64_t)c->Bmax * c->S * R.Wout * (which == 2 ? 4 * R.w : R.w);
+    return set_override(c, 1, block, which, n, idx_host, val_host, limit);
 }
 
 int seld_debug_relu_output(seld_ctx* c, int block, int which, float* dst, int64_t capacity, int64_t* count) {

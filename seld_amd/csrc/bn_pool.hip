@@ -397,6 +397,94 @@ int launch_pool_routing(hipStream_t st, const float* z, const float* p, const un
 }
 
 // ------------------------------------------------------------------------------------------------
+// Test aid (seld_debug_set_routing): make the backward pass take GIVEN routing decisions at a list of pooled elements.  The backward
+// kernels derive a window's routing from the stored tensors (first block: the recorded position `amax` and the sign of the pooled
+// activation p; other blocks: the scan of y = fmaf(z, scale, shift) over the window, strict >, and the sign of its maximum), so the
+// decision is injected by the SMALLEST edit of those tensors that makes them decide as told: amax = pos; or z at the given position
+// moved up ulp by ulp until its y is the window's strict maximum (and positive), p = that y; a closed gate: every positive y of the
+// window moved down to <= 0, p = 0.  The listed elements are near-ties (fp64 margin below 1e-5 by construction of the fixtures): the
+// edits are of that size and touch nothing else.  val = 0: gate closed; 1 + pos: gate open, argmax at window position pos.
+__global__ __launch_bounds__(256) void pool_routing_patch_kernel(float* __restrict__ z, float* __restrict__ p, unsigned char* __restrict__ amax,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const int64_t* __restrict__ idx, const unsigned char* __restrict__ val, int64_t n,
+                                                                 int H, int W, int PT, int PF) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t e = idx[k];
+    const int v = val[k];
+    const int c = (int)(e & 63);
+    const int64_t pp = e >> 6;
+    const int Wp = W / PF, Hp = H / PT;
+    const int fp = (int)(pp % Wp);
+    const int tp = (int)((pp / Wp) % Hp);
+    const int b = (int)(pp / ((int64_t)Wp * Hp));
+    if (amax) {      // first block: recorded position + sign of p
+        if (v == 0) { p[e] = 0.f; return; }
+        amax[e] = (unsigned char)(v - 1);
+        if (!(p[e] > 0.f)) p[e] = 1.17549435e-35f;
+        return;
+    }
+    const float sc = scale[c], sh = shift[c];
+    const size_t base = (((size_t)b * H + (size_t)tp * PT) * W + (size_t)fp * PF) * 64 + c;
+    if (v == 0) {
+        for (int i = 0; i < PT; ++i)
+            for (int j = 0; j < PF; ++j) {
+                float* za = z + base + ((size_t)i * W + j) * 64;
+                float zz = *za;
+                for (int it = 0; it < 65536 && fmaf(zz, sc, sh) > 0.f; ++it) zz = nextafterf(zz, sc > 0.f ? -INFINITY : INFINITY);
+                *za = zz;
+            }
+        p[e] = 0.f;
+        return;
+    }
+    const int pos = v - 1, pi = pos / PF, pj = pos % PF;
+    float other = 0.f;      // the given position must beat every other y of the window AND 0 (an open gate)
+    for (int i = 0; i < PT; ++i)
+        for (int j = 0; j < PF; ++j)
+            if (i != pi || j != pj) other = fmaxf(other, fmaf(z[base + ((size_t)i * W + j) * 64], sc, sh));
+    float* za = z + base + ((size_t)pi * W + pj) * 64;
+    float zz = *za;
+    for (int it = 0; it < 65536 && !(fmaf(zz, sc, sh) > other); ++it) zz = nextafterf(zz, sc > 0.f ? INFINITY : -INFINITY);
+    *za = zz;
+    p[e] = fmaf(zz, sc, sh);
+}
+
+int launch_pool_routing_patch(hipStream_t st, float* z, float* p, unsigned char* amax, const float* scale, const float* shift,
+                              const int64_t* idx, const unsigned char* val, int64_t n, int H, int W, int pt, int pf) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pool_routing_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, p, amax, scale, shift, idx, val, n, H, W, pt, pf);
+    return 0;
+}
+
+// Test aid (seld_debug_set_relu_gates): y[idx] = 0 (val 0) or a tiny positive value where it is not positive (val 1): the backward pass
+// reads a ReLU's gate from the sign of its stored output
+__global__ __launch_bounds__(256) void relu_gate_patch_kernel(float* __restrict__ y, const int64_t* __restrict__ idx, const unsigned char* __restrict__ val, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float* a = y + idx[k];
+    if (val[k] == 0) *a = 0.f;
+    else if (!(*a > 0.f)) *a = 1.17549435e-35f;
+}
+// the same on a packed gate (resnet50_block's output ReLU: bit j of byte q = gate of element 4 q + j), word-wise atomics: two listed
+// elements may share a byte
+__global__ __launch_bounds__(256) void relu_gatebits_patch_kernel(unsigned* __restrict__ gate_words, const int64_t* __restrict__ idx,
+                                                                  const unsigned char* __restrict__ val, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t e = idx[k], byte = e >> 2;
+    const unsigned bit = 1u << ((unsigned)(e & 3) + 8u * (unsigned)(byte & 3));
+    if (val[k]) atomicOr(gate_words + (byte >> 2), bit);
+    else atomicAnd(gate_words + (byte >> 2), ~bit);
+}
+int launch_relu_gate_patch(hipStream_t st, float* y, unsigned char* gate_bits, const int64_t* idx, const unsigned char* val, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(relu_gate_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, idx, val, n);
+    if (gate_bits)
+        hipLaunchKernelGGL(relu_gatebits_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(gate_bits), idx, val, n);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Synchronised BatchNorm (seld_set_sync_bn): the block partials are first reduced to 128 double sums, the host's
 // all-reduce callback sums those over the ranks, and the coefficients come from the global sums / global count.
 // sums[128] = THIS rank's element count: it is all-reduced with the sums, so that ranks holding different numbers of clips (a partial last

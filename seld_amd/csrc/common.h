@@ -205,6 +205,9 @@ int launch_bn_finalize_sums(hipStream_t st, const double* sums, double count, co
                             float* mov_mean, float* mov_var, float* mean, float* invstd, float* scale, float* shift);
 int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float* dbeta);
 int launch_bn_bwd_c1c2(hipStream_t st, const double* sums, double count, float* c1c2);
+int launch_pool_routing_patch(hipStream_t st, float* z, float* p, unsigned char* amax, const float* scale, const float* shift,
+                              const int64_t* idx, const unsigned char* val, int64_t n, int H, int W, int pt, int pf);
+int launch_relu_gate_patch(hipStream_t st, float* y, unsigned char* gate_bits, const int64_t* idx, const unsigned char* val, int64_t n);
 int launch_pool_routing(hipStream_t st, const float* z, const float* p, const unsigned char* amax, const float* scale,
                         const float* shift, unsigned char* pos, unsigned char* gate, int B, int H, int W, int pt, int pf);
 int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const float* mean, const float* invstd,

@@ -149,10 +149,10 @@ def iterloop(model: SeldNet, dataset, sed_loss, doa_loss, metric_class, config, 
 
 
 def main(config, model_config=None, max_epochs=None):
-    """reference train.main (train.py:264-390) around the accelerated steps: datasets, model with
-    n_classes forced to 12, Adam, BCE + MSE|MMSE, SELDMetrics, and the epoch loop with best-model save, LR
-    decay on plateau and early stopping on the validation SELD score (block-wise metrics.SELDMetrics score;
-    the reference's csv-based DCASE scorer is out of scope)."""
+    """reference train.main (train.py:264-390) around the accelerated steps: datasets (train / val / test folds), model with
+    n_classes forced to 12, `--resume` from the saved weights, Adam, BCE + MSE|MMSE, SELDMetrics, and the epoch loop —
+    train, validation and evaluation passes — with best-model save, LR decay on plateau and early stopping on the
+    validation SELD score (block-wise metrics.SELDMetrics score; the reference's csv-based DCASE scorer is out of scope)."""
     import os
     from . import metrics as _metrics
     from . import models
@@ -160,8 +160,9 @@ def main(config, model_config=None, max_epochs=None):
         config, model_config = config
     dev = torch.device('cuda', torch.cuda.current_device())
     trainset, valset = get_dataset(config, 'train', dev), get_dataset(config, 'val', dev)    # HBM-resident
+    testset = get_dataset(config, 'test', dev)                                                # train.py:290 (fold 6)
     x, y = next(iter(trainset.take(1)))
-    input_shape = (max(config.batch, valset.batch_size),) + tuple(x.shape[1:])
+    input_shape = (max(config.batch, valset.batch_size, testset.batch_size),) + tuple(x.shape[1:])
     model_config = dict(model_config)
     n_classes = 12                                                  # train.py:306-307
     model_config['n_classes'] = n_classes
@@ -173,6 +174,12 @@ def main(config, model_config=None, max_epochs=None):
     metric_class = _metrics.SELDMetrics(doa_threshold=config.lad_doa_thresh, n_classes=n_classes)
     model_path = os.path.join('./saved_model', config.name)
     os.makedirs(model_path, exist_ok=True)
+    if getattr(config, 'resume', False):                           # train.py:322-331: the saved model's weights, not the optimizer's slots
+        from glob import glob
+        saved = sorted(glob(os.path.join(model_path, '*.npz')))
+        if len(saved) == 0:
+            raise ValueError('the model is not existing, resume fail')
+        model.load_weights(saved[0])
     best, early, lr_pat, history = 99999.0, 0, 0, []
     for epoch in range(config.epoch if max_epochs is None else min(config.epoch, max_epochs)):
         metric_class.reset_states()
@@ -180,8 +187,11 @@ def main(config, model_config=None, max_epochs=None):
         metric_class.reset_states()
         va = iterloop(model, valset, sed_loss, doa_loss, metric_class, config, mode='val')
         score = va[2]
-        history.append({'epoch': epoch, 'train': tr, 'val': va, 'score': score, 'lr': optimizer.learning_rate})
-        print(f'epoch {epoch}: train sed/doa/seld {tr[0]:.4f}/{tr[1]:.5f}/{tr[2]:.4f}  val {va[0]:.4f}/{va[1]:.5f}/{va[2]:.4f}')
+        metric_class.reset_states()                                 # evaluation loop (train.py:367-369)
+        te = iterloop(model, testset, sed_loss, doa_loss, metric_class, config, mode='test')
+        history.append({'epoch': epoch, 'train': tr, 'val': va, 'test': te, 'score': score, 'lr': optimizer.learning_rate})
+        print(f'epoch {epoch}: train sed/doa/seld {tr[0]:.4f}/{tr[1]:.5f}/{tr[2]:.4f}  val {va[0]:.4f}/{va[1]:.5f}/{va[2]:.4f}'
+              f'  test {te[0]:.4f}/{te[1]:.5f}/{te[2]:.4f}')
         if best > score:                                            # train.py:372-380
             old = os.path.join(model_path, f'bestscore_{best}.npz')
             if os.path.exists(old):

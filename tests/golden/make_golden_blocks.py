@@ -15,7 +15,8 @@ Stored per model (inputs and weights are regenerated from seeds by the test):
     without an oracle on the GPU box.  A decision tensor is the first block's MaxPool(ReLU(.)) routing (value = 0 if the window
     passes 0, else 1 + argmax position) or one of resnet50_block's 48 ReLU gates (value = gate).  For each: `eps` (the margin
     below which a decision counts as unresolvable: 1e-5, or for the deep resnet gates 8 x the fp32 oracle's own error on that
-    pre-activation, clamped to [1e-5, 2e-3]), `near` = the flat indices whose fp64 margin is below eps, and `digest` = (count,
+    pre-activation, clamped to [1e-5, 2e-3]), `near` = the flat indices whose fp64 margin is below eps, `near_val` = the fp64
+    decision at each of them (round 4: injected by the test through seld_debug_set_routing / _set_relu_gates), and `digest` = (count,
     position-weighted checksum mod 2^64) of the fp64 decisions over all OTHER indices (`decision_digest`).  The library's
     decisions, digested with the same `near` indices excluded, must give the same pair: then every differing decision lies in
     `near`, i.e. has an fp64 margin below eps;
@@ -126,6 +127,7 @@ def main(which: str):
         worst = float(margin.reshape(-1)[diff].max()) if diff.any() else 0.0
         k = key.replace(".", "_")
         out[f"dec.{k}.near"] = near.astype(np.uint32)
+        out[f"dec.{k}.near_val"] = val.reshape(-1)[near].astype(np.uint8)      # the fp64 decisions AT the near-ties (round 4: injected by the test)
         out[f"dec.{k}.digest"] = decision_digest(val, near)
         out[f"dec.{k}.eps"] = np.float64(eps)
         names.append(k)

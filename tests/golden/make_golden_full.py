@@ -13,7 +13,9 @@ Stored per case (KB-sized; inputs and weights are regenerated from seeds by the 
     path to max(1e-4, bar) per variable.
   * DECISIONS (since round 3, as make_golden_blocks.py stores them): per conv block the MaxPool(ReLU(.)) routing of the fp64 forward —
     `dec.pool{i}.near` = flat indices of the pooled elements whose fp64 margin (top1 - top2, or |top1| for the ReLU gate) is below
-    1e-5, `dec.pool{i}.digest` = (count, position-weighted checksum) of value = 0 | 1 + argmax position over all OTHER elements.  The
+    1e-5, `dec.pool{i}.near_val` = the fp64 decision at each of them (round 4: tests inject these with seld_debug_set_routing and then
+    hold every variable's gradient to 1e-4 of THIS free-running fp64 evaluation, whose own decisions they are),
+    `dec.pool{i}.digest` = (count, position-weighted checksum) of value = 0 | 1 + argmax position over all OTHER elements.  The
     library's routing (seld_debug_pool_routing), digested with the same indices excluded, must give the same pair: every decision it
     takes differently from fp64 then has an fp64 margin below 1e-5 — asserted at B = 32 without an oracle on the GPU box.
 The reference cannot be imported here (TensorFlow absent), so these vectors pin the oracle restatement,
@@ -90,6 +92,7 @@ def main():
             val, margin = mb.pool_decisions(rr)
             near = np.flatnonzero(margin.reshape(-1) < 1e-5).astype(np.int64)
             out[f"dec.pool{i}.near"] = near.astype(np.uint32)
+            out[f"dec.pool{i}.near_val"] = val.reshape(-1)[near].astype(np.uint8)      # the fp64 decisions AT the near-ties (round 4: injected by the test)
             out[f"dec.pool{i}.digest"] = mb.decision_digest(val, near)
             print(f"  block {i}: {val.size} routing decisions, {near.size} with an fp64 margin below 1e-5")
             del rr, val, margin
