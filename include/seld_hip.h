@@ -392,6 +392,9 @@ int seld_debug_relu_output(seld_ctx* ctx, int block, int which, float* dst, int6
  * Implementation: the stored tensors the backward kernels read a decision from are edited by the smallest amount that makes them
  * decide as told (an ulp walk on one pre-BN value, the recorded argmax byte, a 1e-35 in place of a 0), after the forward pass has
  * finished with them.  Not for production use; calls synchronise the ctx stream. */
+/* xception_block (spec/XCEPTION_BLOCK.md): seld_debug_pool_routing / _set_routing take block = 1 for the EXIT's MaxPool(ReLU(.)) over (1, 8)
+ * ([B, T/5, 2, 64]); seld_debug_relu_output / _set_relu_gates take block = unit index 3 b + u, which = 0, for the ReLU in front of that
+ * unit's SeparableConv2D ([B, T/5, 16, 64]; the read returns the value whose sign is the gate). */
 int seld_debug_set_routing(seld_ctx* ctx, int block, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
 int seld_debug_set_relu_gates(seld_ctx* ctx, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
 /* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`

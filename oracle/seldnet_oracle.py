@@ -401,6 +401,8 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             y = h
             for u in range(3):
                 pre = f"xc{b}.{u}"
+                if record_routing is not None:       # the unit's ReLU gate and the pre-activation behind it (tests/golden/make_golden_blocks.py)
+                    record_routing[f"{pre}.in"] = {"gate": y.detach() > 0, "pre": y.detach()}
                 y = torch.relu(y)
                 dw = w[f"{pre}.depthwise_kernel"].permute(2, 3, 0, 1)           # [kh,kw,in,1] -> [in,1,kh,kw]
                 y = F.conv2d(y.permute(0, 3, 1, 2), dw, None, stride=1, padding=1, groups=C)
@@ -412,6 +414,11 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             h = h + y
             if taps is not None:
                 taps[f"xc{b}"] = h
+        if record_routing is not None:           # the exit's MaxPool(ReLU(.)) routing, as the conv blocks record theirs
+            Bq, Hq, Wq, Cq = h.shape
+            yw = h.detach().reshape(Bq, Hq, Wq // 8, 8, Cq).permute(0, 1, 2, 4, 3)
+            top, idx = yw.topk(2, dim=-1)
+            record_routing["exit"] = {"pos": idx[..., 0], "gate": top[..., 0] > 0, "gap": top[..., 0] - top[..., 1], "top": top[..., 0]}
         h = maxpool_nhwc(torch.relu(h), (1, 8))
     if spec.first == "resnet50_block":
         # spec/RESNET50_BLOCK.md: bottleneck blocks, strides on the frequency axis

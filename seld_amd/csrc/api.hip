@@ -1283,9 +1283,20 @@ static int backward_impl(seld_ctx* c, const float* x) {
             const bool recorded = o.block == 0 && L.amax && (c->gram_active || (L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1)));
             if (!recorded && !L.z) return fail(c, SELD_ERR_UNSUPPORTED, "seld_debug_set_routing: this block keeps neither recorded positions nor its pre-BN tensor");
             launch_pool_routing_patch(st, L.z, L.p, recorded ? L.amax : nullptr, L.scale, L.shift, o.idx, o.val, o.n, L.H, L.W, L.pt, L.pf);
+        } else if (o.kind == 2) {      // xception_block: the ReLU in front of unit o.block's depthwise convolution
+            const int b = o.block / 3, u = o.block % 3;
+            const bool fold = c->xc_fused_fwd && u > 0;
+            if (fold) launch_relu_gate_patch_z(st, c->xc[o.block - 1].z, nullptr, c->xc[o.block - 1].scale, c->xc[o.block - 1].scale + 64, 64, o.idx, o.val, o.n);
+            else launch_relu_gate_patch(st, u == 0 ? c->xc_x[b] : c->xc[o.block - 1].a, nullptr, o.idx, o.val, o.n);
+        } else if (o.kind == 3) {      // xception_block: the exit's MaxPool(ReLU(.)) over (1, 8), scanned from the last module's output
+            launch_pool_routing_patch(st, c->xc_x.back(), c->xc_feat, nullptr, c->xc_ident + 128, c->xc_ident + 192, o.idx, o.val, o.n, c->S, 16, 1, 8);
         } else {
             RnBlock& R = c->rn[o.block];
-            launch_relu_gate_patch(st, o.which == 0 ? R.y0 : (o.which == 1 ? R.y1 : R.out), o.which == 2 ? R.gate : nullptr, o.idx, o.val, o.n);
+            if (o.which == 2) launch_relu_gate_patch(st, R.out, R.gate, o.idx, o.val, o.n);      // read from the gate bits (and the output's sign)
+            else {      // recomputed by the backward kernels from the pre-BN tensor and the forward's scale / shift (coef + 2C, + 3C)
+                RnConv& K = R.c[o.which];
+                launch_relu_gate_patch_z(st, K.z, o.which == 0 ? R.y0 : R.y1, K.coef + 2 * K.Cout, K.coef + 3 * K.Cout, K.Cout, o.idx, o.val, o.n);
+            }
         }
     }
     const int B = c->B, S = c->S, rows = B * S;
@@ -1824,6 +1835,13 @@ int seld_train_step(seld_ctx* c, const float* x, const float* y_sed, const float
 
 // ---------------------------------------------------------------------------------------------- test aid
 int seld_debug_pool_routing(seld_ctx* c, int block, unsigned char* pos, unsigned char* gate) {
+    if (c && pos && gate && c->arch.first_kind == SELD_FIRST_XCEPTION && block == (int)c->conv.size()) {      // the exit pool of xception_block
+        HIPCHK(c, hipSetDevice(c->device));
+        if (launch_pool_routing(c->stream, c->xc_x.back(), c->xc_feat, nullptr, c->xc_ident + 128, c->xc_ident + 192, pos, gate, c->B, c->S, 16, 1, 8))
+            return fail(c, SELD_ERR_UNSUPPORTED, "pool_routing");
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return check_launch(c, "pool_routing");
+    }
     if (!c || !pos || !gate || block < 0 || block >= (int)c->conv.size()) return SELD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     const ConvL& L = c->conv[block];
@@ -1855,6 +1873,11 @@ static int set_override(seld_ctx* c, int kind, int block, int which, int64_t n, 
 }
 
 int seld_debug_set_routing(seld_ctx* c, int block, int64_t n, const int64_t* idx_host, const unsigned char* val_host) {
+    if (c && c->arch.first_kind == SELD_FIRST_XCEPTION && block == (int)c->conv.size()) {      // the exit pool of xception_block
+        for (int64_t k = 0; k < n && val_host; ++k)
+            if (val_host[k] > 8) return fail(c, SELD_ERR_INVALID, "injected routing value exceeds 1 + the window size");
+        return set_override(c, 3, block, 0, n, idx_host, val_host, (int64_t)c->Bmax * c->S * 2 * 64);
+    }
     if (!c || block < 0 || block >= (int)c->conv.size()) return SELD_ERR_INVALID;
     const ConvL& L = c->conv[block];
     const int64_t limit = (int64_t)c->Bmax * (L.H / L.pt) * (L.W / L.pf) * 64;
@@ -1865,6 +1888,10 @@ int seld_debug_set_routing(seld_ctx* c, int block, int64_t n, const int64_t* idx
 
 int seld_debug_set_relu_gates(seld_ctx* c, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host) {
     if (!c || which < 0 || which > 2) return SELD_ERR_INVALID;
+    if (c->arch.first_kind == SELD_FIRST_XCEPTION) {      // block = unit index 3 b + u: the ReLU in front of that unit
+        if (block < 0 || block >= (int)c->xc.size() || which != 0) return SELD_ERR_INVALID;
+        return set_override(c, 2, block, 0, n, idx_host, val_host, (int64_t)c->Bmax * c->S * 16 * 64);
+    }
     if (c->arch.first_kind != SELD_FIRST_RESNET50 || block < 0 || block >= (int)c->rn.size()) return SELD_ERR_INVALID;
     const RnBlock& R = c->rn[block];
     const int64_t limit = (int64_t)c->Bmax * c->S * R.Wout * (which == 2 ? 4 * R.w : R.w);
@@ -1873,6 +1900,18 @@ int seld_debug_set_relu_gates(seld_ctx* c, int block, int which, int64_t n, cons
 
 int seld_debug_relu_output(seld_ctx* c, int block, int which, float* dst, int64_t capacity, int64_t* count) {
     if (!c || !dst || !count || which < 0 || which > 2) return SELD_ERR_INVALID;
+    if (c->arch.first_kind == SELD_FIRST_XCEPTION) {      // block = unit index: the value whose sign is the gate of the ReLU in front of that unit
+        if (block < 0 || block >= (int)c->xc.size() || which != 0) return SELD_ERR_INVALID;
+        HIPCHK(c, hipSetDevice(c->device));
+        const int64_t n = (int64_t)c->B * c->S * 16 * 64;
+        *count = n;
+        if (capacity < n) return fail(c, SELD_ERR_INVALID, "seld_debug_relu_output: destination too small");
+        const int b = block / 3, u = block % 3;
+        const bool fold = c->xc_fused_fwd && u > 0;
+        launch_affine_copy(c->stream, u == 0 ? c->xc_x[b] : (fold ? c->xc[block - 1].z : c->xc[block - 1].a), fold ? c->xc[block - 1].scale : nullptr, dst, n, 64);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return check_launch(c, "relu_output");
+    }
     if (c->arch.first_kind != SELD_FIRST_RESNET50 || block < 0 || block >= (int)c->rn.size()) return SELD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     const RnBlock& R = c->rn[block];

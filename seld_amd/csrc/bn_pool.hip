@@ -476,6 +476,41 @@ __global__ __launch_bounds__(256) void relu_gatebits_patch_kernel(unsigned* __re
     if (val[k]) atomicOr(gate_words + (byte >> 2), bit);
     else atomicAnd(gate_words + (byte >> 2), ~bit);
 }
+// the same where the backward pass RECOMPUTES the gate as fmaf(z, scale, shift) > 0 from the pre-BatchNorm tensor (resnet50_block's two inner
+// ReLUs: no residual behind their BatchNorm): z walks ulp by ulp until that expression says what it is told; y follows
+__global__ __launch_bounds__(256) void relu_gate_patch_z_kernel(float* __restrict__ z, float* __restrict__ y, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int C, const int64_t* __restrict__ idx,
+                                                                const unsigned char* __restrict__ val, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t e = idx[k];
+    const int c = (int)(e % C);
+    const float sc = scale[c], sh = shift[c];
+    const bool want = val[k] != 0;
+    float zz = z[e];
+    for (int it = 0; it < 65536 && ((fmaf(zz, sc, sh) > 0.f) != want); ++it) zz = nextafterf(zz, (want == (sc > 0.f)) ? INFINITY : -INFINITY);
+    z[e] = zz;
+    if (y) y[e] = fmaxf(fmaf(zz, sc, sh), 0.f);
+}
+int launch_relu_gate_patch_z(hipStream_t st, float* z, float* y, const float* scale, const float* shift, int C, const int64_t* idx,
+                             const unsigned char* val, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(relu_gate_patch_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, y, scale, shift, C, idx, val, n);
+    return 0;
+}
+// a stored PRE-ReLU tensor (xception_block's module inputs): val 0 -> the element becomes 0 if it was positive, val 1 -> a tiny positive
+// value if it was not (the same kernel as for a post-ReLU tensor: relu_gate_patch_kernel)
+// dst = fmaf(x, scale[c], shift[c]) (or x): the value whose sign is a unit's ReLU gate (seld_debug_xc_unit_input)
+__global__ __launch_bounds__(256) void affine_copy_kernel(const float* __restrict__ x, const float* __restrict__ aff, float* __restrict__ dst, int64_t n, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    dst[i] = aff ? fmaf(x[i], aff[c], aff[C + c]) : x[i];
+}
+int launch_affine_copy(hipStream_t st, const float* x, const float* aff, float* dst, int64_t n, int C) {
+    hipLaunchKernelGGL(affine_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, aff, dst, n, C);
+    return 0;
+}
 int launch_relu_gate_patch(hipStream_t st, float* y, unsigned char* gate_bits, const int64_t* idx, const unsigned char* val, int64_t n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(relu_gate_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, idx, val, n);

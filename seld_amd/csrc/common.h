@@ -207,6 +207,9 @@ int launch_bn_bwd_local(hipStream_t st, const double* sums, float* dgamma, float
 int launch_bn_bwd_c1c2(hipStream_t st, const double* sums, double count, float* c1c2);
 int launch_pool_routing_patch(hipStream_t st, float* z, float* p, unsigned char* amax, const float* scale, const float* shift,
                               const int64_t* idx, const unsigned char* val, int64_t n, int H, int W, int pt, int pf);
+int launch_relu_gate_patch_z(hipStream_t st, float* z, float* y, const float* scale, const float* shift, int C, const int64_t* idx,
+                             const unsigned char* val, int64_t n);
+int launch_affine_copy(hipStream_t st, const float* x, const float* aff, float* dst, int64_t n, int C);
 int launch_relu_gate_patch(hipStream_t st, float* y, unsigned char* gate_bits, const int64_t* idx, const unsigned char* val, int64_t n);
 int launch_pool_routing(hipStream_t st, const float* z, const float* p, const unsigned char* amax, const float* scale,
                         const float* shift, unsigned char* pos, unsigned char* gate, int B, int H, int W, int pt, int pf);

@@ -13,7 +13,8 @@ Stored per model (inputs and weights are regenerated from seeds by the test):
     oracle evaluated in fp32 (what two evaluations of the reference's own arithmetic differ by at this size);
   * DECISIONS, so that a test can assert "every decision the library takes differently from fp64 is one fp32 cannot resolve"
     without an oracle on the GPU box.  A decision tensor is the first block's MaxPool(ReLU(.)) routing (value = 0 if the window
-    passes 0, else 1 + argmax position) or one of resnet50_block's 48 ReLU gates (value = gate).  For each: `eps` (the margin
+    passes 0, else 1 + argmax position), one of resnet50_block's 48 ReLU gates (value = gate), or — round 4 — one of xception_block's 24
+    unit-input ReLU gates / its exit MaxPool(ReLU(.)) routing.  For each: `eps` (the margin
     below which a decision counts as unresolvable: 1e-5, or for the deep resnet gates 8 x the fp32 oracle's own error on that
     pre-activation, clamped to [1e-5, 2e-3]), `near` = the flat indices whose fp64 margin is below eps, `near_val` = the fp64
     decision at each of them (round 4: injected by the test through seld_debug_set_routing / _set_relu_gates), and `digest` = (count,
@@ -104,7 +105,11 @@ def main(which: str):
     dec64["pool0"] = (val, margin, None)
     for key in list(rec64.keys()):
         v = rec64.pop(key)
-        dec64[key] = (v["gate"].numpy(), np.abs(v["pre"].numpy()), v["pre"].numpy())
+        if "pos" in v:      # a MaxPool(ReLU(.)) routing (xception_block's exit)
+            val, margin = pool_decisions(v)
+            dec64[key] = (val, margin, None)
+        else:               # a ReLU gate (resnet50_block's 48; xception_block's 24 unit inputs)
+            dec64[key] = (v["gate"].numpy(), np.abs(v["pre"].numpy()), v["pre"].numpy())
     t0 = time.time()
     rec32 = {}
     r32 = O.train_step(spec, w, st, x, ys, yd, dtype=torch.float32, record_routing=rec32, **kw)
@@ -112,8 +117,8 @@ def main(which: str):
     g32 = r32["grad"]
     names, flips = [], []
     for key, (val, margin, pre64) in dec64.items():
-        if key == "pool0":
-            rr = rec32.pop(0)
+        if pre64 is None:
+            rr = rec32.pop(0 if key == "pool0" else key)
             rr.pop("windows", None)
             v32, _ = pool_decisions(rr)
             eps = 1e-5

@@ -1225,6 +1225,16 @@ def test_block_model_full_batch_vs_golden(xception_config, resnet50_config, whic
             for k, nm in enumerate(("y0", "y1", "out")):
                 _lib.check(model.lib.seld_debug_relu_output(model.ctx, bi, k, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), model.ctx)
                 dec[f"rn{s_}_{b}_{nm}"] = (buf[:cnt.value] > 0).cpu().numpy()
+    if which == "xception_gru":       # round 4: the 24 unit-input ReLU gates and the exit's MaxPool(ReLU) routing too
+        buf = torch.empty(B * S * 16 * 64, device="cuda")
+        cnt = C.c_int64()
+        for i in range(3 * spec.xc_blocks):
+            _lib.check(model.lib.seld_debug_relu_output(model.ctx, i, 0, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(cnt)), model.ctx)
+            dec[f"xc{i // 3}_{i % 3}_in"] = (buf[:cnt.value] > 0).cpu().numpy()
+        pos2 = torch.empty((B, S, 2, 64), dtype=torch.uint8, device="cuda")
+        gate2 = torch.empty((B, S, 2, 64), dtype=torch.uint8, device="cuda")
+        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, 1, C.c_void_p(pos2.data_ptr()), C.c_void_p(gate2.data_ptr())), model.ctx)
+        dec["exit"] = torch.where(gate2 > 0, pos2.to(torch.int16) + 1, torch.zeros((), dtype=torch.int16, device="cuda")).cpu().numpy()
     assert sorted(dec) == sorted(str(n) for n in z["dec_names"])
     bad, n_near, n_dec = [], 0, 0
     for k, v in dec.items():
@@ -1498,6 +1508,11 @@ def test_full_size_parity_given_fp64_decisions(seldnet_config, xception_config, 
         for bi, (s_, b, ci, wd, stf, proj) in enumerate(O.resnet_plan(spec)):
             for k, nm in enumerate(("y0", "y1", "out")):
                 targets[f"rn{s_}_{b}_{nm}"] = (1, bi, k)
+    if case == "xception_gru":
+        for i in range(3 * spec.xc_blocks):
+            targets[f"xc{i // 3}_{i % 3}_in"] = (1, i, 0)
+        targets["exit"] = (0, 1, 0)
+    assert sorted(targets) == sorted(str(n) for n in z["dec_names"]) if "dec_names" in z else True
     n_inj = 0
     for key, (kind, block, which) in targets.items():
         if f"dec.{key}.near_val" not in z:
@@ -1593,3 +1608,56 @@ def test_bf16_single_product_mode_full_batch(seldnet_config):
     model.set_weights(w, st)
     step()
     np.testing.assert_array_equal(model.get_grads().astype(np.float64), g)
+
+
+@pytest.mark.parametrize("which", ["seldnet", "resnet50_gru"])
+def test_injected_decisions_reach_the_backward_pass(seldnet_config, resnet50_config, which):
+    """Functional test of seld_debug_set_routing / seld_debug_set_relu_gates at a size the fp64 oracle finishes in seconds: with the
+    oracle's OWN decisions injected at EVERY element (not only near-ties) the library's backward pass has no decision of its own left,
+    and every variable's gradient agrees with the free-running fp64 oracle to 1e-4; injecting the complement of a gate tensor instead
+    moves the gradients (the injection is what the backward pass reads)."""
+    import copy
+    import ctypes as C
+    from oracle import seldnet_oracle as O
+    from seld_amd import _lib, losses, models, train
+    if which == "seldnet":
+        cfg, B, T = seldnet_config, 2, 100
+    else:
+        cfg, B, T = copy.deepcopy(resnet50_config), 4, 300
+        cfg["FIRST_ARGS"]["block_num"] = [1, 1, 1, 1]
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 7)
+    x, ys, yd = O.synthetic_batch(B, T, seed=19)
+    free = {}
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64, record_routing=free)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    model.set_weights(w, st)
+
+    def inject(key, vals, kind, block, k):
+        v = np.ascontiguousarray(vals.reshape(-1).astype(np.uint8))
+        idx = np.arange(v.size, dtype=np.int64)
+        if kind == 0:
+            _lib.check(model.lib.seld_debug_set_routing(model.ctx, block, v.size, C.c_void_p(idx.ctypes.data), C.c_void_p(v.ctypes.data)), model.ctx)
+        else:
+            _lib.check(model.lib.seld_debug_set_relu_gates(model.ctx, block, k, v.size, C.c_void_p(idx.ctypes.data), C.c_void_p(v.ctypes.data)), model.ctx)
+
+    n_blocks = len(model_conv_blocks(spec))
+    for i in range(n_blocks):
+        f = free[i]
+        inject(f"pool{i}", np.where(f["gate"].numpy(), f["pos"].numpy() + 1, 0), 0, i, 0)
+    gates = []
+    if which == "resnet50_gru":
+        for bi, (s_, b, ci, wd, stf, proj) in enumerate(O.resnet_plan(spec)):
+            for k, nm in enumerate(("y0", "y1", "out")):
+                gates.append((bi, k, free[f"rn{s_}.{b}.{nm}"]["gate"].numpy()))
+                inject(nm, gates[-1][2], 1, bi, k)
+    step = lambda: train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    step()
+    g = model.get_grads().copy()
+    _per_var(model, f"{which} grad given ALL fp64 decisions", g, ref["grad"])
+    if gates:       # the complement of one gate tensor: the gradients must move
+        bi, k, gt = gates[len(gates) // 2]
+        inject("flip", ~gt, 1, bi, k)
+        model.set_weights(w, st)
+        step()
+        assert np.abs(model.get_grads() - g).max() > 1e-3 * np.abs(g).max()
