@@ -397,6 +397,40 @@ int seld_debug_relu_output(seld_ctx* ctx, int block, int which, float* dst, int6
  * unit's SeparableConv2D ([B, T/5, 16, 64]; the read returns the value whose sign is the gate). */
 int seld_debug_set_routing(seld_ctx* ctx, int block, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
 int seld_debug_set_relu_gates(seld_ctx* ctx, int block, int which, int64_t n, const int64_t* idx_host, const unsigned char* val_host);
+/* ---- module operators (module_ops.hip): what seld_amd/modules.py composes the reference's configurable blocks from — modules.mother_block
+ * / mother_stage (modules.py:15-43, 184-298: Conv2D(k, 'same', strides) + BatchNormalization + skip / projection / concatenation +
+ * squeeze-and-excitation), and, around them, bidirectional_GRU_block and simple_dense_block at ANY feature width.  NHWC fp32 device tensors,
+ * asynchronous on `stream`, no allocation (scratch is the caller's), any channel count / kernel / stride.  The dense products run on the
+ * fp32 MFMA GEMM of gemm.hip; everything else is memory-bound elementwise / reduction work. */
+int seld_m_conv_out(int in, int stride);      /* TensorFlow 'SAME': ceil(in / stride) */
+/* col[(b,ho,wo)][(ki,kj,c)] of Conv2D(k, 'same', strides) on x [B,H,W,C]; the convolution is col * kernel[kh kw C, filters] + bias */
+int seld_m_im2col(const float* x, float* col, int B, int H, int W, int C, int kh, int kw, int sh, int sw, void* stream);
+int seld_m_col2im(const float* dcol, float* dx, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int accumulate, void* stream);
+int seld_m_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int transb, int accumulate, void* stream);
+int64_t seld_m_gemm_tn_scratch(int K1, int N);
+int seld_m_gemm_tn(const float* A, const float* Bm, float* Cm, float* colsum, float* slab, int M, int K1, int N, int seq, int shift, void* stream);
+/* tf.keras.layers.BatchNormalization, training mode (layers.py:33, modules.py:232-268): batch mean / biased variance per channel ... */
+int seld_m_bn_stats(const float* z, int64_t npix, int C, float* mean, float* var, void* stream);
+/* ... out (+)= (z - mean) rsqrt(var + eps) gamma + beta (inference: mean / var = the moving statistics) ... */
+int seld_m_bn_apply(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* out,
+                    int64_t npix, int C, int accumulate, void* stream);
+/* ... moving = moving * momentum + batch * (1 - momentum), the variance Bessel-corrected by count / (count - 1) ... */
+int seld_m_bn_moving(const float* mean, const float* var, float* mov_mean, float* mov_var, int C, float momentum, int64_t count, void* stream);
+/* ... and its gradient: dgamma, dbeta, dz */
+int seld_m_bn_bwd(const float* z, const float* dy, const float* mean, const float* var, const float* gamma, float eps, float* dz, float* dgamma,
+                  float* dbeta, int64_t npix, int C, void* stream);
+#define SELD_ACT_SWISH 4
+/* y = act(x); dx (+)= dy act'(x) from the pre-activation x.  kind: SELD_ACT_NONE / _SIGMOID / _TANH / _RELU / _SWISH */
+int seld_m_act(const float* x, float* y, int64_t n, int kind, void* stream);
+int seld_m_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int kind, int accumulate, void* stream);
+int seld_m_axpy(float* dst, const float* src, int64_t n, float alpha, void* stream);      /* dst += alpha src */
+/* tf.concat(axis=-1) piece: mode 0 dst[r][off + c] = src[r][c]; mode 1 (its gradient) src[r][c] += dst[r][off + c] */
+int seld_m_copy_channels(float* src, float* dst, int64_t rows, int Cs, int Cd, int off, int mode, void* stream);
+/* squeeze-and-excitation (modules.py:287-294): reduce_mean over (H, W); out = se * out; and their gradients */
+int seld_m_mean_hw(const float* x, float* out, int B, int HW, int C, void* stream);
+int seld_m_scale_hw(const float* x, const float* s, float* y, int B, int HW, int C, void* stream);
+int seld_m_scale_hw_bwd_ds(const float* x, const float* dy, float* ds, int B, int HW, int C, void* stream);
+int seld_m_scale_hw_bwd_dx(const float* dy, const float* s, const float* dmean, float* dx, int B, int HW, int C, int accumulate, void* stream);
 /* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */

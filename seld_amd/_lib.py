@@ -145,6 +145,24 @@ SIGNATURES = {
     "seld_debug_set_routing": (_I, [_P, _I, _L, _P, _P]),
     "seld_debug_set_relu_gates": (_I, [_P, _I, _I, _L, _P, _P]),
     "seld_k_gru_timing": (_I, [_I, _P, _I]),
+    "seld_m_conv_out": (_I, [_I, _I]),
+    "seld_m_im2col": (_I, [_P, _P] + [_I] * 8 + [_P]),
+    "seld_m_col2im": (_I, [_P, _P] + [_I] * 9 + [_P]),
+    "seld_m_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "seld_m_gemm_tn_scratch": (_L, [_I, _I]),
+    "seld_m_gemm_tn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "seld_m_bn_stats": (_I, [_P, _L, _I, _P, _P, _P]),
+    "seld_m_bn_apply": (_I, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P]),
+    "seld_m_bn_moving": (_I, [_P, _P, _P, _P, _I, _F, _L, _P]),
+    "seld_m_bn_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
+    "seld_m_act": (_I, [_P, _P, _L, _I, _P]),
+    "seld_m_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "seld_m_axpy": (_I, [_P, _P, _L, _F, _P]),
+    "seld_m_copy_channels": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "seld_m_mean_hw": (_I, [_P, _P, _I, _I, _I, _P]),
+    "seld_m_scale_hw": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "seld_m_scale_hw_bwd_ds": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "seld_m_scale_hw_bwd_dx": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "seld_k_rn_conv": (_I, [_P, _P, _P] + [_I] * 7),
     "seld_k_rn_conv_bwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 7),
     "seld_k_rn_bn": (_I, [_P] * 7 + [_L, _I, _I]),

@@ -267,8 +267,17 @@ class SeldNet:
             pass
 
 
-def seldnet(input_shape, model_config, device=None, dtype: str = "float32") -> SeldNet:
-    """reference models.seldnet (models.py:18-32).  `dtype="bfloat16"`: bf16 single-product mode (SELD_DTYPE_BF16)."""
+COMPOSED_FIRST = ("mother_block", "mother_stage")      # seld_amd/modules.py: composed from the module operators, no fused ctx
+
+
+def seldnet(input_shape, model_config, device=None, dtype: str = "float32"):
+    """reference models.seldnet (models.py:18-32).  `dtype="bfloat16"`: bf16 single-product mode (SELD_DTYPE_BF16).  FIRST = mother_block /
+    mother_stage (modules.py:15-43, 184-298) builds a modules.ComposedSeldNet (layer-by-layer module operators) instead of a fused ctx."""
+    if model_config.get("FIRST") in COMPOSED_FIRST:
+        if dtype != "float32":
+            raise ValueError("composed models compute in float32")
+        from .modules import ComposedSeldNet
+        return ComposedSeldNet(input_shape, model_config, device)
     return SeldNet(input_shape, model_config, device, dtype)
 
 

@@ -47,6 +47,10 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
     ranks with one RCCL all-reduce between backward and Adam; BatchNorm statistics stay per replica."""
     if not isinstance(sed_loss, losses.BinaryCrossentropy):
         raise ValueError("sed_loss must be seld_amd.losses.BinaryCrossentropy()")
+    if not isinstance(model, SeldNet):       # modules.ComposedSeldNet (FIRST = mother_block / mother_stage): single process
+        if parallel.world_size(process_group) > 1:
+            raise ValueError("composed models are not data-parallel")
+        return model.train_step(x, y, _cfg(doa_loss, loss_weight), optimizer, agc)
     x = model._prep(x)
     B = x.shape[0]
     ys, yd = _labels(model, y, B)
@@ -83,6 +87,8 @@ def trainstep(model: SeldNet, x, y, sed_loss, doa_loss, loss_weight, optimizer: 
 
 def teststep(model: SeldNet, x, y, sed_loss, doa_loss):
     """reference train.teststep (train.py:39-44) -> (y_p, sloss, dloss)."""
+    if not isinstance(model, SeldNet):       # modules.ComposedSeldNet
+        return model.test_step(x, y, _cfg(doa_loss, (1.0, 1.0)))
     x = model._prep(x)
     B = x.shape[0]
     ys, yd = _labels(model, y, B)

@@ -46,8 +46,11 @@ def test_create_fails_loudly_without_gpu_or_bad_args(seld_lib):
 def test_unsupported_blocks_raise_value_error():
     import pytest
     from seld_amd import models
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):      # a fused ctx has no mother_block (models.seldnet composes one from module operators: seld_amd/modules.py)
         models._arch_from_config({"FIRST": "mother_block", "SECOND": "bidirectional_GRU_block", "SED": "simple_dense_block",
+                                  "DOA": "simple_dense_block"}, 7, 64)
+    with pytest.raises(ValueError):      # blocks of the reference that nothing here implements
+        models._arch_from_config({"FIRST": "conformer_encoder_stage", "SECOND": "bidirectional_GRU_block", "SED": "simple_dense_block",
                                   "DOA": "simple_dense_block"}, 7, 64)
     with pytest.raises(ValueError):      # xception_block kernels exist for the JSON's width only (spec/XCEPTION_BLOCK.md)
         models._arch_from_config({"FIRST": "xception_block", "FIRST_ARGS": {"filters": 48, "block_num": 8},
