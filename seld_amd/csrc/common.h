@@ -120,6 +120,7 @@ int launch_flip_weights(hipStream_t st, const float* w, float* wt);
 int launch_split_weights(hipStream_t st, const float* w, unsigned short* wsp);
 // up to 8 tensors in one launch; flip[i] != 0: the planes of the flipped (input-gradient) weights, from the unflipped tensor
 int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, unsigned short* const* dst, const int* flip);
+extern int g_tn_lds_floor_kb;   // gemm_tn_sb.hip: extra dynamic LDS (KB) of the GRU weight-gradient batch launches (0 = none)
 extern int g_gru_var;       // gru.hip: step-body variants (bit 0 forward, bit 1 backward)
 extern int g_conv64_dbuf;   // conv_sb.hip: 1 = double-buffered-weights kernel (default)
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,

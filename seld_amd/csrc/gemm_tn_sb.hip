@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
 }
 
 // K1 = 128, N % 128 == 0, 16-byte aligned operands with leading dimensions % 4 == 0; same slab layout / n_slab as launch_gemm_tn
+int g_tn_lds_floor_kb = 0;
 int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N) {
     return K1 == 128 && (N % 128) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
@@ -189,8 +190,16 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     int rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    if (g_mfma_one) hipLaunchKernelGGL((gemm_tn_sb_kernel<false, true>), dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
-    else hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false>), dim3(N / 128, njobs, splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    // g_tn_lds_floor_kb (option "tn_lds_floor", experiment): extra dynamic LDS per workgroup so that these side-stream blocks (48 KB static) cannot land on a
+    // CU that holds a GRU recurrence block (49 / 57 KB of the 160): the batch launches run under the next layer's BPTT
+    const size_t dyn = (size_t)g_tn_lds_floor_kb * 1024;
+    if (g_mfma_one) {
+        if (dyn) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_sb_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((gemm_tn_sb_kernel<false, true>), dim3(N / 128, njobs, splits), dim3(256), dyn, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    } else {
+        if (dyn) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_sb_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false>), dim3(N / 128, njobs, splits), dim3(256), dyn, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    }
     *nslab = splits;
     return 0;
 }
