@@ -11,7 +11,7 @@ mkdir -p "$out"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$root/tools/mfma_probe.hip" -o /tmp/mfma_probe 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_bench" -o pmc -- \
-    python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-features --no-inference --no-kernel-timing --no-configs > /dev/null 2> "$out/rocprof_bench.log"
+    python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-features --no-inference --no-kernel-timing --no-configs --detail-out /dev/null > /dev/null 2> "$out/rocprof_bench.log"
 timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_probe" -o pmc -- \
     /tmp/mfma_probe > "$out/probe.txt" 2> "$out/rocprof_probe.log"
 b=$(find "$out/pmc_bench" -name '*counter_collection.csv' | head -1)
