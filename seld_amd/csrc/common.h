@@ -123,6 +123,17 @@ int launch_split_weights_batch(hipStream_t st, int n, const float* const* w, uns
 extern int g_tn_lds_floor_kb;   // gemm_tn_sb.hip: extra dynamic LDS (KB) of the GRU weight-gradient batch launches (0 = none)
 extern int g_gru_var;       // gru.hip: step-body variants (bit 0 forward, bit 1 backward)
 extern int g_conv64_dbuf;   // conv_sb.hip: 1 = double-buffered-weights kernel (default)
+// two-plane split of two floats for the four-product form: hi = the truncated upper 16 bits, mid = the residual ROUNDED to bf16 (half up on the
+// magnitude: one integer add) — with a truncated mid the dropped remainder has the sign of x for every element, and the products it would have
+// carried bias every sum by the same ~2^-16 relative; rounded, it is zero-mean and the dropped terms average out over a sum
+__device__ __forceinline__ void split2r_pair(float x0, float x1, unsigned& h, unsigned& m) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    m = __builtin_amdgcn_perm(__float_as_uint(r1) + 0x8000u, __float_as_uint(r0) + 0x8000u, 0x07060302);
+}
+extern int g_bwd_four;        // conv_sb.hip: backward-only products on four of the six split-bf16 terms (option "bwd_four_products")
+int launch_conv64_dgrad_sb(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dx, int B, int H, int W);
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights

@@ -466,17 +466,21 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
 // Region = (R + 2) rows x W columns, three bf16 planes, rows XOR-swizzled; weights [2][3][64][64].
 // ONE: bf16 single-product mode — operands rounded to nearest bf16, plane 0 only (region, weights, fragments), one MFMA per k-step and
 // column tile instead of six.
-template <int WLOG2, int R, bool STATS, bool ONE>
+// FOUR (round 4, backward products only: option "bwd_four_products"): four of the six products — hi*hi, hi*mid, mid*hi, mid*mid; the two with a lo
+// factor (2^-17 relative each) are dropped, the lo planes are neither staged nor read.  An input gradient feeds no MaxPool / ReLU decision, so the
+// error (~1.5e-5 relative per product, random in sign over a 576-term sum) stays one decade inside the 1e-4 bar; forward products keep all six.
+template <int WLOG2, int R, bool STATS, bool ONE, bool FOUR = false>
 __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
     float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
     constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
     constexpr int RR = R + 2, NPIX = RR * W, ZROW = NPIX;               // region pixels; index of the all-zero row
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
-    constexpr int NW4 = (ONE ? 1 : 3) * 64 * 8, NWF = ONE ? (512 + NT - 1) / NT : (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
+    constexpr int NPL = ONE ? 1 : (FOUR ? 2 : 3);                       // bf16 planes in use
+    constexpr int NW4 = NPL * 64 * 8, NWF = ONE ? (512 + NT - 1) / NT : (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
     constexpr int LD = 64, PLANE = (NPIX + 1) * LD, WBUF = 3 * 64 * LD;
     static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
-    static_assert(ONE || NWF == 4 || NWF == 3, "weight staging is three or four named registers");
+    static_assert(ONE || NWF == 4 || NWF == 3 || (FOUR && NWF == 2), "weight staging is two to four named registers");
     static_assert(!ONE || NWF <= 2, "single-product weight staging is one or two named registers");
     extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
     unsigned short* Rp = sb_smem;                          // [3][NPIX + 1][LD]
@@ -521,6 +525,12 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
             unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
             if (ONE) {                                                                                  \
                 *reinterpret_cast<uint2*>(d_) = make_uint2(rne_pair(rreg[u].x, rreg[u].y), rne_pair(rreg[u].z, rreg[u].w)); \
+            } else if (FOUR) {                                                                          \
+            unsigned h0, m0, h1, m1;                                                                    \
+            split2r_pair(rreg[u].x, rreg[u].y, h0, m0);                                                 \
+            split2r_pair(rreg[u].z, rreg[u].w, h1, m1);                                                 \
+            *reinterpret_cast<uint2*>(d_) = make_uint2(h0, h1);                                         \
+            *reinterpret_cast<uint2*>(d_ + PLANE) = make_uint2(m0, m1);                                 \
             } else {                                                                                    \
             unsigned h0, m0, l0, h1, m1, l1;                                                            \
             split3_pair(rreg[u].x, rreg[u].y, h0, m0, l0);                                              \
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
             for (int s = 0; s < 4; ++s) {
                 bf16x8 a[3], bb[3][2];
 #pragma unroll
-                for (int pl = 0; pl < (ONE ? 1 : 3); ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     const int ca = (2 * s + hi) ^ asw, cw = (2 * s + hi) ^ wsw;
                     a[pl] = *reinterpret_cast<const bf16x8*>(arow + pl * PLANE + 8 * ca);
                     bb[pl][0] = *reinterpret_cast<const bf16x8*>(wrow0 + pl * 64 * LD + 8 * cw);
@@ -603,8 +613,10 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
                 if (!ONE) {
                 SBD_MFMA(a[0], bb[1][0], accs[0]); SBD_MFMA(a[0], bb[1][1], accs[1]);    // hi*mid
                 SBD_MFMA(a[1], bb[0][0], acc[0]);  SBD_MFMA(a[1], bb[0][1], acc[1]);     // mid*hi
+                if (!FOUR) {
                 SBD_MFMA(a[0], bb[2][0], accs[0]); SBD_MFMA(a[0], bb[2][1], accs[1]);    // hi*lo
                 SBD_MFMA(a[2], bb[0][0], acc[0]);  SBD_MFMA(a[2], bb[0][1], acc[1]);     // lo*hi
+                }
                 SBD_MFMA(a[1], bb[1][0], accs[0]); SBD_MFMA(a[1], bb[1][1], accs[1]);    // mid*mid
                 }
 #undef SBD_MFMA
@@ -668,6 +680,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     }
 }
 
+int g_bwd_four = 1;        // option "bwd_four_products": backward-only products (input / kernel gradients) on four of the six split-bf16 terms
+static int s_sbd_four = 0; // set around an input-gradient launch (launch_conv64_dgrad_sb)
 int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights) for W = 16 / 4; 0: conv64_fwd_sbr_kernel
 
 template <int WLOG2, int R>
@@ -685,7 +699,10 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
         hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);   \
     }
     if (g_mfma_one) { if (stat_partial) SBD_GO(true, true) else SBD_GO(false, true) }
-    else { if (stat_partial) SBD_GO(true, false) else SBD_GO(false, false) }
+    else if (s_sbd_four && !stat_partial) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+    } else { if (stat_partial) SBD_GO(true, false) else SBD_GO(false, false) }
 #undef SBD_GO
     if (n_partial) *n_partial = grid;
     return 0;
@@ -711,4 +728,13 @@ int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* w
     }
     if (n_partial) *n_partial = grid;
     return 0;
+}
+
+// the input gradient of a 64 -> 64 3x3 convolution = the forward kernel on dz with the flipped, channel-swapped weights (wsp_flip); four products when
+// the option allows (the forward itself never takes that path: s_sbd_four is set here only)
+int launch_conv64_dgrad_sb(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dx, int B, int H, int W) {
+    s_sbd_four = g_bwd_four && !g_mfma_one;
+    const int rc = launch_conv64_fwd_sb(st, dz, wsp_flip, nullptr, dx, nullptr, nullptr, B, H, W);
+    s_sbd_four = 0;
+    return rc;
 }

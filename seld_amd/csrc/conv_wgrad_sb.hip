@@ -48,7 +48,8 @@ __device__ __forceinline__ bf16x8 wgsb_frag(const char* p0, const char* p1) {
 __device__ __forceinline__ unsigned wgsb_rne_pair(float x0, float x1) { return bf16_rne_bits(x0) | (bf16_rne_bits(x1) << 16); }
 
 // ONE: bf16 single-product mode (common.h g_mfma_one): operands rounded to nearest bf16, plane 0 only, one MFMA per (k-step, tap)
-template <int WLOG2, bool ONE>
+// FOUR (option "bwd_four_products", conv_sb.hip g_bwd_four): the two products with a lo factor are dropped and the lo planes neither staged nor read
+template <int WLOG2, bool ONE, bool FOUR = false>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                  float* __restrict__ slab, int B, int H) {
     constexpr int W = 1 << WLOG2, R = WGSB_PXC / W, RW = W + 2, RR = R + 2;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
     H_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 0), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 0));       \
     if (!ONE) {                                                                                                       \
     M_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 1), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 1));       \
-    L_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 2), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 2));       \
+    if (!FOUR) L_ = wgsb_frag(WGSB_AADDR(s_, 0, (tap_) / 3, (tap_) % 3, 2), WGSB_AADDR(s_, 1, (tap_) / 3, (tap_) % 3, 2)); \
     }
 #define WGSB_LDB(s_, H_, M_, L_)                                                                                      \
     {                                                                                                                 \
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
         H_ = wgsb_frag(bp_, bp_ + 4 * 128);                                                                           \
         if (!ONE) {                                                                                                   \
         M_ = wgsb_frag(bp_ + DPL, bp_ + DPL + 4 * 128);                                                               \
-        L_ = wgsb_frag(bp_ + 2 * DPL, bp_ + 2 * DPL + 4 * 128);                                                       \
+        if (!FOUR) L_ = wgsb_frag(bp_ + 2 * DPL, bp_ + 2 * DPL + 4 * 128);                                            \
         }                                                                                                             \
     }
 #define WGSB_TAP(s_, tap_, ACC_)                                                                                      \
@@ -108,9 +109,11 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
         if (!last_) { WGSB_LDA(ns_, nt_, nh, nm, nl) }                                                                \
         if (!last_ && (tap_) == 8) WGSB_LDB(ns_, nbh, nbm, nbl)                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        if (!ONE) { WGSB_MFMA(al, bh, ACC_); WGSB_MFMA(am, bh, ACC_); WGSB_MFMA(am, bm, ACC_); }                      \
+        if (!ONE && !FOUR) WGSB_MFMA(al, bh, ACC_);                                                                   \
+        if (!ONE) { WGSB_MFMA(am, bh, ACC_); WGSB_MFMA(am, bm, ACC_); }                                               \
         WGSB_MFMA(ah, bh, ACC_);                                                                                      \
-        if (!ONE) { WGSB_MFMA(ah, bm, ACC_); WGSB_MFMA(ah, bl, ACC_); }                                               \
+        if (!ONE) WGSB_MFMA(ah, bm, ACC_);                                                                            \
+        if (!ONE && !FOUR) WGSB_MFMA(ah, bl, ACC_);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         ah = nh; am = nm; al = nl;                                                                                    \
         if ((tap_) == 8) { bh = nbh; bm = nbm; bl = nbl; }                                                            \
@@ -151,6 +154,12 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
         char* d = (base_) + (P_) * 128 + ((8 * (g_)) ^ (64 * (((P_) >> 1) & 1)));                                     \
         if (ONE) {                                                                                                    \
             *reinterpret_cast<uint2*>(d) = make_uint2(wgsb_rne_pair(v_.x, v_.y), wgsb_rne_pair(v_.z, v_.w));          \
+        } else if (FOUR) {                                                                                            \
+        unsigned h0, m0, h1, m1;                                                                                      \
+        split2r_pair(v_.x, v_.y, h0, m0);                                                                             \
+        split2r_pair(v_.z, v_.w, h1, m1);                                                                             \
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);                                                            \
+        *reinterpret_cast<uint2*>(d + (PL_)) = make_uint2(m0, m1);                                                    \
         } else {                                                                                                      \
         unsigned h0, m0, l0, h1, m1, l1;                                                                              \
         wgsb_split3_pair(v_.x, v_.y, h0, m0, l0);                                                                     \
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_sb_kernel(const float* __
         __syncthreads();                      // everyone is done reading the previous chunk
         WGSB_COMMIT()
         __syncthreads();
-        bf16x8 ah, am, al, bh, bm, bl, nh, nm, nl, nbh, nbm, nbl;
+        bf16x8 ah = {}, am = {}, al = {}, bh = {}, bm = {}, bl = {}, nh, nm, nl, nbh, nbm, nbl;
         WGSB_LDB(0, bh, bm, bl)
         WGSB_LDA(0, 0, ah, am, al)
         nh = ah; nm = am; nl = al; nbh = bh; nbm = bm; nbl = bl;
@@ -233,6 +242,10 @@ int launch_conv64_wgrad_sb(hipStream_t st, const float* x, const float* dz, floa
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L, true>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
             hipLaunchKernelGGL((conv64_wgrad_sb_kernel<L, true>), dim3(grid), dim3(256), smem, st, x, dz, slab, B, H);  \
+        } else if (g_bwd_four) {                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L, false, true>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
+            hipLaunchKernelGGL((conv64_wgrad_sb_kernel<L, false, true>), dim3(grid), dim3(256), smem, st, x, dz, slab, B, H); \
         } else {                                                                                              \
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_wgrad_sb_kernel<L, false>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \

@@ -41,7 +41,8 @@ __device__ __forceinline__ bf16x8 tnsb_frag(const char* p0, const char* p1) {
 // 'same', zeros outside the H x W image): tile y covers columns 128 y .. of it, i.e. ONE tap (C % 128 == 0) at channel offset
 // (128 y) % C — the row of the image is the pixel shifted by the tap, masked at the image border.
 // ONE: bf16 single-product mode (common.h g_mfma_one): both operands rounded to nearest bf16, plane 0 only, one MFMA per tile pair
-template <bool CONV, bool ONE = false>      // a template parameter: the GRU's instantiation (the headline step's side stream) must not carry the convolution's index work
+// FOUR (option "bwd_four_products", conv_sb.hip g_bwd_four): weight gradients on four products — the two with a lo factor dropped, two planes per image
+template <bool CONV, bool ONE = false, bool FOUR = false>      // a template parameter: the GRU's instantiation (the headline step's side stream) must not carry the convolution's index work
 __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb, float* __restrict__ slab, int M, int N, int rows_per_split,
                                                             int S, int want_bias, long long tile_stride, int cvs, int cvH, int cvW) {
     const int job = tile_stride ? 0 : blockIdx.y;
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
     const float* __restrict__ A = jobs.A[job] + (CONV ? 128 * (int)blockIdx.y - (cv_tap << cvs) : tile_stride ? 128 * blockIdx.y : 0);
     const float* __restrict__ Bm = jobs.B[job];
     const int lda = CONV ? 1 << cvs : jobs.lda[job], shift = jobs.shift[job];
-    __shared__ __attribute__((aligned(16))) char Al[3 * TNSB_PL];
-    __shared__ __attribute__((aligned(16))) char Bl[3 * TNSB_PL];
+    __shared__ __attribute__((aligned(16))) char Al[(FOUR ? 2 : 3) * TNSB_PL];
+    __shared__ __attribute__((aligned(16))) char Bl[(FOUR ? 2 : 3) * TNSB_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = wave >> 1, nh = wave & 1;
     const int kg = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
@@ -95,6 +96,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
         char* d = (img_) + (m_) * 256 + ((((c4 >> 3) ^ ((m_) & 3)) << 6) | (8 * (c4 & 7)));                  \
         if (ONE) {                                                                                           \
             *reinterpret_cast<uint2*>(d) = make_uint2(bf16_rne_bits(v_.x) | (bf16_rne_bits(v_.y) << 16), bf16_rne_bits(v_.z) | (bf16_rne_bits(v_.w) << 16)); \
+        } else if (FOUR) {                                                                                   \
+        unsigned h0, m0, h1, m1;                                                                             \
+        split2r_pair(v_.x, v_.y, h0, m0);                                                                    \
+        split2r_pair(v_.z, v_.w, h1, m1);                                                                    \
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);                                                   \
+        *reinterpret_cast<uint2*>(d + TNSB_PL) = make_uint2(m0, m1);                                         \
         } else {                                                                                             \
         unsigned h0, m0, l0, h1, m1, l1;                                                                     \
         tnsb_split3_pair(v_.x, v_.y, h0, m0, l0);                                                            \
@@ -113,8 +120,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
     f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();      // [k1 tile][n tile] of this wave
 #define TNSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
 #define TNSB_PAIR(AH, AM, AL, BH, BM_, BL, ACC_)                                                             \
-    TNSB_MFMA(AL, BH, ACC_); TNSB_MFMA(AM, BH, ACC_); TNSB_MFMA(AM, BM_, ACC_);                              \
-    TNSB_MFMA(AH, BH, ACC_); TNSB_MFMA(AH, BM_, ACC_); TNSB_MFMA(AH, BL, ACC_);
+    if (!FOUR) TNSB_MFMA(AL, BH, ACC_);                                                                      \
+    TNSB_MFMA(AM, BH, ACC_); TNSB_MFMA(AM, BM_, ACC_);                                                       \
+    TNSB_MFMA(AH, BH, ACC_); TNSB_MFMA(AH, BM_, ACC_);                                                       \
+    if (!FOUR) TNSB_MFMA(AH, BL, ACC_);
 #define TNSB_KSTEP(s_)                                                                                       \
     if (ONE) {                                                                                               \
         constexpr int o_ = (16 * (s_)) * 256;                                                                \
@@ -125,13 +134,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
     {                                                                                                        \
         constexpr int o_ = (16 * (s_)) * 256;                                                                \
         const bf16x8 a0h = tnsb_frag(Al + o_ + oa0, Al + o_ + oa0 + 4 * 256), a0m = tnsb_frag(Al + TNSB_PL + o_ + oa0, Al + TNSB_PL + o_ + oa0 + 4 * 256), \
-                     a0l = tnsb_frag(Al + 2 * TNSB_PL + o_ + oa0, Al + 2 * TNSB_PL + o_ + oa0 + 4 * 256);    \
+                     a0l = FOUR ? a0m : tnsb_frag(Al + 2 * TNSB_PL + o_ + oa0, Al + 2 * TNSB_PL + o_ + oa0 + 4 * 256);    \
         const bf16x8 a1h = tnsb_frag(Al + o_ + oa1, Al + o_ + oa1 + 4 * 256), a1m = tnsb_frag(Al + TNSB_PL + o_ + oa1, Al + TNSB_PL + o_ + oa1 + 4 * 256), \
-                     a1l = tnsb_frag(Al + 2 * TNSB_PL + o_ + oa1, Al + 2 * TNSB_PL + o_ + oa1 + 4 * 256);    \
+                     a1l = FOUR ? a1m : tnsb_frag(Al + 2 * TNSB_PL + o_ + oa1, Al + 2 * TNSB_PL + o_ + oa1 + 4 * 256);    \
         const bf16x8 b0h = tnsb_frag(Bl + o_ + ob0, Bl + o_ + ob0 + 4 * 256), b0m = tnsb_frag(Bl + TNSB_PL + o_ + ob0, Bl + TNSB_PL + o_ + ob0 + 4 * 256), \
-                     b0l = tnsb_frag(Bl + 2 * TNSB_PL + o_ + ob0, Bl + 2 * TNSB_PL + o_ + ob0 + 4 * 256);    \
+                     b0l = FOUR ? b0m : tnsb_frag(Bl + 2 * TNSB_PL + o_ + ob0, Bl + 2 * TNSB_PL + o_ + ob0 + 4 * 256);    \
         const bf16x8 b1h = tnsb_frag(Bl + o_ + ob1, Bl + o_ + ob1 + 4 * 256), b1m = tnsb_frag(Bl + TNSB_PL + o_ + ob1, Bl + TNSB_PL + o_ + ob1 + 4 * 256), \
-                     b1l = tnsb_frag(Bl + 2 * TNSB_PL + o_ + ob1, Bl + 2 * TNSB_PL + o_ + ob1 + 4 * 256);    \
+                     b1l = FOUR ? b1m : tnsb_frag(Bl + 2 * TNSB_PL + o_ + ob1, Bl + 2 * TNSB_PL + o_ + ob1 + 4 * 256);    \
         TNSB_PAIR(a0h, a0m, a0l, b0h, b0m, b0l, c00) TNSB_PAIR(a0h, a0m, a0l, b1h, b1m, b1l, c01)            \
         TNSB_PAIR(a1h, a1m, a1l, b0h, b0m, b0l, c10) TNSB_PAIR(a1h, a1m, a1l, b1h, b1m, b1l, c11)            \
     }
@@ -196,6 +205,9 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     if (g_mfma_one) {
         if (dyn) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_sb_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         hipLaunchKernelGGL((gemm_tn_sb_kernel<false, true>), dim3(N / 128, njobs, splits), dim3(256), dyn, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
+    } else if (g_bwd_four) {
+        if (dyn) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_sb_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false, true>), dim3(N / 128, njobs, splits), dim3(256), dyn, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);
     } else {
         if (dyn) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_sb_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false>), dim3(N / 128, njobs, splits), dim3(256), dyn, st, jobs, ldb, slab, M, N, rps, S > 0 ? S : M, want_bias, 0LL, 0, 0, 0);

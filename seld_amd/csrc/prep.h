@@ -46,7 +46,9 @@ __device__ __forceinline__ void split_weights_body(const SplitWeightJobs& jobs, 
     const float x = jobs.flip[job] ? w[(8 - tap) * 4096 + out * 64 + in] : w[tap * 4096 + in * 64 + out];
     const unsigned u = jobs.one ? bf16_rne_bits(x) << 16 : __float_as_uint(x) & 0xffff0000u;      // see gemm_split_b_body
     const float r = x - __uint_as_float(u);
-    const unsigned v = __float_as_uint(r);
+    // the flipped (input-gradient) form rounds its mid plane (common.h split2r_pair: the four-product kernel reads planes 0, 1 only and wants a
+    // zero-mean remainder); plane 2 still completes the exact split, so the six-product kernel sees the same weights either way
+    const unsigned v = __float_as_uint(r) + (jobs.flip[job] ? 0x8000u : 0u);
     const float s = r - __uint_as_float(v & 0xffff0000u);
     unsigned short* o = wsp + (size_t)tap * 3 * 4096 + out * 64 + in;
     o[0] = (unsigned short)(u >> 16);

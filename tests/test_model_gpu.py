@@ -546,7 +546,7 @@ def test_main_loop_on_tiny_dataset(tmp_path, seldnet_config, monkeypatch, aug):
         config_r, _ = params.get_param(["--name", "t", "--abspath", str(tmp_path) + "/", "--batch", "16", "--loop_time", "1", "--epoch", "1",
                                         "--resume"], model_config_dir=str(mcd))
         m2, h2 = train.main((config_r, mc))
-        assert h2[0]["val"][1] <= hist[0]["val"][1]          # it starts where the saved model was, not from scratch
+        assert h2[0]["train"][1] < hist[0]["train"][1]       # it starts where the saved model was, not from scratch (the validation loss moves in the fifth digit only on this data)
         config_n, _ = params.get_param(["--name", "nothing_saved", "--abspath", str(tmp_path) + "/", "--batch", "16", "--resume"], model_config_dir=str(mcd))
         with pytest.raises(ValueError):
             train.main((config_n, mc))
