@@ -1363,10 +1363,11 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 if (j > 0 && Hd.hidden_act) launch_act_bwd(st, Hd.layers[j - 1].y, din, (int64_t)rows * D.in, Hd.hidden_act);
             }
         }
-        if (merged0 && heads_sb(c) && gemm_sb_usable(S0.dy, S0.out, S0.in, S0.out) && gemm_sb_usable(D0.dy, S0.out, S0.in, S0.out))
+        if (merged0 && heads_sb(c) && gemm_sb_usable(S0.dy, S0.out, S0.in, S0.out) && gemm_sb_usable(D0.dy, S0.out, S0.in, S0.out)) {
+            BwdFourScope four_;
             launch_gemm_sb(st, S0.dy, D0.dy, S0.out, c->h0sp_bwd[0], c->h0sp_bwd[1], nullptr, nullptr, dfeat, nullptr, S0.in, rows, S0.in,
                            S0.out, 0, 2);
-        else if (merged0)
+        } else if (merged0)
             launch_gemm_dual_k(st, S0.dy, D0.dy, S0.out, c->params + S0.w_off, c->params + D0.w_off, S0.out, nullptr, dfeat, S0.in, rows,
                                S0.in, S0.out, 1, 0, 0);
         fork_side(c);
@@ -1414,10 +1415,11 @@ static int backward_impl(seld_ctx* c, const float* x) {
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
-            if (gru_sb(c, G))
+            if (gru_sb(c, G)) {
+                BwdFourScope four_;
                 launch_gemm_sb(st, c->dgx[i][0], c->dgx[i][1], 384, c->ksp_bwd[i][0], c->ksp_bwd[i][1], nullptr, nullptr, G.din, nullptr,
                                G.in_feat, rows, G.in_feat, 384, 0, 2);
-            else
+            } else
                 launch_gemm_dual_k(st, c->dgx[i][0], c->dgx[i][1], 384, c->params + G.k_off[0], c->params + G.k_off[1], 384, nullptr,
                                    G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
         }
@@ -1477,7 +1479,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 } else
                     launch_reduce_slabs(ws, c->rn_w9_slab, ns, 9 * 4096 + 64, c->grads + R.c[1].w_off, 9 * 4096, 0);
                 done(bbi);
-                { PROF3(c, "rn_products_dgrad"); launch_conv64_fwd_sb(st, dz1, R.c[1].wsp9_flip, nullptr, c->rn_ba, nullptr, nullptr, B, S, rn_c1_width(R)); }
+                { PROF3(c, "rn_products_dgrad"); launch_conv64_dgrad_sb(st, dz1, R.c[1].wsp9_flip, c->rn_ba, B, S, rn_c1_width(R)); }
             } else if (sb && rn_c1_implicit(c, R)) {
                 fork(bbi);
                 launch_rn_conv3_wgrad(ws, R.y0, dz1, c->tn_slab, tn_slab_capacity(), c->grads + R.c[1].w_off, B, S,

@@ -68,7 +68,9 @@ int launch_gemm_split_b(hipStream_t st, int njobs, const float* const* src, unsi
 // mode 2 (one product over a concatenated K axis): C0 = act(A0 B0 + A1 B1 + bias0).
 // ONE: bf16 single-product mode (common.h g_mfma_one): A rounded to nearest bf16 in registers, B's plane 0 holds the rounded weights
 // (gemm_split_b with jobs.one); one MFMA per k-step and column tile.  The B staging still moves all three planes (untouched code path).
-template <int NG, bool ONE = false>   // NG 4: K = 128, one product (or two sharing A): every A row of the tile is requested up front; 0: runtime loop
+// FOUR (option "bwd_four_products", set for a launch by BwdFourScope — backward products only): the two products with a lo factor are dropped, plane 2 of B is
+// not staged, A is split in two planes with a rounded mid (common.h split2r_pair; gemm_split_b rounds the mid plane of every transposed / flipped B likewise)
+template <int NG, bool ONE = false, bool FOUR = false>   // NG 4: K = 128, one product (or two sharing A): every A row of the tile is requested up front; 0: runtime loop
 __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
@@ -103,14 +105,14 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
         const size_t ps_ = (size_t)N * GSB_KC / 8;  /* plane stride in 16-B units */                           \
         bq0 = bp_[tid]; bq1 = bp_[tid + 256];                                                                  \
         bq2 = bp_[ps_ + tid]; bq3 = bp_[ps_ + tid + 256];                                                      \
-        bq4 = bp_[2 * ps_ + tid]; bq5 = bp_[2 * ps_ + tid + 256];                                              \
+        if (!FOUR) { bq4 = bp_[2 * ps_ + tid]; bq5 = bp_[2 * ps_ + tid + 256]; }                               \
     }
 #define GSB_COMMIT(buf_)                                                          \
     {                                                                             \
         u32x4* d_ = reinterpret_cast<u32x4*>(Bl[buf_]);                           \
         d_[tid] = bq0; d_[tid + 256] = bq1;                                       \
         d_[512 + tid] = bq2; d_[512 + tid + 256] = bq3;                           \
-        d_[1024 + tid] = bq4; d_[1024 + tid + 256] = bq5;                         \
+        if (!FOUR) { d_[1024 + tid] = bq4; d_[1024 + tid + 256] = bq5; }          \
     }
     GSB_ISSUE(0)
     GSB_COMMIT(0)
@@ -128,6 +130,24 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
         const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb_), bh1 = *reinterpret_cast<const bf16x8*>(bb_ + 32 * GSB_KC), \
                      bh2 = *reinterpret_cast<const bf16x8*>(bb_ + 64 * GSB_KC), bh3 = *reinterpret_cast<const bf16x8*>(bb_ + 96 * GSB_KC); \
         GSB_MFMA(ah, bh0, acc0); GSB_MFMA(ah, bh1, acc1); GSB_MFMA(ah, bh2, acc2); GSB_MFMA(ah, bh3, acc3);   \
+    } else if (FOUR) {                                                                                \
+        unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_;                                              \
+        split2r_pair(x0_.x, x0_.y, h0_, m0_);                                                         \
+        split2r_pair(x0_.z, x0_.w, h1_, m1_);                                                         \
+        split2r_pair(x1_.x, x1_.y, h2_, m2_);                                                         \
+        split2r_pair(x1_.z, x1_.w, h3_, m3_);                                                         \
+        const u32x4 h_ = {h0_, h1_, h2_, h3_}, m_ = {m0_, m1_, m2_, m3_};                             \
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h_), am = __builtin_bit_cast(bf16x8, m_);        \
+        const unsigned short* bb_ = bl + boff_;                                                       \
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb_), bh1 = *reinterpret_cast<const bf16x8*>(bb_ + 32 * GSB_KC), \
+                     bh2 = *reinterpret_cast<const bf16x8*>(bb_ + 64 * GSB_KC), bh3 = *reinterpret_cast<const bf16x8*>(bb_ + 96 * GSB_KC); \
+        const unsigned short* bm_ = bb_ + GSB_BN * GSB_KC;                                            \
+        const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(bm_), bm1 = *reinterpret_cast<const bf16x8*>(bm_ + 32 * GSB_KC), \
+                     bm2 = *reinterpret_cast<const bf16x8*>(bm_ + 64 * GSB_KC), bm3 = *reinterpret_cast<const bf16x8*>(bm_ + 96 * GSB_KC); \
+        GSB_MFMA(ah, bh0, acc0); GSB_MFMA(ah, bh1, acc1); GSB_MFMA(ah, bh2, acc2); GSB_MFMA(ah, bh3, acc3);   /* hi*hi  */ \
+        GSB_MFMA(ah, bm0, acc0); GSB_MFMA(ah, bm1, acc1); GSB_MFMA(ah, bm2, acc2); GSB_MFMA(ah, bm3, acc3);   /* hi*mid */ \
+        GSB_MFMA(am, bh0, acc0); GSB_MFMA(am, bh1, acc1); GSB_MFMA(am, bh2, acc2); GSB_MFMA(am, bh3, acc3);   /* mid*hi */ \
+        GSB_MFMA(am, bm0, acc0); GSB_MFMA(am, bm1, acc1); GSB_MFMA(am, bm2, acc2); GSB_MFMA(am, bm3, acc3);   /* mid*mid */ \
     } else                                                                                            \
     {                                                                                                 \
         unsigned h0_, h1_, h2_, h3_, m0_, m1_, m2_, m3_, l0_, l1_, l2_, l3_;                          \
@@ -166,10 +186,10 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
 #define GSB_LDB(c_, set_) { const u32x4* bp_ = reinterpret_cast<const u32x4*>(Bs0 + ((size_t)(c_) * 3 * N + n0) * GSB_KC); \
                             const size_t ps_ = (size_t)N * GSB_KC / 8;                                                       \
                             pb[set_][0] = bp_[tid]; pb[set_][1] = bp_[tid + 256]; pb[set_][2] = bp_[ps_ + tid];              \
-                            pb[set_][3] = bp_[ps_ + tid + 256]; pb[set_][4] = bp_[2 * ps_ + tid]; pb[set_][5] = bp_[2 * ps_ + tid + 256]; }
+                            pb[set_][3] = bp_[ps_ + tid + 256]; if (!FOUR) { pb[set_][4] = bp_[2 * ps_ + tid]; pb[set_][5] = bp_[2 * ps_ + tid + 256]; } }
 #define GSB_STB(buf_, set_) { u32x4* d_ = reinterpret_cast<u32x4*>(Bl[buf_]);                                  \
                               d_[tid] = pb[set_][0]; d_[tid + 256] = pb[set_][1]; d_[512 + tid] = pb[set_][2]; \
-                              d_[512 + tid + 256] = pb[set_][3]; d_[1024 + tid] = pb[set_][4]; d_[1024 + tid + 256] = pb[set_][5]; }
+                              d_[512 + tid + 256] = pb[set_][3]; if (!FOUR) { d_[1024 + tid] = pb[set_][4]; d_[1024 + tid + 256] = pb[set_][5]; } }
         // chunk 0 of A and B came through the generic prologue (ca*, Bl[0]); request the rest
         GSB_LDB(1, 1)
         GSB_LDA(1) GSB_LDA(2) GSB_LDA(3)
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
 // M = 19200): K = 2 x 384, N = 128: 37 us against 52 us; K = 128, N = 2 x 384: 38 us against 35 us — the launcher
 // picks by the number of column groups.  (Prefetching three chunks ahead and placing the next chunk's split / LDS stores
 // in the MFMA gaps with sched_group_barrier were both measured slower than this plain form.)
-template <int NG, bool CONV = false, bool ONE = false>   // chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
+template <int NG, bool CONV = false, bool ONE = false, bool FOUR = false>   // FOUR: see gemm_sb_kernel; chunks of 32 k when known at compile time (fully unrolled, 3 chunks of loads in flight), 0: runtime loop
 __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict__ A0, const float* __restrict__ A1, int lda,
                                                          const unsigned short* __restrict__ Bs0,
                                                          const unsigned short* __restrict__ Bs1,
@@ -287,13 +307,19 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         na = *reinterpret_cast<const float4*>((h_ ? A1 : A0) + aoff + (size_t)gc_ * GSB_KC);                    \
         const u32x4* bp_ = reinterpret_cast<const u32x4*>((h_ ? Bs1 : Bs0) + ((size_t)gc_ * 3 * N + n0) * GSB_KC); \
         nb0 = bp_[(tid >> 9) * bplane + (tid & 511)];            /* planes 0 and 1 */                           \
-        nb1 = bp_[2 * bplane + (tid & 511)];                     /* plane 2: used by the first 512 threads */   \
+        if (!FOUR) nb1 = bp_[2 * bplane + (tid & 511)];          /* plane 2: used by the first 512 threads */   \
     }
 #define G16_COMMIT(buf_)                                                                                        \
     {                                                                                                           \
         unsigned short* ad_ = Al[buf_] + a_dst;                                                                 \
         if (ONE) {                                                                                              \
             *reinterpret_cast<uint2*>(ad_) = make_uint2(gsb_rne_pair(na.x, na.y), gsb_rne_pair(na.z, na.w));    \
+        } else if (FOUR) {                                                                                      \
+        unsigned h0_, m0_, h1_, m1_;                                                                            \
+        split2r_pair(na.x, na.y, h0_, m0_);                                                                     \
+        split2r_pair(na.z, na.w, h1_, m1_);                                                                     \
+        *reinterpret_cast<uint2*>(ad_) = make_uint2(h0_, h1_);                                                  \
+        *reinterpret_cast<uint2*>(ad_ + 128 * GSB_KC) = make_uint2(m0_, m1_);                                   \
         } else {                                                                                                \
         unsigned h0_, m0_, l0_, h1_, m1_, l1_;                                                                  \
         gsb_split3_pair(na.x, na.y, h0_, m0_, l0_);                                                             \
@@ -304,7 +330,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         }                                                                                                       \
         u32x4* bd_ = reinterpret_cast<u32x4*>(Bl[buf_]);                                                        \
         bd_[tid] = nb0;                                                                                         \
-        if (tid < 512) bd_[1024 + tid] = nb1;                                                                   \
+        if (!FOUR && tid < 512) bd_[1024 + tid] = nb1;                                                          \
     }
     G16_ISSUE(0)
     G16_COMMIT(0)
@@ -320,7 +346,11 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         const unsigned short* bp_ = bl + bofs + foff_;                                                          \
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_), bh = *reinterpret_cast<const bf16x8*>(bp_);    \
         GSB_MFMA(ah, bh, acc0);                                                                                 \
-        if (!ONE) {                                                                                             \
+        if (FOUR) {                                                                                             \
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap_ + 128 * GSB_KC);                                 \
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp_ + GSB_BN * GSB_KC);                              \
+        GSB_MFMA(ah, bm, acc1); GSB_MFMA(am, bh, acc0); GSB_MFMA(am, bm, acc1);                                 \
+        } else if (!ONE) {                                                                                      \
         const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap_ + 128 * GSB_KC),                                 \
                      al_ = *reinterpret_cast<const bf16x8*>(ap_ + 2 * 128 * GSB_KC);                            \
         const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp_ + GSB_BN * GSB_KC),                              \
@@ -412,6 +442,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
 }
 
 int g_gsb_dbg = 0;
+int g_gsb_four_now = 0;       // set for the duration of a backward launch (common.h BwdFourScope)
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
                    const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
                    int accum, int conv_C, int conv_H, int conv_W) {
@@ -431,6 +462,8 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     if (cvs ? false : (g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide) {
 #define GSB_GO(NG_) { if (g_mfma_one) hipLaunchKernelGGL((gemm_sb_kernel<NG_, true>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
                                        mode, g_gsb_dbg & 3, accum);                                                                                            \
+                      else if (g_gsb_four_now) hipLaunchKernelGGL((gemm_sb_kernel<NG_, false, true>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
+                                       mode, g_gsb_dbg & 3, accum);                                                                                            \
                       else hipLaunchKernelGGL((gemm_sb_kernel<NG_, false>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
                                        mode, g_gsb_dbg & 3, accum); }
         if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4)
@@ -438,21 +471,22 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
 #undef GSB_GO
     } else {
         const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
-#define G16_GO(NG_, CV_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
+#define G16_GO(NG_, CV_) { if (g_gsb_four_now) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W); \
+                           else hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W); }
 #define G16_GO1(NG_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
         // bf16 single-product mode: instantiated for the shapes of the headline model (the GRU input gradients, K = 128, and the generic loop);
         // the implicit-convolution and resnet50 shapes keep the exact products
         if (g_mfma_one && !cvs && !(g_gsb_dbg & 16) && (ng == 24 || ng == 4)) { if (ng == 24) G16_GO1(24); else G16_GO1(4); return 0; }
         if (g_mfma_one && !cvs && ng != 36 && ng != 16 && ng != 12 && ng != 8) { G16_GO1(0); return 0; }
-        if (cvs) { if (ng == 36) G16_GO(36, true); else if (ng == 72) G16_GO(72, true); else G16_GO(0, true); }      // implicit 3x3: K = 9 x 128 / 9 x 256 unrolled
-        else if (g_gsb_dbg & 16) G16_GO(0, false);
-        else if (ng == 36) G16_GO(36, false);       // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
-        else if (ng == 24) G16_GO(24, false);       // the GRU input gradients: K = 2 x 384
-        else if (ng == 16) G16_GO(16, false);       // ... its 1x1 products with K = 512
-        else if (ng == 12) G16_GO(12, false);
-        else if (ng == 8) G16_GO(8, false);
-        else if (ng == 4) G16_GO(4, false);
-        else G16_GO(0, false);
+        if (cvs) { if (ng == 36) G16_GO(36, true) else if (ng == 72) G16_GO(72, true) else G16_GO(0, true) }      // implicit 3x3: K = 9 x 128 / 9 x 256 unrolled
+        else if (g_gsb_dbg & 16) G16_GO(0, false)
+        else if (ng == 36) G16_GO(36, false)        // resnet50_block stage 2: the 3x3 product on im2col rows (K = 9 x 128)
+        else if (ng == 24) G16_GO(24, false)        // the GRU input gradients: K = 2 x 384
+        else if (ng == 16) G16_GO(16, false)        // ... its 1x1 products with K = 512
+        else if (ng == 12) G16_GO(12, false)
+        else if (ng == 8) G16_GO(8, false)
+        else if (ng == 4) G16_GO(4, false)
+        else G16_GO(0, false)
 #undef G16_GO
 #undef G16_GO1
     }

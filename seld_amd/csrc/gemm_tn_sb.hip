@@ -237,8 +237,13 @@ int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float
     splits = (M + rps - 1) / rps;
     TnJobs jobs = {};
     jobs.A[0] = A; jobs.B[0] = Bm; jobs.lda[0] = lda; jobs.shift[0] = 0;
-    if (cvs) hipLaunchKernelGGL(gemm_tn_sb_kernel<true>, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+    const bool four = g_bwd_four && !g_mfma_one;      // a kernel gradient: backward only
+    if (cvs && four) hipLaunchKernelGGL((gemm_tn_sb_kernel<true, false, true>), dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
                                 (long long)K1 * N, cvs, conv_H, conv_W);
+    else if (cvs) hipLaunchKernelGGL(gemm_tn_sb_kernel<true>, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+                                (long long)K1 * N, cvs, conv_H, conv_W);
+    else if (four) hipLaunchKernelGGL((gemm_tn_sb_kernel<false, false, true>), dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
+                            (long long)K1 * N, 0, 0, 0);
     else hipLaunchKernelGGL(gemm_tn_sb_kernel<false>, dim3(N / 128, K1 / 128, (unsigned)splits), dim3(256), 0, st, jobs, ldb, slab, M, N, rps, M, 0,
                             (long long)K1 * N, 0, 0, 0);
     *nslab = (int)splits;

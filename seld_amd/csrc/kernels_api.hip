@@ -41,6 +41,7 @@ int seld_k_set_option(const char* key, int value) {
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "bf16_single")) { g_mfma_one = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
+    if (!strcmp(key, "bwd_four_products")) { g_bwd_four = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { g_rn_split_bf16 = value != 0; return SELD_OK; }
     return SELD_ERR_INVALID;
 }
@@ -92,8 +93,11 @@ int seld_k_conv3x3_dgrad(const float* dz, const float* w, float* dx, int B, int 
     if (g_conv64_split_bf16) {
         unsigned short* wsp = reinterpret_cast<unsigned short*>(s.get(9 * 3 * 4096 / 2 + 16));
         if (!wsp) return SELD_ERR_NOMEM;
-        launch_split_weights(0, wt, wsp);
-        launch_conv64_fwd_sb(0, dz, wsp, nullptr, dx, nullptr, nullptr, B, H, W);
+        // the model's own route: the flipped planes straight from w (prep.h split_weights_body, flip = 1) and the input-gradient launcher, which takes
+        // the four-product form under option "bwd_four_products"
+        const float* ws[1] = {w}; unsigned short* ds[1] = {wsp}; const int fl[1] = {1};
+        launch_split_weights_batch(0, 1, ws, ds, fl);
+        launch_conv64_dgrad_sb(0, dz, wsp, dx, B, H, W);
     } else
         launch_conv64_fwd(0, dz, wt, nullptr, dx, nullptr, nullptr, B, H, W);
     return done();

@@ -26,7 +26,9 @@ __device__ __forceinline__ void gemm_split_b_body(const GemmSplitJobs& jobs, int
         // weights in both modes — it never reads an unwritten plane.
         const unsigned u = jobs.one ? bf16_rne_bits(x) << 16 : __float_as_uint(x) & 0xffff0000u;
         const float r = x - __uint_as_float(u);
-        const unsigned v = __float_as_uint(r);
+        // a transposed / flipped B is a backward operand: its mid plane is rounded (common.h split2r_pair) for the four-product form; plane 2 completes
+        // the split exactly either way
+        const unsigned v = __float_as_uint(r) + (transb ? 0x8000u : 0u);
         const float s = r - __uint_as_float(v & 0xffff0000u);
         const int c = k >> 5, kk = k & 31, piece = (kk >> 3) ^ ((n >> 2) & 3);
         unsigned short* o = dst + ((size_t)c * 3 * N + n) * 32 + piece * 8 + (kk & 7);

@@ -369,6 +369,7 @@ int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* 
 // wsp_t: the planes of w^T (launch_gemm_split_b with transb = 1, K' = N, N' = K)
 int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, const unsigned short* wsp_t, float* dA, int ldd, int M, int K, int N,
                             int accumulate) {
+    BwdFourScope four_;
     if (wsp_t && rn_sb_dgrad_ok(K, N) && gemm_sb_usable(dz, N, K, N))
         return launch_gemm_sb(st, dz, nullptr, N, wsp_t, nullptr, nullptr, nullptr, dA, nullptr, ldd, M, K, N, 0, 0, accumulate);
     return launch_gemm(st, dz, N, w, N, nullptr, dA, ldd, M, K, N, 1, 0, accumulate);
@@ -394,6 +395,7 @@ int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* 
 }
 // input gradient = the convolution of dz [.][N] with the flipped, channel-swapped kernel; wsp_flip: launch_gemm_split_b(w, ldb N, transb 2, K 9 N, N C)
 int launch_rn_conv3_dgrad(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dimg, int B, int H, int W, int C, int N) {
+    BwdFourScope four_;
     return launch_gemm_sb(st, dz, nullptr, N, wsp_flip, nullptr, nullptr, nullptr, dimg, nullptr, C, B * H * W, C, 9 * N, 0, 0, 0, N, H, W);
 }
 int launch_rn_conv3_wgrad(hipStream_t st, const float* img, const float* dz, float* slab, int64_t slab_cap, float* dw, int B, int H, int W, int C, int N) {

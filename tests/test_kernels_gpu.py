@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import check, dev, ptr, rel_err
+from helpers import REL_TOL, check, dev, ptr, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -50,12 +50,18 @@ def test_conv_dgrad(seld_lib, B, H, W):
     y = F.conv2d(x.permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
     (g,) = torch.autograd.grad(y, x, torch.as_tensor(dz, dtype=torch.float64))
     dzd, wd = dev(dz), dev(w)
-    for mode in (1, 0):
-        assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
-        dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
-        assert seld_lib.seld_k_conv3x3_dgrad(ptr(dzd), ptr(wd), ptr(dx), B, H, W, 64, 64) == 0
-        check(f"conv_dgrad {B,H,W} mode{mode}", dx.cpu().numpy(), g.numpy(), tol=2e-6)
-    seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
+    # mode 1 = split-bf16: the six-product form (fp32-level, 2e-6) and the four-product form backward products take by default (option
+    # "bwd_four_products": the two lo-factor terms dropped, a rounded mid plane; 2e-5 here, one decade inside the 1e-4 bar); mode 0 = the f32-input kernel
+    try:
+        for mode, four, tol in ((1, 0, 2e-6), (1, 1, 2e-5), (0, 0, 2e-6)):
+            assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
+            assert seld_lib.seld_k_set_option(b"bwd_four_products", four) == 0
+            dx = torch.full((B, H, W, 64), float("nan"), device="cuda")
+            assert seld_lib.seld_k_conv3x3_dgrad(ptr(dzd), ptr(wd), ptr(dx), B, H, W, 64, 64) == 0
+            check(f"conv_dgrad {B,H,W} mode{mode} four{four}", dx.cpu().numpy(), g.numpy(), tol=tol)
+    finally:
+        seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
+        seld_lib.seld_k_set_option(b"bwd_four_products", 1)
 
 
 @pytest.mark.parametrize("B,H,W,Cin", [(2, 50, 64, 7), (1, 7, 64, 7), (2, 30, 64, 10), (1, 9, 64, 10), (2, 20, 16, 64), (3, 10, 4, 64), (1, 37, 16, 64),
@@ -72,14 +78,17 @@ def test_conv_wgrad(seld_lib, B, H, W, Cin):
     db = torch.full((64,), float("nan"), device="cuda")
     xd, dzd = dev(x), dev(dz)
     # 64 -> 64: split-bf16 with transposed LDS reads (conv_wgrad_sb.hip, default) and the f32-input MFMA kernel
-    for mode in ((1, 0) if Cin == 64 else (1,)):
+    # (the split-bf16 kernel in both of its forms: six products, and the four the backward pass takes by default — option "bwd_four_products")
+    for mode, four in (((1, 1), (1, 0), (0, 0)) if Cin == 64 else ((1, 1),)):
         dw.fill_(float("nan")); db.fill_(float("nan"))
         assert seld_lib.seld_k_set_option(b"conv64_split_bf16", mode) == 0
+        assert seld_lib.seld_k_set_option(b"bwd_four_products", four) == 0
         try:
             assert seld_lib.seld_k_conv3x3_wgrad(ptr(xd), ptr(dzd), ptr(dw), ptr(db), B, H, W, Cin, 64) == 0
         finally:
             seld_lib.seld_k_set_option(b"conv64_split_bf16", 1)
-        check(f"conv_wgrad dw {B,H,W,Cin} mode{mode}", dw.cpu().numpy(), gw.numpy())
+            seld_lib.seld_k_set_option(b"bwd_four_products", 1)
+        check(f"conv_wgrad dw {B,H,W,Cin} mode{mode} four{four}", dw.cpu().numpy(), gw.numpy())
         check(f"conv_wgrad db {B,H,W,Cin} mode{mode}", db.cpu().numpy(), gb.numpy())
 
 
@@ -295,18 +304,20 @@ def test_gemm_tn(seld_lib, M, K1, N):
     cs = torch.full((N,), float("nan"), device="cuda")
     Ad, Bd = dev(A), dev(Bm)
     ref = A.astype(np.float64).T @ Bm.astype(np.float64)
-    for mode in (1, 0):
+    for mode, four in ((1, 1), (1, 0), (0, 0)):      # four: the split-bf16 kernel's four-product form (option "bwd_four_products", the default of a kernel gradient)
         assert seld_lib.seld_k_set_option(b"gemm_tn_split_bf16", mode) == 0
+        assert seld_lib.seld_k_set_option(b"bwd_four_products", four) == 0
         try:
             Cd.fill_(float("nan")); cs.fill_(float("nan"))
             assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), ptr(cs), M, K1, N) == 0
-            check(f"gemm_tn {M,K1,N} mode{mode}", Cd.cpu().numpy(), ref)
+            check(f"gemm_tn {M,K1,N} mode{mode} four{four}", Cd.cpu().numpy(), ref)
             check(f"gemm_tn colsum {M,K1,N} mode{mode}", cs.cpu().numpy(), Bm.astype(np.float64).sum(0))
             Cd.fill_(float("nan"))
             assert seld_lib.seld_k_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), None, M, K1, N) == 0
             check(f"gemm_tn (no colsum) {M,K1,N} mode{mode}", Cd.cpu().numpy(), ref)
         finally:
             seld_lib.seld_k_set_option(b"gemm_tn_split_bf16", 1)
+            seld_lib.seld_k_set_option(b"bwd_four_products", 1)
 
 
 def _gru_ref(gx, U, brec, reverse):
