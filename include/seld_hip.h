@@ -88,6 +88,13 @@ typedef struct seld_arch {
     float doa_dropout;
     /* 1 = models.seldnet_v1 (models.py:36-52; model_config/seldnet_v1.json): doa_out = tanh(doa * Concatenate([sed] * 3)). */
     int32_t output_coupling;
+    /* `dropout_rate` of the FIRST and SECOND blocks (0 in every shipped config), training only; masks drawn like the heads' (dropout_kernel).
+     * conv_dropout: simple_conv_block's Dropout(rate) behind every MaxPooling2D (model_config/seldnet.json:7; first_kind 0 only).
+     * gru_dropout: bidirectional_GRU_block passes it as BOTH `dropout` and `recurrent_dropout` of every GRU (modules.py:306, 312-314): per
+     * direction one input mask [B, in_feat] and one state mask [B, units], values 0 | 1/(1-rate), constant over the sequence (Keras GRUCell,
+     * implementation 2: the input is masked before the kernel product, the previous state before the recurrent product AND the blend). */
+    float conv_dropout;
+    float gru_dropout;
 } seld_arch;
 #define SELD_ACT_NONE 0
 #define SELD_ACT_SIGMOID 1

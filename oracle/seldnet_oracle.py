@@ -76,6 +76,8 @@ class Spec:
     doa_kernel_size: int = 1
     sed_dropout: float = 0.0           # simple_dense_block's dropout_rate (modules.py:357, 373-374), training only
     doa_dropout: float = 0.0
+    conv_dropout: float = 0.0          # simple_conv_block's dropout_rate (model_config/seldnet.json:7): Dropout behind every MaxPooling2D
+    gru_dropout: float = 0.0           # bidirectional_GRU_block's dropout_rate: GRU(dropout=rate, recurrent_dropout=rate) (modules.py:306, 312-314)
     output_coupling: bool = False      # models.seldnet_v1 (models.py:36-52): doa_out = tanh(doa * Concatenate([sed] * 3))
     dropout_seed: int = 0x5e1d5e1d5e1d5e1d   # the library's default (api.hip); option "dropout_seed" v -> 0x5e1d5e1d00000000 ^ v
 
@@ -102,6 +104,8 @@ class Spec:
         sp.doa_kernel_size = int(model_config["DOA_ARGS"].get("kernel_size", 1))
         sp.sed_dropout = float(model_config["SED_ARGS"].get("dropout_rate", 0))
         sp.doa_dropout = float(model_config["DOA_ARGS"].get("dropout_rate", 0))
+        sp.conv_dropout = float(model_config["FIRST_ARGS"].get("dropout_rate", 0) or 0) if sp.first == "simple_conv_block" else 0.0
+        sp.gru_dropout = float(model_config["SECOND_ARGS"].get("dropout_rate", 0) or 0)
         for a in (sp.sed_dense_act, sp.doa_dense_act):
             if a not in (None, "linear", "relu", "tanh", "sigmoid"):
                 raise ValueError(f"dense_activation {a!r} not restated")
@@ -297,16 +301,25 @@ def pool_windows(y, pool):
     return y.reshape(B, H // pt, pt, W // pf, pf, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // pt, W // pf, C, pt * pf)
 
 
-def gru_direction(x, kernel, rec_kernel, bias, reverse: bool, return_aux: bool = False):
+def gru_direction(x, kernel, rec_kernel, bias, reverse: bool, return_aux: bool = False, in_mask=None, rec_mask=None):
     """Keras GRU(units, reset_after=True, return_sequences=True) over [B,S,I] (modules.py:312-315).
-    reverse=True is Bidirectional's backward layer: consume time-reversed input, output re-reversed."""
+    reverse=True is Bidirectional's backward layer: consume time-reversed input, output re-reversed.
+    in_mask [B,I] / rec_mask [B,u] (training with dropout / recurrent_dropout > 0; values 0 | 1/(1-rate), one row per clip for the whole
+    sequence): Keras GRUCell.call, implementation 2 (the default) — `inputs = inputs * dp_mask[0]` before the kernel product and
+    `h_tm1 = h_tm1 * rec_dp_mask[0]` before the recurrent product; h_tm1 is REASSIGNED there, so the blend z * h_tm1 + (1 - z) * hh
+    sees the masked state too, while the emitted output (and the state handed to the next step, masked again there) is the unmasked h.
+    Restated from the published Keras source (tensorflow>=2.4.1, requirements.txt:2), which is not in the snapshot: unpinned."""
     B, S, _ = x.shape
     u = rec_kernel.shape[0]
+    if in_mask is not None:
+        x = x * in_mask[:, None, :]
     gx = x @ kernel + bias[0]  # [B,S,3u]
     h = x.new_zeros(B, u)
     outs = [None] * S
     order = range(S - 1, -1, -1) if reverse else range(S)
     for t in order:
+        if rec_mask is not None:
+            h = h * rec_mask
         gh = h @ rec_kernel + bias[1]
         z = torch.sigmoid(gx[:, t, :u] + gh[:, :u])
         r = torch.sigmoid(gx[:, t, u:2 * u] + gh[:, u:2 * u])
@@ -316,10 +329,12 @@ def gru_direction(x, kernel, rec_kernel, bias, reverse: bool, return_aux: bool =
     return torch.stack(outs, dim=1)
 
 
-def bigru_mul(x, w, prefix):
-    """Bidirectional(GRU, merge_mode='mul') (modules.py:311-316)."""
-    hf = gru_direction(x, w[f"{prefix}.fwd.kernel"], w[f"{prefix}.fwd.recurrent_kernel"], w[f"{prefix}.fwd.bias"], False)
-    hb = gru_direction(x, w[f"{prefix}.bwd.kernel"], w[f"{prefix}.bwd.recurrent_kernel"], w[f"{prefix}.bwd.bias"], True)
+def bigru_mul(x, w, prefix, masks=None):
+    """Bidirectional(GRU, merge_mode='mul') (modules.py:311-316).  masks = ((in_f, rec_f), (in_b, rec_b)): each direction is its own cell
+    with its own dropout draws."""
+    mf, mb = masks if masks is not None else ((None, None), (None, None))
+    hf = gru_direction(x, w[f"{prefix}.fwd.kernel"], w[f"{prefix}.fwd.recurrent_kernel"], w[f"{prefix}.fwd.bias"], False, in_mask=mf[0], rec_mask=mf[1])
+    hb = gru_direction(x, w[f"{prefix}.bwd.kernel"], w[f"{prefix}.bwd.recurrent_kernel"], w[f"{prefix}.bwd.bias"], True, in_mask=mb[0], rec_mask=mb[1])
     return hf * hb
 
 
@@ -346,6 +361,15 @@ def philox_uniform(n: int, seed: int, layer: int, step: int) -> np.ndarray:
     c = philox4x32_10(i, np.full(n4, layer, np.uint64), np.full(n4, step, np.uint64), i >> np.uint64(32), seed, seed >> 32)
     words = np.stack(c, axis=1).reshape(-1)[:n]
     return (words >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+
+
+def dropout_mask(shape, rate: float, seed: int, layer: int, step: int, dtype) -> torch.Tensor:
+    """Keras dropout mask from the library's draws: 0 where uniform < rate, 1 / (1 - rate) elsewhere (rate as the fp32 the library holds).
+    Draw streams (`layer`): heads 16 hd + j, simple_conv_block's Dropout behind pool i 64 + i, GRU layer i direction d input mask
+    96 + 4 i + d and state mask 98 + 4 i + d (api.hip forward_impl)."""
+    n = int(np.prod(shape))
+    u = philox_uniform(n, seed, layer, step).reshape(shape)
+    return torch.as_tensor((u >= np.float32(rate)).astype(np.float64) / (1.0 - float(np.float32(rate))), dtype=dtype)
 
 
 def conv1d_same(a, kernel, bias):
@@ -394,6 +418,8 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
         if taps is not None:
             taps[f"conv{i}.z"] = z
             taps[f"pool{i}"] = h
+        if training and spec.conv_dropout > 0 and spec.first == "simple_conv_block":      # Dropout(dropout_rate) behind the pool (seldnet.json:7)
+            h = h * dropout_mask(h.shape, spec.conv_dropout, spec.dropout_seed, 64 + i, dropout_step, h.dtype)
     if spec.first == "xception_block":
         # spec/XCEPTION_BLOCK.md: MIDDLE flow (residual modules of three ReLU -> SeparableConv2D -> BN) and EXIT (ReLU -> pool (1,8))
         C = h.shape[-1]
@@ -450,7 +476,12 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
     B, S = h.shape[0], h.shape[1]
     h = h.reshape(B, S, -1)  # layers.force_1d_inputs: feature index = f*C + c
     for i in range(len(spec.gru_units)):
-        h = bigru_mul(h, w, f"gru{i}")
+        masks = None
+        if training and spec.gru_dropout > 0:      # GRU(dropout=rate, recurrent_dropout=rate) (modules.py:312-314): per direction, per clip
+            masks = tuple((dropout_mask((B, h.shape[-1]), spec.gru_dropout, spec.dropout_seed, 96 + 4 * i + d, dropout_step, h.dtype),
+                           dropout_mask((B, spec.gru_units[i]), spec.gru_dropout, spec.dropout_seed, 98 + 4 * i + d, dropout_step, h.dtype))
+                          for d in range(2))
+        h = bigru_mul(h, w, f"gru{i}", masks)
         if taps is not None:
             taps[f"gru{i}"] = h
     outs = []
@@ -462,8 +493,7 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             # Conv1D(units, kernel_size, padding='same', activation=dense_activation) [+ Dropout] (modules.py:355-357, 368-374)
             a = hact(conv1d_same(a, w[f"{head}.dense{j}.kernel"], w[f"{head}.dense{j}.bias"]))
             if training and rate > 0:
-                u = philox_uniform(a.numel(), spec.dropout_seed, 16 * hd + j, dropout_step).reshape(a.shape)
-                a = a * torch.as_tensor((u >= np.float32(rate)).astype(np.float64) / (1.0 - float(np.float32(rate))), dtype=a.dtype)
+                a = a * dropout_mask(a.shape, rate, spec.dropout_seed, 16 * hd + j, dropout_step, a.dtype)
         outs.append(act(a @ w[f"{head}.out.kernel"] + w[f"{head}.out.bias"]))
     if spec.output_coupling:                     # models.seldnet_v1 (models.py:48-50)
         outs[1] = torch.tanh(outs[1] * torch.cat([outs[0]] * 3, dim=-1))

@@ -44,7 +44,8 @@ class Arch(C.Structure):
                 ("first_kind", C.c_int32), ("xc_blocks", C.c_int32), ("rn_filters", C.c_int32), ("rn_blocks", C.c_int32 * 4),
                 ("sed_dense_act", C.c_int32), ("doa_dense_act", C.c_int32),
                 ("sed_kernel_size", C.c_int32), ("doa_kernel_size", C.c_int32), ("sed_dropout", C.c_float), ("doa_dropout", C.c_float),
-                ("output_coupling", C.c_int32)]
+                ("output_coupling", C.c_int32),
+                ("conv_dropout", C.c_float), ("gru_dropout", C.c_float)]
 
 
 class LossCfg(C.Structure):

@@ -23,6 +23,7 @@ struct ConvL {
     int64_t w_off, b_off, g_off, be_off;   // trainable offsets
     int64_t mm_off, mv_off;           // state offsets
     float *z = nullptr, *p = nullptr, *dp = nullptr;
+    float* pd = nullptr;              // seld_arch.conv_dropout > 0: the block's output after Dropout (p stays the pooled tensor the backward reads)
     unsigned char* amax = nullptr;    // first block only: position of each pooling window's extreme [B,H/pt,W/pf,64]
     float* zext = nullptr;            // first block only: the windows' extreme z (kept next to p for the z-free backward)
     float *mean, *invstd, *scale, *shift, *c1c2;   // into small buffer
@@ -32,6 +33,10 @@ struct GruL {
     int in_feat;
     int64_t k_off[2], u_off[2], b_off[2];
     float *gx[2], *sv[2], *h[2], *out, *din;   // din: gradient w.r.t. this layer's input
+    // seld_arch.gru_dropout > 0 (training): per direction the input mask [B][in_feat] and the state mask [B][128] (0 | 1/(1-rate)), the masked
+    // input rows xm [rows][in_feat] (the kernel product's and the kernel gradient's operand), the masked state sequence hm [rows][128]
+    // (h_prev of the backward pass and the recurrent-kernel gradient's operand); dtmp: the second direction's input gradient before its mask
+    float *imask[2] = {}, *rmask[2] = {}, *xm[2] = {}, *hm[2] = {}, *dtmp = nullptr;
 };
 
 struct DenseL {
@@ -147,6 +152,7 @@ struct seld_ctx {
     float *dsed_pre = nullptr, *ddoa_pre = nullptr, *sed_int = nullptr, *doa_int = nullptr;
     float *doa_v1 = nullptr;                   // models.seldnet_v1 (models.py:36-52): tanh(doa * [sed | sed | sed]), the prediction the losses see
     float *head_tmp = nullptr;                 // [rows][max ks * in_base]: a Conv1D head layer's input gradient before it is folded back over the taps
+    float* ones = nullptr;    // [B * 2048] of 1.0: the GRU dropout masks are launch_dropout of it
     uint64_t dropout_seed = 0x5e1d5e1d5e1d5e1dull; unsigned dropout_step = 0, dropout_cur = 0; int last_training = 0;   // dropout_cur: the counter the LAST training forward drew its masks with (its backward recomputes them)
     float *loss_scratch = nullptr, *den_dev = nullptr, *loss_out = nullptr;
     float *fin_sl = nullptr, *fin_dl = nullptr;   // deferred loss finalize of the running training step
@@ -289,6 +295,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     if (a->n_classes <= 0) return fail(nullptr, SELD_ERR_INVALID, "n_classes must be positive");
     const bool xcep = a->first_kind == SELD_FIRST_XCEPTION, resn = a->first_kind == SELD_FIRST_RESNET50;
     if (a->first_kind != SELD_FIRST_SIMPLE_CONV && !xcep && !resn) return fail(nullptr, SELD_ERR_UNSUPPORTED, "unknown FIRST block kind");
+    if (!(a->conv_dropout >= 0.f && a->conv_dropout < 1.f) || !(a->gru_dropout >= 0.f && a->gru_dropout < 1.f))
+        return fail(nullptr, SELD_ERR_INVALID, "conv_dropout / gru_dropout: 0 <= rate < 1");
+    if (a->conv_dropout > 0.f && a->first_kind != SELD_FIRST_SIMPLE_CONV)
+        return fail(nullptr, SELD_ERR_UNSUPPORTED, "conv_dropout: simple_conv_block only (the other FIRST blocks' specs have no Dropout)");
     if (resn) {
         if (a->n_conv != 1 || a->pool_t[0] != 5 || a->pool_f[0] != 4 || a->rn_filters != 32)
             return fail(nullptr, SELD_ERR_UNSUPPORTED, "resnet50_block: one entry conv2d_bn(64) with pool (5,4), filters 32 (spec/RESNET50_BLOCK.md)");
@@ -436,6 +446,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         const size_t nz = (size_t)B * L.H * L.W * 64;
         const size_t np = (size_t)B * (L.H / L.pt) * (L.W / L.pf) * 64;
         ALLOC(L.z, nz); ALLOC(L.p, np); ALLOC(L.dp, np);
+        if (a->conv_dropout > 0.f) ALLOC(L.pd, np);
         if (i == 0) { float* am = nullptr; ALLOC(am, (np + 3) / 4); L.amax = reinterpret_cast<unsigned char*>(am); ALLOC(L.zext, np); }
         if (nz > zmax) zmax = nz;
         float* sm = c->small + (size_t)i * 64 * 6;
@@ -520,6 +531,14 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         GruL& G = c->gru[i];
         for (int d = 0; d < 2; ++d) { ALLOC(G.gx[d], rows * 384); ALLOC(G.sv[d], rows * 512); ALLOC(G.h[d], rows * 128); }
         ALLOC(G.out, rows * 128); ALLOC(G.din, rows * (size_t)G.in_feat);
+        if (a->gru_dropout > 0.f) {
+            for (int d = 0; d < 2; ++d) {
+                ALLOC(G.imask[d], (size_t)B * G.in_feat); ALLOC(G.rmask[d], (size_t)B * 128);
+                ALLOC(G.xm[d], rows * (size_t)G.in_feat); ALLOC(G.hm[d], rows * 128);
+            }
+            ALLOC(G.dtmp, rows * (size_t)G.in_feat);
+            if (!c->ones) { ALLOC(c->ones, (size_t)B * 2048); launch_fill(0, c->ones, (int64_t)B * 2048, 1.f); }
+        }
     }
     ALLOC(c->feat_grad, rows * 128);
     for (int i = 0; i < a->n_gru; ++i)
@@ -789,6 +808,10 @@ static int heads_couple(seld_ctx* c, float* doa, int rows) {
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
     g_mfma_one = c->bf16_single;      // process-wide kernel choice, read by the launchers this pass calls (common.h)
+    c->last_training = training;
+    if (training) c->dropout_cur = c->dropout_step++;      // every training forward draws new masks (Keras), backward or not
+    const bool conv_drop = training && c->arch.conv_dropout > 0.f, gru_drop = training && c->arch.gru_dropout > 0.f;
+    if (gru_drop && !save) return fail(c, SELD_ERR_UNSUPPORTED, "gru_dropout: a training forward without saved gates");
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
     const int rows = B * S;
@@ -902,6 +925,10 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
         }
         in = L.p;
+        if (conv_drop) {      // Dropout behind the pool (stream 64 + i); the backward masks the gradient arriving at this block with the same draws
+            launch_dropout(st, L.p, L.pd, (int64_t)B * (L.H / L.pt) * (L.W / L.pf) * 64, c->arch.conv_dropout, c->dropout_seed, 64u + (unsigned)i, c->dropout_cur);
+            in = L.pd;
+        }
     }
     if (c->arch.first_kind == SELD_FIRST_XCEPTION) {
         // ---- xception_block middle flow + exit (spec/XCEPTION_BLOCK.md) on [B,S,16,64]
@@ -1051,6 +1078,25 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
     for (size_t i = 0; i < c->gru.size(); ++i) {
         GruL& G = c->gru[i];
+        if (gru_drop) {
+            // Keras GRU dropout / recurrent_dropout (modules.py:312-314): each direction's cell draws its own input mask (stream 96 + 4 i + d) and
+            // state mask (98 + 4 i + d); the directions no longer share their input rows, so the projections are two products
+            PROF(c, "gru_fwd");
+            const float rate = c->arch.gru_dropout;
+            for (int d = 0; d < 2; ++d) {
+                launch_dropout(st, c->ones, G.imask[d], (int64_t)B * G.in_feat, rate, c->dropout_seed, 96u + 4u * (unsigned)i + d, c->dropout_cur);
+                launch_dropout(st, c->ones, G.rmask[d], (int64_t)B * 128, rate, c->dropout_seed, 98u + 4u * (unsigned)i + d, c->dropout_cur);
+                launch_mask_rows(st, feat, G.imask[d], G.xm[d], rows, S, G.in_feat, 0);
+                if (gru_sb(c, G) && gemm_sb_usable(G.xm[d], G.in_feat, 384, G.in_feat))
+                    launch_gemm_sb(st, G.xm[d], nullptr, G.in_feat, c->ksp_fwd[i][d], nullptr, c->params + G.b_off[d], nullptr, G.gx[d], nullptr, 384, rows, 384,
+                                   G.in_feat, 0, 0);
+                else
+                    launch_gemm(st, G.xm[d], G.in_feat, c->params + G.k_off[d], 384, c->params + G.b_off[d], G.gx[d], 384, rows, 384, G.in_feat, 0, 0, 0);
+            }
+            if (launch_gru_fwd(st, G.gx[0], G.gx[1], c->params + G.u_off[0], c->params + G.u_off[1], c->params + G.b_off[0] + 384,
+                               c->params + G.b_off[1] + 384, G.h[0], G.h[1], G.sv[0], G.sv[1], B, S, G.rmask[0], G.rmask[1], G.hm[0], G.hm[1]))
+                return fail(c, SELD_ERR_UNSUPPORTED, "gru_fwd (dropout)");
+        } else {
         {
             PROF2(c, "gru_inproj_gemm");
             // both directions' projections of the same input in one launch
@@ -1067,6 +1113,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             launch_gru_fwd(st, G.gx[0], G.gx[1], c->params + G.u_off[0], c->params + G.u_off[1], c->params + G.b_off[0] + 384,
                            c->params + G.b_off[1] + 384, G.h[0], G.h[1], save ? G.sv[0] : nullptr, save ? G.sv[1] : nullptr, B, S);
         }
+        }
+        if (i == 0 && c->gram_active && gru_drop) fork_side(c);
         if (i == 0 && c->gram_active) {
             // Gram matrix of the input patches (conv_gram.hip): depends on x alone -> side stream, under the GRU
             // recurrences (2B of the 256 CUs): eligible when the first GRU kernel is (fork event recorded in front of it) but
@@ -1086,8 +1134,6 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // the first layers of the two heads read the same features: one launch when their shapes agree (seldnet.json:
         // Conv1D(128) in both) and neither is the head's output layer
         DenseL &S0 = c->heads[0].layers[0], &D0 = c->heads[1].layers[0];
-        c->last_training = training;
-        if (training) c->dropout_cur = c->dropout_step++;      // every training forward draws new masks (Keras), backward or not
         if (heads_lin(c)) {
             DenseL &S1 = c->heads[0].layers[1], &D1 = c->heads[1].layers[1];
             const int nt = S1.out + D1.out;
@@ -1385,9 +1431,15 @@ static int backward_impl(seld_ctx* c, const float* x) {
     const float* dout = c->feat_grad;
     for (int i = (int)c->gru.size() - 1; i >= 0; --i) {
         GruL& G = c->gru[i];
-        const float* lin = i == 0 ? (c->arch.first_kind == SELD_FIRST_XCEPTION ? c->xc_feat : (c->arch.first_kind == SELD_FIRST_RESNET50 ? c->rn.back().out : c->conv.back().p)) : c->gru[i - 1].out;
+        const bool conv_drop = c->last_training && c->arch.conv_dropout > 0.f, gru_drop = c->last_training && c->arch.gru_dropout > 0.f;
+        const float* lin = i == 0 ? (c->arch.first_kind == SELD_FIRST_XCEPTION ? c->xc_feat : (c->arch.first_kind == SELD_FIRST_RESNET50 ? c->rn.back().out : (conv_drop ? c->conv.back().pd : c->conv.back().p))) : c->gru[i - 1].out;
         {
             PROF(c, "gru_bwd");
+            if (gru_drop) {
+                if (launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
+                                   c->dgx[i][1], c->dgh[i][0], c->dgh[i][1], B, S, G.rmask[0], G.rmask[1], G.hm[0], G.hm[1]))
+                    return fail(c, SELD_ERR_UNSUPPORTED, "gru_bwd (dropout)");
+            } else
             launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
                            c->dgx[i][1], c->dgh[i][0], c->dgh[i][1], B, S);
         }
@@ -1398,9 +1450,9 @@ static int backward_impl(seld_ctx* c, const float* x) {
         for (int d = 0; d < 2; ++d) {
             // kernel + input bias (bias row 0); recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction
             // h[t+1]) + bias row 1
-            tj.A[2 * d] = lin; tj.lda[2 * d] = G.in_feat; tj.B[2 * d] = c->dgx[i][d]; tj.shift[2 * d] = 0;
+            tj.A[2 * d] = gru_drop ? G.xm[d] : lin; tj.lda[2 * d] = G.in_feat; tj.B[2 * d] = c->dgx[i][d]; tj.shift[2 * d] = 0;
             tj.out_w[2 * d] = c->grads + G.k_off[d]; tj.out_b[2 * d] = c->grads + G.b_off[d];
-            tj.A[2 * d + 1] = G.h[d]; tj.lda[2 * d + 1] = 128; tj.B[2 * d + 1] = c->dgh[i][d]; tj.shift[2 * d + 1] = d == 0 ? -1 : 1;
+            tj.A[2 * d + 1] = gru_drop ? G.hm[d] : G.h[d]; tj.lda[2 * d + 1] = 128; tj.B[2 * d + 1] = c->dgh[i][d]; tj.shift[2 * d + 1] = d == 0 ? -1 : 1;
             tj.out_w[2 * d + 1] = c->grads + G.u_off[d]; tj.out_b[2 * d + 1] = c->grads + G.b_off[d] + 384;
         }
         int ns4 = 0;
@@ -1415,7 +1467,17 @@ static int backward_impl(seld_ctx* c, const float* x) {
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
-            if (gru_sb(c, G)) {
+            if (gru_drop) {      // din = (dgx_f K_f^T) * imask_f + (dgx_b K_b^T) * imask_b: each direction's input rows had their own mask
+                for (int d = 0; d < 2; ++d) {
+                    float* t_ = d == 0 ? G.din : G.dtmp;
+                    if (gru_sb(c, G)) {
+                        BwdFourScope four_;
+                        launch_gemm_sb(st, c->dgx[i][d], nullptr, 384, c->ksp_bwd[i][d], nullptr, nullptr, nullptr, t_, nullptr, G.in_feat, rows, G.in_feat, 384, 0, 0);
+                    } else
+                        launch_gemm(st, c->dgx[i][d], 384, c->params + G.k_off[d], 384, nullptr, t_, G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
+                    launch_mask_rows(st, t_, G.imask[d], G.din, rows, S, G.in_feat, d);
+                }
+            } else if (gru_sb(c, G)) {
                 BwdFourScope four_;
                 launch_gemm_sb(st, c->dgx[i][0], c->dgx[i][1], 384, c->ksp_bwd[i][0], c->ksp_bwd[i][1], nullptr, nullptr, G.din, nullptr,
                                G.in_feat, rows, G.in_feat, 384, 0, 2);
@@ -1427,6 +1489,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
     }
     // ---- conv blocks, last to first.  dout = gradient w.r.t. the last pooled output
     const float* dp = dout;
+    const bool conv_drop = c->last_training && c->arch.conv_dropout > 0.f;
     if (c->arch.first_kind == SELD_FIRST_RESNET50) {
         // ---- resnet50_block backward, blocks last to first; g = gradient w.r.t. the block's output
         PROF(c, "rn_stages_bwd");
@@ -1607,6 +1670,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
         int np = 0;
         char tn[32];
         snprintf(tn, sizeof tn, "pool%d_bwd_reduce", i + 1);
+        if (conv_drop) {      // through this block's Dropout: the forward's draws again (in place: dp is a buffer of this context)
+            float* g_ = const_cast<float*>(dp);
+            launch_dropout(st, g_, g_, (int64_t)B * (L.H / L.pt) * (L.W / L.pf) * 64, c->arch.conv_dropout, c->dropout_seed, 64u + (unsigned)i, c->dropout_cur);
+        }
         {
             PROF2(c, tn);
             const bool gz = i == 0 && c->gram_active;      // no z: the windows' extreme values stand in
@@ -1651,7 +1718,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_reduce_slabs(st, c->wgrad_slab, ns, conv_first_wgrad_slab_stride(L.Cin), c->grads + L.w_off,
                                 (int64_t)(9 * L.Cin + 1) * 64, 0);
         } else {
-            const float* lin = c->conv[i - 1].p;
+            const float* lin = conv_drop ? c->conv[i - 1].pd : c->conv[i - 1].p;
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
             {
                 PROF2(c, tn);

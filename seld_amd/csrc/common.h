@@ -295,10 +295,11 @@ int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nsla
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
-                   int B, int S);
+                   int B, int S, const float* rm_f = nullptr, const float* rm_b = nullptr, float* hm_f = nullptr, float* hm_b = nullptr);
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
-                   float* dgh_f, float* dgh_b, int B, int S);
+                   float* dgh_f, float* dgh_b, int B, int S, const float* rm_f = nullptr, const float* rm_b = nullptr, const float* hm_f = nullptr,
+                   const float* hm_b = nullptr);
 int gru_timing_read(int which, unsigned long long* out, int blocks);
 int launch_mul(hipStream_t st, const float* a, const float* b, float* out, int64_t n);
 
@@ -308,6 +309,9 @@ int launch_act_bwd(hipStream_t st, const float* y, float* dy, int64_t n, int act
 int launch_time_expand(hipStream_t st, const float* x, float* xe, int B, int S, int C, int ks);
 int launch_time_fold(hipStream_t st, const float* dxe, float* dx, int B, int S, int C, int ks, int accumulate);
 int launch_dropout(hipStream_t st, const float* in, float* out, int64_t n, float rate, uint64_t seed, unsigned layer, unsigned step);
+// a per-clip mask over the feature axis, constant over the clip's S rows (Keras GRU dropout masks): out[r][f] (+)= in[r][f] * mask[r / S][f]; F % 4 == 0
+int launch_mask_rows(hipStream_t st, const float* in, const float* mask, float* out, int64_t rows, int S, int F, int accumulate);
+int launch_fill(hipStream_t st, float* out, int64_t n, float v);
 // loss_adam.hip: models.seldnet_v1's output coupling tanh(doa * [sed | sed | sed]) and its gradient (in place on the losses' gradients)
 int launch_v1_couple_fwd(hipStream_t st, const float* sed, const float* doa1, float* out, float* out2, int rows, int nc);
 int launch_v1_couple_bwd(hipStream_t st, const float* sed, const float* doa1, float* dsed_pre, int ld_sed, float* ddoa_pre, int ld_doa, int rows, int nc);

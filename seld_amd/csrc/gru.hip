@@ -101,12 +101,18 @@ __device__ __forceinline__ float quad_sum(float v) {
 //     among the candidate gate's 16 packed FMAs (two sub-chains), instead of every gate finishing together behind the last FMA;
 //   * log2(e) factors folded into fma operands: sigmoid = rcp(1 + exp2(fma(s, -log2e, pre))), tanh through exp2(fma(r', gh, gx')),
 //     and the blend is ONE fma behind the last rcp: h' = fma(-2(1-z), rc, z h + (1-z)).
-template <int VAR, bool SAVE, bool PRIO = false>
+// DROP (Keras GRU recurrent_dropout, modules.py:312-314; training only): the cell's previous state is multiplied by a per-(clip, unit) mask
+// rm = 0 | 1 / (1 - rate), constant over the sequence, before it is used — GRUCell.call, implementation 2: `h_tm1 = h_tm1 * rec_dp_mask[0]`
+// ahead of the recurrent product AND of the blend z * h_tm1 + (1 - z) * hh.  The layer's output stays the unmasked h (stored to H);
+// the masked state is what the exchange buffer / h_own carry and, for the backward pass, what HM receives.
+template <int VAR, bool SAVE, bool PRIO = false, bool DROP = false>
 __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_b,
                                                       const float* __restrict__ U_f, const float* __restrict__ U_b,
                                                       const float* __restrict__ brec_f, const float* __restrict__ brec_b,
                                                       float* __restrict__ h_f, float* __restrict__ h_b,
-                                                      float* __restrict__ sv_f, float* __restrict__ sv_b, int S) {
+                                                      float* __restrict__ sv_f, float* __restrict__ sv_b, int S,
+                                                      const float* __restrict__ rm_f = nullptr, const float* __restrict__ rm_b = nullptr,
+                                                      float* __restrict__ hm_f = nullptr, float* __restrict__ hm_b = nullptr) {
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* gx = (dir ? gx_b : gx_f) + (size_t)b * S * GRU_G;
     const float* U = dir ? U_b : U_f;
@@ -115,6 +121,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     float* sv = dir ? sv_b : sv_f;
     if (sv) sv += (size_t)b * S * 4 * GRU_U;
     const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    float mk = 1.f;
+    float* HM = nullptr;
+    if constexpr (DROP) { mk = (dir ? rm_b : rm_f)[b * GRU_U + j]; HM = (dir ? hm_b : hm_f) + (size_t)b * S * GRU_U; }
     __shared__ __attribute__((aligned(16))) float gxl[2][GRUF_CH * GRU_G];
     // padded h vector: index k lives at k + 4*(k>>5) so the 4 quarters start in different bank groups
     __shared__ __attribute__((aligned(16))) float hl[2][144];
@@ -212,11 +221,12 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const float ghh = ah + bh;
             const float hh = tanh_(gxh + r * ghh);
             const float hn = fmaf(z, h_own - hh, hh);      // z h + (1 - z) hh
-            h_own = hn;
+            h_own = DROP ? hn * mk : hn;
             GRU_TR(0, 2)
             if (q == 0) {
-                hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
+                hl[(step + 1) & 1][j + 4 * (j >> 5)] = h_own;
                 H[(size_t)t * GRU_U + j] = hn;
+                if constexpr (DROP) HM[(size_t)t * GRU_U + j] = h_own;
             }
             if (sv) {
                 // lane q of a quad saves gate q (z | r | hh | gh).  Even lanes finished z and odd lanes r in `sg` itself, so lanes 0 / 1
@@ -289,15 +299,16 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             const float ghh = quad_sum(ah2.x + ah2.y) + bh;
             const float rc = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(r2, ghh, gxh2)));
             const float hn = fmaf(bb, rc, ba);      // z h + (1 - z) (1 - 2 rc)
-            h_own = hn;
+            h_own = DROP ? hn * mk : hn;
 #ifdef GRU_TRACE2
             __builtin_amdgcn_sched_barrier(0);
             TR2(3)
 #endif
             // all four lanes of a quad hold the same hn and store it to the same word (LDS: a same-address 4-way write costs at most 4
             // array cycles; memory: one dword per quad either way): no exec-mask region, the step body stays ONE basic block
-            hl[(step + 1) & 1][j + 4 * (j >> 5)] = hn;
+            hl[(step + 1) & 1][j + 4 * (j >> 5)] = h_own;
             __builtin_amdgcn_sched_barrier(0);      // the exchange write leaves first; output stores and the next step's input terms follow
+            if constexpr (DROP) *reinterpret_cast<float*>(reinterpret_cast<char*>(HM) + ((unsigned)t * (GRU_U * 4u) + h_off)) = h_own;
             // uniform row base + 32-bit lane offset: the stores take the SGPR-base form, no 64-bit vector address arithmetic per step
             *reinterpret_cast<float*>(reinterpret_cast<char*>(H) + ((unsigned)t * (GRU_U * 4u) + h_off)) = hn;
             if (prefetch) load_gx(i + 1);
@@ -342,7 +353,13 @@ int g_gru_var = 11;     // kernel choice (process-wide, option "gru_var"): bit 0
 
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
-                   int B, int S) {
+                   int B, int S, const float* rm_f, const float* rm_b, float* hm_f, float* hm_b) {
+    if (rm_f) {      // recurrent dropout (training: the gates are saved): masks rm [B][128] per direction, masked state sequences hm [B][S][128]
+        if (!rm_b || !hm_f || !hm_b || !sv_f) return -1;
+        hipLaunchKernelGGL((gru_fwd_kernel<1, true, false, true>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S,
+                           rm_f, rm_b, hm_f, hm_b);
+        return 0;
+    }
 #define GRUF_GO(V_, SV_) hipLaunchKernelGGL((gru_fwd_kernel<V_, SV_>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S)
     const bool save = sv_f != nullptr;
     if ((g_gru_var & 9) == 9) {
@@ -380,16 +397,20 @@ __device__ __forceinline__ float row16_allsum(float v) {
 // up owning and the fold over the quad is three DPP adds with NO per-lane selects (VAR 0: six v_cndmask on the carry's critical path);
 // (b) the idle quarter of the lanes (role 3) repeats role 0's gate gradient — same value, same address — so the gate stage has no exec-mask
 // region and the step is one basic block; (c) the exchange write is pinned ahead of the output stores.
-template <int VAR, bool PRIO = false>
+// DROP (see gru_fwd_kernel): h_prev is the MASKED state sequence (hm_*, written by the forward), and the gradient carried to the previous step
+// is the gradient w.r.t. that masked state times the mask: carry = rm * (dh z + dgh U^T); h_other (the merge partner) stays the unmasked output
+template <int VAR, bool PRIO = false, bool DROP = false>
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ h_f,
                                                       const float* __restrict__ h_b, const float* __restrict__ sv_f,
                                                       const float* __restrict__ sv_b, const float* __restrict__ U_f,
                                                       const float* __restrict__ U_b, float* __restrict__ dgx_f,
                                                       float* __restrict__ dgx_b, float* __restrict__ dgh_f,
-                                                      float* __restrict__ dgh_b, int S) {
+                                                      float* __restrict__ dgh_b, int S,
+                                                      const float* __restrict__ rm_f = nullptr, const float* __restrict__ rm_b = nullptr,
+                                                      const float* __restrict__ hm_f = nullptr, const float* __restrict__ hm_b = nullptr) {
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* dO = dout + (size_t)b * S * GRU_U;
-    const float* Hown = (dir ? h_b : h_f) + (size_t)b * S * GRU_U;
+    const float* Hown = (DROP ? (dir ? hm_b : hm_f) : (dir ? h_b : h_f)) + (size_t)b * S * GRU_U;
     const float* Hoth = (dir ? h_f : h_b) + (size_t)b * S * GRU_U;
     const float* sv = (dir ? sv_b : sv_f) + (size_t)b * S * 4 * GRU_U;
     const float* U = dir ? U_b : U_f;
@@ -399,6 +420,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const int cp = lane & 15;                       // column part of the mat-vec
     const int j0 = 4 * (4 * wave + (lane >> 4));    // first of this lane's 4 outputs
     const int jm = j0 + (cp & 3), qr = cp >> 2;     // unit / role (z, r, h, -) of this lane in the gate stage
+    float mk = 1.f;
+    if constexpr (DROP) mk = (dir ? rm_b : rm_f)[b * GRU_U + jm];
     const bool b0 = cp & 1, b1 = cp & 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* stage = smem;                          // [2][GRUB_CH][GRUB_ROW]
@@ -568,6 +591,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
                 mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
                 carry = dh * c_zs + mine;
+                if constexpr (DROP) carry *= mk;
 #ifdef GRU_TRACE2
                 __builtin_amdgcn_sched_barrier(0);
                 TR2(4)
@@ -583,6 +607,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x128 /*row_ror:8*/, 0xF, 0xF, true));
             mine += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x124 /*row_ror:4*/, 0xF, 0xF, true));
             carry = dh * c_zs + mine;
+            if constexpr (DROP) carry *= mk;
             ++step;
         };
         for (int i = 0; i < n - 1; ++i) {
@@ -636,12 +661,19 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
 
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
-                   float* dgh_f, float* dgh_b, int B, int S) {
+                   float* dgh_f, float* dgh_b, int B, int S, const float* rm_f, const float* rm_b, const float* hm_f, const float* hm_b) {
     const size_t smem = (size_t)(2 * GRUB_CH * GRUB_ROW + 2 * GRUB_GL) * sizeof(float);
+    if (rm_f) {      // recurrent dropout: see gru_fwd_kernel
+        if (!rm_b || !hm_f || !hm_b) return -1;
+        auto kd = gru_bwd_kernel<1, false, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kd, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b, dgh_f, dgh_b, S, rm_f, rm_b, hm_f, hm_b);
+        return 0;
+    }
     auto kern = (g_gru_var & 2) ? ((g_gru_var & 8) ? gru_bwd_kernel<1, true> : gru_bwd_kernel<1, false>) : gru_bwd_kernel<0, false>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(2 * B), dim3(512), smem, st, dout, h_f, h_b, sv_f, sv_b, U_f, U_b, dgx_f, dgx_b,
-                       dgh_f, dgh_b, S);
+                       dgh_f, dgh_b, S, nullptr, nullptr, nullptr, nullptr);
     return 0;
 }
 

@@ -380,3 +380,32 @@ int launch_dropout(hipStream_t st, const float* in, float* out, int64_t n, float
                        reinterpret_cast<float4*>(out), n4, rate, 1.f / (1.f - rate), (unsigned)seed, (unsigned)(seed >> 32), layer, step);
     return 0;
 }
+
+// ---- Keras GRU dropout masks (modules.py:312-314): one mask row per clip, the same for every step of the sequence
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float4* __restrict__ in, const float4* __restrict__ mask, float4* __restrict__ out, int64_t n4, int S,
+                                                        int F4, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t r = i / F4;
+    const int f = (int)(i - r * F4);
+    const float4 v = in[i], m = mask[(r / S) * F4 + f];
+    float4 o = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+    if (accumulate) { const float4 p = out[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    out[i] = o;
+}
+int launch_mask_rows(hipStream_t st, const float* in, const float* mask, float* out, int64_t rows, int S, int F, int accumulate) {
+    if ((F & 3) || rows <= 0 || S <= 0) return -1;
+    const int64_t n4 = rows * (F / 4);
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(in),
+                       reinterpret_cast<const float4*>(mask), reinterpret_cast<float4*>(out), n4, S, F / 4, accumulate);
+    return 0;
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ out, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+int launch_fill(hipStream_t st, float* out, int64_t n, float v) {
+    if (n <= 0) return -1;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, v);
+    return 0;
+}

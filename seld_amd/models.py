@@ -63,8 +63,14 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int, output_coupli
         filters, pools = list(fa["filters"]), [tuple(p) for p in fa["pool_size"]]
     if len(filters) != len(pools):
         raise ValueError("filters and pool_size must have the same length")
-    if fa.get("dropout_rate", 0.0) or model_config["SECOND_ARGS"].get("dropout_rate", 0.0):
-        raise ValueError("dropout_rate > 0 has no kernel (seldnet.json uses 0.0)")
+    # dropout_rate of the FIRST / SECOND blocks (0.0 in every shipped config): simple_conv_block's Dropout behind each pool; Keras GRU
+    # dropout = recurrent_dropout = rate (modules.py:306, 312-314).  The other FIRST blocks' specs have no Dropout: refuse instead of ignoring.
+    conv_dropout, gru_dropout = float(fa.get("dropout_rate", 0.0) or 0.0), float(model_config["SECOND_ARGS"].get("dropout_rate", 0.0) or 0.0)
+    for name, r in (("FIRST_ARGS", conv_dropout), ("SECOND_ARGS", gru_dropout)):
+        if not 0.0 <= r < 1.0:
+            raise ValueError(f"{name}['dropout_rate']={r!r}: [0, 1)")
+    if conv_dropout and (xception or resnet):
+        raise ValueError(f"{model_config['FIRST']} has no Dropout in its spec: FIRST_ARGS['dropout_rate'] must be 0")
     gru = list(model_config["SECOND_ARGS"]["units"])
     sed, doa = list(model_config["SED_ARGS"]["units"]), list(model_config["DOA_ARGS"]["units"])
     # simple_dense_block honours these keys (modules.py:350-376): `dense_activation` None (seldnet.json: what lets W1 W2 fold into one
@@ -104,6 +110,7 @@ def _arch_from_config(model_config: dict, in_ch: int, n_freq: int, output_coupli
     a.sed_dropout = float(model_config["SED_ARGS"].get("dropout_rate", 0))
     a.doa_dropout = float(model_config["DOA_ARGS"].get("dropout_rate", 0))
     a.output_coupling = 1 if output_coupling else 0
+    a.conv_dropout, a.gru_dropout = conv_dropout, gru_dropout
     a.first_kind = 2 if resnet else (1 if xception else 0)
     a.xc_blocks = int(fa["block_num"]) if xception else 0
     if resnet:

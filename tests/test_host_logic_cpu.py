@@ -92,6 +92,31 @@ def test_synthetic_batch_matches_the_oracles_generator():
         assert got.dtype == want.dtype and np.array_equal(got, want)
 
 
+def test_first_and_second_block_dropout_rates_reach_the_arch(seldnet_config):
+    """FIRST_ARGS / SECOND_ARGS `dropout_rate` (model_config/seldnet.json:7,13; modules.py:306, 312-314) -> seld_arch.conv_dropout / gru_dropout;
+    out-of-range rates and a Dropout the other FIRST blocks' specs do not have are refused."""
+    import copy
+    from seld_amd import models
+    a = models._arch_from_config(seldnet_config, 7, 64)
+    assert (a.conv_dropout, a.gru_dropout) == (0.0, 0.0)
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST_ARGS"]["dropout_rate"], cfg["SECOND_ARGS"]["dropout_rate"] = 0.25, 0.5
+    a = models._arch_from_config(cfg, 7, 64)
+    assert (a.conv_dropout, a.gru_dropout) == (0.25, 0.5)
+    for key, val in (("FIRST_ARGS", 1.0), ("FIRST_ARGS", -0.5), ("SECOND_ARGS", 1.0), ("SECOND_ARGS", -0.1)):
+        bad = copy.deepcopy(seldnet_config)
+        bad[key]["dropout_rate"] = val
+        with pytest.raises(ValueError):
+            models._arch_from_config(bad, 7, 64)
+    xc = copy.deepcopy(seldnet_config)
+    xc["FIRST"], xc["FIRST_ARGS"] = "xception_block", {"filters": 32, "block_num": 8, "dropout_rate": 0.1}
+    with pytest.raises(ValueError, match="no Dropout"):
+        models._arch_from_config(xc, 7, 64)
+    xc["FIRST_ARGS"]["dropout_rate"] = 0.0
+    xc["SECOND_ARGS"]["dropout_rate"] = 0.2
+    assert abs(models._arch_from_config(xc, 7, 64).gru_dropout - 0.2) < 1e-7
+
+
 def test_head_args_the_kernels_do_not_implement_are_rejected(seldnet_config):
     """simple_dense_block honours dense_activation / kernel_size / dropout_rate (modules.py:350-376): the HIP heads take
     dense_activation None / linear / relu / tanh / sigmoid (config_sampler.py:216-218 samples None and relu), kernel_size 1 .. 15 and

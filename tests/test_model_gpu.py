@@ -202,6 +202,54 @@ def test_train_step_dense_kernel_size_and_dropout(seldnet_config, sed_args, doa_
         np.testing.assert_array_equal(y_r[0].cpu().numpy(), y_p[0].cpu().numpy())
 
 
+@pytest.mark.parametrize("conv_rate,gru_rate,B,T", [(0.0, 0.2, 2, 50), (0.25, 0.0, 3, 100), (0.2, 0.1, 2, 200), (0.1, 0.15, 3, 100), (0.0, 0.5, 1, 35)])
+def test_train_step_first_and_second_block_dropout(seldnet_config, conv_rate, gru_rate, B, T):
+    """`dropout_rate` of FIRST_ARGS / SECOND_ARGS (0.0 in every shipped config).  simple_conv_block: Dropout behind every MaxPooling2D.
+    bidirectional_GRU_block hands the rate to Keras as `dropout` AND `recurrent_dropout` of each GRU (modules.py:306, 312-314): per direction one
+    input mask and one state mask per clip, constant over the sequence; the masked previous state feeds the recurrent product and the blend
+    (GRUCell.call, implementation 2) while the emitted sequence is the unmasked state.  Forward, losses and every gradient of a train step
+    against the fp64 oracle on the library's draws (step 7); the evaluation step applies no mask; the next step draws new ones.
+    The cases are the well-conditioned ones: Keras' masked state is scaled by 1/(1-rate) at every step, so where an update gate sits near 1 it
+    GROWS (rate 0.3 over 20 steps of these random weights: |h| up to 874, and the oracle in fp32 is itself 4e-4 / 3e-3 from the oracle in fp64
+    for outputs / gradients); at the rates and lengths below fp32 and fp64 oracles agree to 2e-6, the last case (state up to 33) to 2e-5."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST_ARGS"]["dropout_rate"] = conv_rate
+    cfg["SECOND_ARGS"]["dropout_rate"] = gru_rate
+    spec = O.Spec.from_config(cfg)
+    assert (spec.conv_dropout, spec.gru_dropout) == (conv_rate, gru_rate)
+    w, st = O.random_weights(spec, 0)
+    x, ys, yd = O.synthetic_batch(B, T)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    model.set_weights(w, st)
+    ref_t = O.test_step(spec, w, st, x, ys, yd, "MSE", dtype=torch.float64)
+    y_t, _, _ = train.teststep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE)
+    check("teststep sed (no mask at inference)", y_t[0].cpu().numpy(), ref_t["sed"])
+    check("teststep doa (no mask at inference)", y_t[1].cpu().numpy(), ref_t["doa"])
+    model.set_option("dropout_step", 7)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64, dropout_step=7)
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    check("trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check("trainstep doa", y_p[1].cpu().numpy(), ref["doa"])
+    check("trainstep sloss", sl.cpu().numpy(), ref["sloss"])
+    check("trainstep dloss", dl.cpu().numpy(), ref["dloss"])
+    _per_var(model, "FIRST / SECOND dropout grad", model.get_grads(), ref["grad"])
+    # the masks did something: the same step without them gives another output
+    ref0 = O.train_step(O.Spec.from_config(seldnet_config), w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    assert np.abs(ref0["sed"] - ref["sed"]).max() > 1e-4
+    # the counter moved on: other masks; rewound: the same ones, bit for bit
+    model.set_weights(w, st)
+    y_n, _, _ = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    assert np.abs(y_n[0].cpu().numpy() - y_p[0].cpu().numpy()).max() > 1e-5
+    model.set_weights(w, st)
+    model.set_option("dropout_step", 7)
+    y_r, _, _ = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    np.testing.assert_array_equal(y_r[0].cpu().numpy(), y_p[0].cpu().numpy())
+    model.close()
+
+
 def test_train_step_stage_wrappers_and_identity_head(seldnet_config):
     """SECOND = bidirectional_GRU_stage (modules.py:46-61), SED = simple_dense_stage (depth 2, relu; modules.py:86-103), DOA =
     identity_block (modules.py:639-642: the output Dense straight on the recurrent features): train step against the fp64 oracle."""

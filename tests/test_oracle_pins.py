@@ -235,3 +235,70 @@ def test_seldnet_v1_output_coupling(spec):
     b = O.test_step(sp1, w, st, x, ys, yd, "MSE", dtype=torch.float64)
     np.testing.assert_array_equal(a["sed"], b["sed"])
     np.testing.assert_allclose(b["doa"], np.tanh(a["doa"] * np.concatenate([a["sed"]] * 3, axis=-1)), rtol=0, atol=1e-15)
+
+
+def test_gru_dropout_masks_follow_keras_implementation_2():
+    """Keras GRUCell.call, implementation 2 (the default; modules.py:312-314 passes dropout = recurrent_dropout = rate): `inputs * dp_mask[0]`
+    ahead of the kernel product, `h_tm1 = h_tm1 * rec_dp_mask[0]` ahead of the recurrent product — and, h_tm1 being reassigned, of the blend.
+    Properties of the restatement: an all-ones mask changes nothing; a zero in the input mask = that kernel row zeroed; a zero in the state
+    mask at unit k = recurrent row k zeroed AND unit k's output reduced to (1 - z) * hh (its own previous state never comes back); the
+    masks scale by 1 / (1 - rate) and hold for the whole sequence."""
+    from oracle import seldnet_oracle as O
+    rng = np.random.default_rng(5)
+    B, S, I, u = 2, 7, 6, 4
+    x = torch.as_tensor(rng.standard_normal((B, S, I)))
+    k = torch.as_tensor(rng.standard_normal((I, 3 * u)) * 0.5)
+    r = torch.as_tensor(rng.standard_normal((u, 3 * u)) * 0.5)
+    b = torch.as_tensor(rng.standard_normal((2, 3 * u)) * 0.1)
+    for rev in (False, True):
+        base = O.gru_direction(x, k, r, b, rev)
+        same = O.gru_direction(x, k, r, b, rev, in_mask=torch.ones(B, I, dtype=x.dtype), rec_mask=torch.ones(B, u, dtype=x.dtype))
+        np.testing.assert_allclose(same.numpy(), base.numpy(), rtol=0, atol=0)
+        im = torch.ones(B, I, dtype=x.dtype); im[:, 2] = 0.0
+        k0 = k.clone(); k0[2] = 0.0
+        np.testing.assert_allclose(O.gru_direction(x, k, r, b, rev, in_mask=im).numpy(), O.gru_direction(x, k0, r, b, rev).numpy(), rtol=1e-12, atol=1e-12)
+        rm = torch.ones(B, u, dtype=x.dtype); rm[:, 1] = 0.0
+        got = O.gru_direction(x, k, r, b, rev, rec_mask=rm)
+        r0 = r.clone(); r0[1] = 0.0
+        other = O.gru_direction(x, k, r0, b, rev)              # unit 1 unseen by the recurrent product, but still blended with its own past
+        keep = [0, 2, 3]
+        np.testing.assert_allclose(got.numpy()[..., keep], other.numpy()[..., keep], rtol=1e-12, atol=1e-12)      # the other units see unit 1 through the recurrent product alone
+        assert np.abs(got.numpy()[..., 1] - other.numpy()[..., 1]).max() > 1e-3                                  # unit 1 itself lost its own past in the blend
+        # unit 1 by hand: z, hh from the masked state; h = (1 - z) * hh
+        h = torch.zeros(B, u, dtype=x.dtype)
+        gx = x @ k + b[0]
+        for t in (range(S - 1, -1, -1) if rev else range(S)):
+            hm = h * rm
+            gh = hm @ r + b[1]
+            z = torch.sigmoid(gx[:, t, :u] + gh[:, :u]); rr = torch.sigmoid(gx[:, t, u:2 * u] + gh[:, u:2 * u])
+            hh = torch.tanh(gx[:, t, 2 * u:] + rr * gh[:, 2 * u:])
+            h = z * hm + (1 - z) * hh
+            np.testing.assert_allclose(got[:, t].numpy(), h.numpy(), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(got[:, t, 1].numpy(), ((1 - z) * hh)[:, 1].numpy(), rtol=1e-12, atol=1e-12)
+    m = O.dropout_mask((3, 8), 0.25, 0x5e1d5e1d5e1d5e1d, 96, 7, torch.float64).numpy()
+    assert set(np.unique(m)) <= {0.0, 1.0 / 0.75} and 0 < (m == 0).sum() < m.size
+    u_ = O.philox_uniform(24, 0x5e1d5e1d5e1d5e1d, 96, 7).reshape(3, 8)
+    np.testing.assert_array_equal(m == 0, u_ < np.float32(0.25))
+
+
+def test_first_and_second_block_dropout_in_the_oracle_forward(spec):
+    """FIRST_ARGS / SECOND_ARGS dropout_rate reach the oracle's forward only in training; the draws are those of the given step."""
+    import copy
+    from oracle import seldnet_oracle as O
+    sp = copy.deepcopy(spec)
+    sp.conv_dropout, sp.gru_dropout = 0.2, 0.3
+    w, st = O.random_weights(sp, 0)
+    tr, nt = O.variable_specs(sp)
+    wd, sd = O.unflatten(torch.as_tensor(w), tr), O.unflatten(torch.as_tensor(st), nt)
+    x, _, _ = O.synthetic_batch(2, 40)
+    xt = torch.as_tensor(x)
+    with torch.no_grad():
+        e0 = O.forward(spec, wd, sd, xt, training=False)[0]
+        e1 = O.forward(sp, wd, sd, xt, training=False)[0]
+        t0 = O.forward(spec, wd, sd, xt, training=True)[0]
+        t1 = O.forward(sp, wd, sd, xt, training=True, dropout_step=3)[0]
+        t1b = O.forward(sp, wd, sd, xt, training=True, dropout_step=3)[0]
+        t2 = O.forward(sp, wd, sd, xt, training=True, dropout_step=4)[0]
+    np.testing.assert_array_equal(e0.numpy(), e1.numpy())
+    np.testing.assert_array_equal(t1.numpy(), t1b.numpy())
+    assert np.abs(t0.numpy() - t1.numpy()).max() > 1e-5 and np.abs(t1.numpy() - t2.numpy()).max() > 1e-5
