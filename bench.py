@@ -37,6 +37,10 @@ SPLIT_BF16_GROUPS = {"conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "co
                      # resnet50_block: 87 % of the stages' FLOP (stages 2-3, the 128-column products of stages 0-1, stage 1's 3x3) run on
                      # the split-bf16 kernels, the 32- / 64-column rest on the f32 MFMA: the whole group is priced against the split peak
                      "rn_stages_fwd", "rn_stages_bwd"}   # with the default options (seld_set_option)
+# backward-only products (input / kernel gradients: they feed no MaxPool / ReLU decision) run FOUR of the six products by default (option
+# "bwd_four_products", conv_sb.hip): their ceiling is a quarter of the bf16 peak — the harder bar, and the one these groups are priced against
+PEAK_SPLIT4_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 4
+FOUR_PRODUCT_GROUPS = {"conv2_dgrad", "conv2_wgrad", "conv3_dgrad", "conv3_wgrad", "gru_bwd_gemms", "rn_stages_bwd", "rn_products_dgrad"}
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 # GRU recurrence (gru.hip): S dependent steps per launch on the 2B CUs that hold a (clip, direction) each.  The HARDWARE floor of a step is
 # its mat-vec at the CU's fp32 rate: 128 x 384 multiply-adds / (128 FMA per clock per CU: 4 SIMD-32 x 32 lanes) = 384 cycles, forward and
@@ -320,6 +324,8 @@ def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_
             ach, unit = amount / per_unit_s / 1e12, "TFLOP/s"
             peak = round(PEAK_SPLIT_BF16_TFLOPS, 1) if split else PEAK_F32_MFMA_TFLOPS
             path = "fp32-equivalent FLOP on 6 bf16 MFMA products of exactly split operands" if split else "f32-input MFMA"
+            if split and name in FOUR_PRODUCT_GROUPS:
+                peak, path = round(PEAK_SPLIT4_BF16_TFLOPS, 1), "fp32-equivalent FLOP on 4 bf16 MFMA products (hi*hi, hi*mid, mid*hi, mid*mid; backward-only)"
             if bf16 and split:
                 peak, path = PEAK_BF16_MFMA_TFLOPS, "one bf16 MFMA product per product (operands rounded to nearest bf16), dense bf16 peak"
         else:

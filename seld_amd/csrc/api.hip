@@ -120,6 +120,8 @@ struct seld_ctx {
     unsigned short *wsp_fwd[SELD_MAX_LAYERS] = {}, *wsp_bwd[SELD_MAX_LAYERS] = {};
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
     bool xc_fused_fwd = true;              // xception_block: depthwise + pointwise + BN statistics of a unit in one kernel
+    int gram_parts = 2;                    // 2: the background Gram launch in two halves, one under each of the first two GRU layers' forward recurrences
+    bool gru_din_first = false;            // backward: a GRU layer's input-gradient product ahead of the side stream's release (measured: no gain, see backward_impl)
     bool gru_wgrad_batch = true;           // a GRU layer's four weight-gradient products in one launch (+ one combine)
     bool gram_active = false;              // the last training forward took that path
     float *gram_slab = nullptr, *gram = nullptr, *mmat = nullptr;
@@ -648,6 +650,8 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gru_din_first")) { c->gru_din_first = value != 0; return SELD_OK; }
+    if (!strcmp(key, "gram_parts") && (value == 1 || value == 2)) { c->gram_parts = value; return SELD_OK; }
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
@@ -1076,6 +1080,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         in = X;       // [B,S,2,1024] = [B,S,2048]
     }
     const float* feat = in;  // [B,S,128] (force_1d_inputs: feature = f*64 + c)
+    const int gparts = !c->gram_active ? 0 : (c->gram_parts == 2 && c->gru.size() >= 2 ? 2 : 1);
+    int gram_ns = 0;
     for (size_t i = 0; i < c->gru.size(); ++i) {
         GruL& G = c->gru[i];
         if (gru_drop) {
@@ -1107,24 +1113,29 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 launch_gemm_dual_n(st, feat, G.in_feat, c->params + G.k_off[0], c->params + G.k_off[1], 384, c->params + G.b_off[0],
                                    c->params + G.b_off[1], G.gx[0], G.gx[1], 384, rows, 384, G.in_feat, 0, 0);
         }
-        if (i == 0 && c->gram_active) fork_side(c);
+        if ((int)i < gparts) fork_side(c);
         {
             PROF(c, "gru_fwd");
             launch_gru_fwd(st, G.gx[0], G.gx[1], c->params + G.u_off[0], c->params + G.u_off[1], c->params + G.b_off[0] + 384,
                            c->params + G.b_off[1] + 384, G.h[0], G.h[1], save ? G.sv[0] : nullptr, save ? G.sv[1] : nullptr, B, S);
         }
         }
-        if (i == 0 && c->gram_active && gru_drop) fork_side(c);
-        if (i == 0 && c->gram_active) {
+        if ((int)i < gparts && gru_drop) fork_side(c);
+        if ((int)i < gparts) {
             // Gram matrix of the input patches (conv_gram.hip): depends on x alone -> side stream, under the GRU
             // recurrences (2B of the 256 CUs): eligible when the first GRU kernel is (fork event recorded in front of it) but
             // enqueued after it, on a lower-priority stream, so that the recurrence gets its CUs first
+            // option "gram_parts" = 2: half of the tiles under each of the first two layers' recurrences (each part released by its own fork)
             int ns = 0;
             const int kp = conv_gram_dim(c->conv[0].Cin);
-            if (launch_conv_first_gram(c->side, x, c->gram_slab, &ns, B, c->conv[0].H, c->conv[0].Cin, 1))
+            if (i == 0) gram_ns = 0;
+            if (launch_conv_first_gram(c->side, x, c->gram_slab + (size_t)gram_ns * kp * kp, &ns, B, c->conv[0].H, c->conv[0].Cin, 1, (int)i, gparts))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_gram");
-            launch_reduce_slabs(c->side, c->gram_slab, ns, (int64_t)kp * kp, c->gram, (int64_t)kp * kp, 0);
-            hipEventRecord(c->ev_gram, c->side);
+            gram_ns += ns;
+            if ((int)i == gparts - 1) {
+                launch_reduce_slabs(c->side, c->gram_slab, gram_ns, (int64_t)kp * kp, c->gram, (int64_t)kp * kp, 0);
+                hipEventRecord(c->ev_gram, c->side);
+            }
         }
         launch_mul(st, G.h[0], G.h[1], G.out, (int64_t)rows * 128);
         feat = G.out;
@@ -1443,27 +1454,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
             launch_gru_bwd(st, dout, G.h[0], G.h[1], G.sv[0], G.sv[1], c->params + G.u_off[0], c->params + G.u_off[1], c->dgx[i][0],
                            c->dgx[i][1], c->dgh[i][0], c->dgh[i][1], B, S);
         }
-        // weight gradients of this layer: side stream (they overlap with the next layer's BPTT, which uses 2B of the 256 CUs)
-        fork_side(c);
-        if (i == (int)c->gru.size() - 1 && heads_lin(c)) heads_lin_side(c, rows);
-        TnJobs tj = {};
-        for (int d = 0; d < 2; ++d) {
-            // kernel + input bias (bias row 0); recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction
-            // h[t+1]) + bias row 1
-            tj.A[2 * d] = gru_drop ? G.xm[d] : lin; tj.lda[2 * d] = G.in_feat; tj.B[2 * d] = c->dgx[i][d]; tj.shift[2 * d] = 0;
-            tj.out_w[2 * d] = c->grads + G.k_off[d]; tj.out_b[2 * d] = c->grads + G.b_off[d];
-            tj.A[2 * d + 1] = gru_drop ? G.hm[d] : G.h[d]; tj.lda[2 * d + 1] = 128; tj.B[2 * d + 1] = c->dgh[i][d]; tj.shift[2 * d + 1] = d == 0 ? -1 : 1;
-            tj.out_w[2 * d + 1] = c->grads + G.u_off[d]; tj.out_b[2 * d + 1] = c->grads + G.b_off[d] + 384;
-        }
-        int ns4 = 0;
-        if (c->gru_wgrad_batch && c->gemm_split_bf16 && G.in_feat == 128 && launch_gemm_tn_sb_batch(c->side, tj, 4, 384, c->tn_slab_side, &ns4, rows, 384, S, 1) == 0) {
-            // the layer's four products in one launch, their slabs combined by one more
-            launch_reduce_slabs2_batch(c->side, c->tn_slab_side, ns4, (int64_t)128 * 384 + 384, tj, 4, (int64_t)128 * 384, 384);
-        } else
-            for (int j = 0; j < 4; ++j)
-                wgrad_dense(c, c->side, c->tn_slab_side, tj.A[j], tj.lda[j], tj.B[j], 384, rows, j & 1 ? 128 : G.in_feat, 384,
-                            tj.out_w[j] - c->grads, tj.out_b[j] - c->grads, j & 1 ? S : 0, tj.shift[j]);
-        hipEventRecord(c->ev_bucket[(int)c->gru.size() - 1 - i], c->side);   // this layer's (and, for the last layer, the heads') gradients are final
+        // the input gradient the next BPTT (or the conv backward) waits for: main stream.  Option "gru_din_first" (experiment, default 0) enqueues it BEFORE the
+        // side stream is released for this layer's weight gradients, so that they do not share the card with it: same box 2.651 / 2.650 ms per step with,
+        // 2.639 / 2.635 without — what the product gains the weight gradients lose under the next BPTT
+        auto din_gemm = [&]() {
         {
             PROF2(c, "gru_bwd_gemms");   // main stream: the input gradient the next BPTT waits for
             // din = dgx_f K_f^T + dgx_b K_b^T: one product over the concatenated K axis (no read-modify-write of din)
@@ -1485,6 +1479,30 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 launch_gemm_dual_k(st, c->dgx[i][0], c->dgx[i][1], 384, c->params + G.k_off[0], c->params + G.k_off[1], 384, nullptr,
                                    G.din, G.in_feat, rows, G.in_feat, 384, 1, 0, 0);
         }
+        };
+        if (c->gru_din_first) din_gemm();
+        // weight gradients of this layer: side stream (they overlap with the next layer's BPTT, which uses 2B of the 256 CUs)
+        fork_side(c);
+        if (i == (int)c->gru.size() - 1 && heads_lin(c)) heads_lin_side(c, rows);
+        TnJobs tj = {};
+        for (int d = 0; d < 2; ++d) {
+            // kernel + input bias (bias row 0); recurrent kernel: H_prev^T dgh (forward direction saw h[t-1], backward direction
+            // h[t+1]) + bias row 1
+            tj.A[2 * d] = gru_drop ? G.xm[d] : lin; tj.lda[2 * d] = G.in_feat; tj.B[2 * d] = c->dgx[i][d]; tj.shift[2 * d] = 0;
+            tj.out_w[2 * d] = c->grads + G.k_off[d]; tj.out_b[2 * d] = c->grads + G.b_off[d];
+            tj.A[2 * d + 1] = gru_drop ? G.hm[d] : G.h[d]; tj.lda[2 * d + 1] = 128; tj.B[2 * d + 1] = c->dgh[i][d]; tj.shift[2 * d + 1] = d == 0 ? -1 : 1;
+            tj.out_w[2 * d + 1] = c->grads + G.u_off[d]; tj.out_b[2 * d + 1] = c->grads + G.b_off[d] + 384;
+        }
+        int ns4 = 0;
+        if (c->gru_wgrad_batch && c->gemm_split_bf16 && G.in_feat == 128 && launch_gemm_tn_sb_batch(c->side, tj, 4, 384, c->tn_slab_side, &ns4, rows, 384, S, 1) == 0) {
+            // the layer's four products in one launch, their slabs combined by one more
+            launch_reduce_slabs2_batch(c->side, c->tn_slab_side, ns4, (int64_t)128 * 384 + 384, tj, 4, (int64_t)128 * 384, 384);
+        } else
+            for (int j = 0; j < 4; ++j)
+                wgrad_dense(c, c->side, c->tn_slab_side, tj.A[j], tj.lda[j], tj.B[j], 384, rows, j & 1 ? 128 : G.in_feat, 384,
+                            tj.out_w[j] - c->grads, tj.out_b[j] - c->grads, j & 1 ? S : 0, tj.shift[j]);
+        hipEventRecord(c->ev_bucket[(int)c->gru.size() - 1 - i], c->side);   // this layer's (and, for the last layer, the heads') gradients are final
+        if (!c->gru_din_first) din_gemm();
         dout = G.din;
     }
     // ---- conv blocks, last to first.  dout = gradient w.r.t. the last pooled output

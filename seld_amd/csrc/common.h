@@ -103,7 +103,7 @@ int conv_gram_dim(int Cin);
 extern int g_gram_bg_blocks;
 int conv_gram_slab_capacity();
 int conv_msparse_slab_capacity();
-int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background = 0);
+int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background = 0, int part = 0, int nparts = 1);
 int launch_conv_first_msparse(hipStream_t st, const float* x, const float* p, const float* dp, const unsigned char* amax,
                               const float* scale, float* slab, int* n_slab, int B, int H, int Cin);
 int launch_conv_first_assemble(hipStream_t st, const float* G, const float* M, const float* W, const float* bias, const float* coef,

@@ -34,7 +34,7 @@ int conv_gram_slab_capacity() { return GRAM_MAX_BLOCKS; }
 
 // G slab per block: [KP][KP] (only the upper tiles are written; the assembler mirrors them)
 template <int CIN>
-__global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __restrict__ x, float* __restrict__ slab, int B, int H) {
+__global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __restrict__ x, float* __restrict__ slab, int B, int H, int tile0, int tile1) {
     using G = GramGeom<CIN>;
     constexpr int K = G::K, KP = G::KP, NKT = G::NKT, ROWF = G::ROWF, NV = G::NV, SLOTS = G::SLOTS, PER = G::PER;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __
     __syncthreads();
     if (tid < 2) patch[tid * (G::PATCH + 4) + G::PATCH] = 1.f;       // the ones column (k = K); PATCH + 1 stays 0 (k > K)
     const int tiles_per_img = (H + 3) >> 2;
-    const int ntiles = B * tiles_per_img;
+    const int ntiles = tile1;            // this launch covers tiles [tile0, tile1) of the B * tiles_per_img (a background launch may come in two parts)
     float4 stg[PER];
 #define GR_ISSUE(tile_)                                                                                 \
     {                                                                                                   \
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __
         }                                                                                               \
     }
     typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
-    int tile = blockIdx.x, cur = 0;
+    int tile = tile0 + blockIdx.x, cur = 0;
     if (tile < ntiles) {
         GR_ISSUE(tile)
         GR_COMMIT(patch)
@@ -145,23 +145,32 @@ __global__ __launch_bounds__(256, 2) void conv_first_gram_kernel(const float* __
 // a background launch asks for 112 KB of LDS per block — it cannot land on a CU that runs a recurrence block — and for
 // at most 128 blocks (swept 64..192: 128 disturbs the input-projection GEMMs and the second GRU layer least while still
 // finishing well before the first block's backward needs G, ~2 ms later).
-int g_gram_bg_blocks = 128;   // workgroups of the background launch (swept: fewer stretch it over later kernels, more crowd the recurrence)
-int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background) {
-    if ((Cin != 7 && Cin != 10) || B <= 0 || H <= 0) return -2;
-    const int ntiles = B * ((H + 3) / 4);
+// Round 4: the background launch comes in two halves (api.hip, option "gram_parts" = 2), one under each of the first two GRU layers' forward
+// recurrences, 192 blocks each: a half is done (~0.23 ms) before its recurrence is (0.29 ms), so the Gram product no longer shares the card with the second
+// layer's input projection, the heads and the losses (the heads' product took 44 us beside it, ~15 alone).  Same box: 2.652 / 2.645 ms per step with one
+// 128-block launch, 2.673 / 2.657 with two of 128, 2.631 / 2.633 with two of 192, 2.643 with two of 160.
+int g_gram_bg_blocks = 192;   // workgroups of a background launch
+// part / nparts: the launch covers the part-th of nparts equal shares of the tiles and writes its slabs behind those of the parts before it
+// (*n_slab = this part's slab count; the caller sums them)
+int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background, int part, int nparts) {
+    if ((Cin != 7 && Cin != 10) || B <= 0 || H <= 0 || nparts < 1 || part < 0 || part >= nparts) return -2;
+    const int all = B * ((H + 3) / 4);
+    const int tile0 = (int)((int64_t)all * part / nparts), tile1 = (int)((int64_t)all * (part + 1) / nparts);
+    const int ntiles = tile1 - tile0;
     const int cap = background ? g_gram_bg_blocks : GRAM_MAX_BLOCKS;
     const int grid = ntiles < cap ? ntiles : cap;
+    if (grid < 1) { *n_slab = 0; return 0; }
     const size_t lds_floor = background ? (size_t)112 * 1024 : 0;
     if (Cin == 7) {
         size_t smem = (size_t)(2 * (GramGeom<7>::PATCH + 4) + 4096) * sizeof(float);
         if (smem < lds_floor) smem = lds_floor;
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_gram_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(conv_first_gram_kernel<7>, dim3(grid), dim3(256), smem, st, x, slab, B, H);
+        hipLaunchKernelGGL(conv_first_gram_kernel<7>, dim3(grid), dim3(256), smem, st, x, slab, B, H, tile0, tile1);
     } else {
         size_t smem = (size_t)(2 * (GramGeom<10>::PATCH + 4) + 4096) * sizeof(float);
         if (smem < lds_floor) smem = lds_floor;
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_gram_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(conv_first_gram_kernel<10>, dim3(grid), dim3(256), smem, st, x, slab, B, H);
+        hipLaunchKernelGGL(conv_first_gram_kernel<10>, dim3(grid), dim3(256), smem, st, x, slab, B, H, tile0, tile1);
     }
     *n_slab = grid;
     return 0;
