@@ -250,6 +250,50 @@ def test_train_step_first_and_second_block_dropout(seldnet_config, conv_rate, gr
     model.close()
 
 
+@pytest.mark.parametrize("first", ["xception_block", "resnet50_block"])
+def test_gru_dropout_behind_the_block_models(xception_config, resnet50_config, first):
+    """SECOND_ARGS dropout_rate behind the two other FIRST blocks (GRU input width 128 after xception_block, 2048 after resnet50_block: the input
+    mask is [B, in_feat]); a FIRST_ARGS dropout_rate is refused for them (their specs have no Dropout).  One train step against the fp64 oracle."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(xception_config if first == "xception_block" else resnet50_config)
+    if first == "xception_block":
+        cfg["FIRST_ARGS"]["block_num"] = 1
+    else:
+        cfg["FIRST_ARGS"]["block_num"] = [1, 1, 1, 1]
+    cfg["SECOND_ARGS"]["dropout_rate"] = 0.1
+    B, T = 2, 50
+    spec = O.Spec.from_config(cfg)
+    assert spec.gru_dropout == 0.1 and spec.conv_dropout == 0.0
+    w, st = O.random_weights(spec, 3)
+    x, ys, yd = O.synthetic_batch(B, T, seed=5)
+    model = models.seldnet((B, T, 64, 7), cfg)
+    model.set_weights(w, st)
+    model.set_option("dropout_step", 2)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64, dropout_step=2)
+    ref0 = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64, dropout_step=3)
+    assert np.abs(ref0["sed"] - ref["sed"]).max() > 1e-6          # the masks matter
+    y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+    check(f"{first} + GRU dropout trainstep sed", y_p[0].cpu().numpy(), ref["sed"])
+    check(f"{first} + GRU dropout trainstep doa", y_p[1].cpu().numpy(), ref["doa"], tol=2e-4 if first == "resnet50_block" else 1e-4)
+    if first == "xception_block":
+        _per_var(model, f"{first} + GRU dropout grad", model.get_grads(), ref["grad"])
+    else:
+        # resnet50_block's own variables are compared decision-aware in test_resnet50_gru_train_step (a ReLU gate within rounding of 0 moves a
+        # channel's gradient; some variables' gradients are exactly 0): here the recurrent block's and the heads', which see the masks
+        got = model.get_grads()
+        for n, off, sh in model.variables:
+            if n.startswith(("gru", "sed", "doa")):
+                k = int(np.prod(sh))
+                check(f"{first} + GRU dropout grad {n}", got[off:off + k], ref["grad"][off:off + k], 3e-4)
+    model.close()
+    bad = copy.deepcopy(cfg)
+    bad["FIRST_ARGS"]["dropout_rate"] = 0.2
+    with pytest.raises(ValueError, match="no Dropout"):
+        models.seldnet((B, T, 64, 7), bad)
+
+
 def test_train_step_stage_wrappers_and_identity_head(seldnet_config):
     """SECOND = bidirectional_GRU_stage (modules.py:46-61), SED = simple_dense_stage (depth 2, relu; modules.py:86-103), DOA =
     identity_block (modules.py:639-642: the output Dense straight on the recurrent features): train step against the fp64 oracle."""
