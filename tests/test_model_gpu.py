@@ -749,6 +749,46 @@ def test_seld_metrics_on_device(seldnet_config):
     assert float(dm.state.abs().sum()) == 0.0
 
 
+def _grads_given_the_librarys_routing(O, spec, model, w, st, x, ys, yd, B, T, label):
+    """After a train step of `model`: the library's MaxPool(ReLU) decisions of every block (seld_debug_pool_routing), each decision that differs
+    from the free-running fp64 oracle's asserted to have an fp64 margin below 1e-5, and the fp64 oracle's train step WITH the library's decisions."""
+    import ctypes as C
+    from seld_amd import _lib
+    routing = {}
+    H, W = T, 64
+    for i, (pt, pf) in enumerate(spec.pools):
+        shape = (B, H // pt, W // pf, 64)
+        pos = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        gate = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, i, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
+        routing[i] = (pos.cpu().to(torch.int64), gate.cpu().bool())
+        assert int(routing[i][0].max()) < pt * pf
+        H, W = H // pt, W // pf
+    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    free = {}
+    O.train_step(spec, w, st, x, ys, yd, record_routing=free, **kw)
+    n_flip = 0
+    for i in range(len(spec.pools)):
+        pos, gate = routing[i]
+        f = free[i]
+        both = gate & f["gate"]
+        arg = (pos != f["pos"]) & both
+        # the library's choice against the fp64 maximum of the same window: the margin fp32 would have had to resolve
+        chosen = f["windows"].gather(-1, pos.unsqueeze(-1)).squeeze(-1)
+        margin = (f["top"] - chosen)[arg]
+        gflip = gate != f["gate"]
+        gmargin = f["top"].abs()[gflip]
+        n_flip += int(arg.sum()) + int(gflip.sum())
+        print(f"[routing] {label} block {i}: {pos.numel()} pooled elements, argmax flips {int(arg.sum())} (max fp64 margin "
+              f"{float(margin.max()) if margin.numel() else 0.0:.2e}), ReLU gate flips {int(gflip.sum())} "
+              f"(max |top| {float(gmargin.max()) if gmargin.numel() else 0.0:.2e})")
+        assert (margin < 1e-5).all() and (gmargin < 1e-5).all()
+        del f["windows"]
+    ref = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
+    print(f"[routing] {label}: {n_flip} decisions differ from the free-running fp64 oracle; gradients against the fp64 oracle WITH the library's routing:")
+    return ref, n_flip
+
+
 def test_full_length_clips_train_step(seldnet_config):
     """BASELINE geometry along time (T = 3000 -> S = 600 GRU steps, 300 conv1 tiles per clip) at a batch the
     CPU oracle finishes in seconds: one train step against the oracle."""
@@ -759,7 +799,15 @@ def test_full_length_clips_train_step(seldnet_config):
     check("T=3000 sed", y_p[0].cpu().numpy(), ref["sed"])
     check("T=3000 doa", y_p[1].cpu().numpy(), ref["doa"])
     check("T=3000 dloss", dl.cpu().numpy(), ref["dloss"])
-    _per_var(model, "T=3000 grad", model.get_grads(), ref["grad"])
+    # gradients: among the 1.2 M first-block windows of two clips one can hold its two largest elements within an fp32 rounding of each other,
+    # and WHICH way an fp32 evaluation decides it depends on the summation order of the kernel of the day (it passed free-running until the
+    # first conv's K axis was re-packed in round 4: one flip, 4.8e-3 on conv0.kernel).  So, as in test_parity_given_identical_routing: the
+    # library's decisions differ from fp64's only where fp64's margin is below 1e-5, and GIVEN them every gradient is within 1e-4
+    g = model.get_grads()
+    ref_r, n_flip = _grads_given_the_librarys_routing(O, spec, model, w, st, x, ys, yd, 2, 3000, "B=2")
+    _per_var(model, "T=3000 grad (the library's routing)", g, ref_r["grad"])
+    if n_flip == 0:
+        _per_var(model, "T=3000 grad (free-running)", g, ref["grad"])
 
 
 def test_full_size_batch_consistency(seldnet_config):
@@ -881,44 +929,12 @@ def test_parity_given_identical_routing(seldnet_config):
           fp64 margin behind it (top1 - top2 of the window, or |top1| for the ReLU gate) is below 1e-5;
       (2) GIVEN the library's decisions (seld_debug_pool_routing), the fp64 oracle's gradients agree with the library's to
           1e-4 for every variable — no cancellation or summation error hides behind the flips."""
-    import ctypes as C
     B, T = 4, 3000
     O, spec, model, w, st, x, ys, yd = _setup(seldnet_config, B, T)
-    from seld_amd import _lib, losses, train
+    from seld_amd import losses, train
     train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3), False)
     g = model.get_grads()
-    routing = {}
-    H, W = T, 64
-    for i, (pt, pf) in enumerate(spec.pools):
-        shape = (B, H // pt, W // pf, 64)
-        pos = torch.empty(shape, dtype=torch.uint8, device="cuda")
-        gate = torch.empty(shape, dtype=torch.uint8, device="cuda")
-        _lib.check(model.lib.seld_debug_pool_routing(model.ctx, i, C.c_void_p(pos.data_ptr()), C.c_void_p(gate.data_ptr())), model.ctx)
-        routing[i] = (pos.cpu().to(torch.int64), gate.cpu().bool())
-        assert int(routing[i][0].max()) < pt * pf
-        H, W = H // pt, W // pf
-    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
-    free = {}
-    O.train_step(spec, w, st, x, ys, yd, record_routing=free, **kw)
-    n_flip = 0
-    for i in range(len(spec.pools)):
-        pos, gate = routing[i]
-        f = free[i]
-        both = gate & f["gate"]
-        arg = (pos != f["pos"]) & both
-        # the library's choice against the fp64 maximum of the same window: the margin fp32 would have had to resolve
-        chosen = f["windows"].gather(-1, pos.unsqueeze(-1)).squeeze(-1)
-        margin = (f["top"] - chosen)[arg]
-        gflip = gate != f["gate"]
-        gmargin = f["top"].abs()[gflip]
-        n_flip += int(arg.sum()) + int(gflip.sum())
-        print(f"[routing] block {i}: {pos.numel()} pooled elements, argmax flips {int(arg.sum())} (max fp64 margin "
-              f"{float(margin.max()) if margin.numel() else 0.0:.2e}), ReLU gate flips {int(gflip.sum())} "
-              f"(max |top| {float(gmargin.max()) if gmargin.numel() else 0.0:.2e})")
-        assert (margin < 1e-5).all() and (gmargin < 1e-5).all()
-        del f["windows"]
-    ref = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
-    print(f"[routing] {n_flip} decisions differ from the free-running fp64 oracle; gradients against the fp64 oracle WITH the library's routing:")
+    ref, _ = _grads_given_the_librarys_routing(O, spec, model, w, st, x, ys, yd, B, T, "B=4")
     _per_var(model, "routed grad", g, ref["grad"])
 
 
