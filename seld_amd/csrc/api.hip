@@ -658,7 +658,8 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "rn_implicit3x3")) { c->rn_implicit3x3 = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
-    if (!strcmp(key, "bwd_four_products")) { g_bwd_four = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
+    if (!strcmp(key, "bwd_four_products")) { g_bwd_four = value != 0; return SELD_OK; }
+    if (!strcmp(key, "tn_tile_blocks") && value >= 64 && value <= 4096) { g_tn_tile_blocks = value; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
     if (!strcmp(key, "gru_var")) { g_gru_var = value; return SELD_OK; }
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { g_tn_lds_floor_kb = value; return SELD_OK; }   // experiment (process-wide): gemm_tn_sb.hip     // kernel choice (process-wide): gru.hip
     if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip

@@ -133,6 +133,7 @@ __device__ __forceinline__ void split2r_pair(float x0, float x1, unsigned& h, un
     m = __builtin_amdgcn_perm(__float_as_uint(r1) + 0x8000u, __float_as_uint(r0) + 0x8000u, 0x07060302);
 }
 extern int g_gsb_four_now;    // gemm_sb.hip
+extern int g_tn_tile_blocks;   // gemm_tn_sb.hip
 extern int g_bwd_four;        // conv_sb.hip: backward-only products on four of the six split-bf16 terms (option "bwd_four_products")
 // a backward-only launch_gemm_sb (input gradients: their B planes come from a transposed / flipped gemm_split_b job) inside this scope takes the four-product form
 struct BwdFourScope {

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_sb_kernel(TnJobs jobs, int ldb
 
 // K1 = 128, N % 128 == 0, 16-byte aligned operands with leading dimensions % 4 == 0; same slab layout / n_slab as launch_gemm_tn
 int g_tn_lds_floor_kb = 0;
+int g_tn_tile_blocks = 384;      // tile mode: workgroups per launch the split count aims at (option "tn_tile_blocks"; resnet50_gru same box: 14.709 / 14.752 ms per step at 768, 14.646 at 384, 14.691 at 512, 14.87 at 256 and 1024)
 int gemm_tn_sb_usable(const void* A, int lda, const void* Bm, int ldb, int K1, int N) {
     return K1 == 128 && (N % 128) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
@@ -216,7 +217,7 @@ int launch_gemm_tn_sb_batch(hipStream_t st, const TnJobs& jobs, int njobs, int l
     return 0;
 }
 // C[K1][N] = A^T B with K1 % 128 == 0: one launch, (K1/128) x (N/128) tiles x splits blocks; slabs of K1 * N floats each (no bias part).
-// The split count fills the card about once (768 resident blocks) within the slab buffer's capacity.
+// The split count aims at g_tn_tile_blocks workgroups per launch (384: fewer slabs to write and combine than the 768 that fill every CU three times) within the slab buffer's capacity.
 int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, float* slab, int64_t slab_cap, int* nslab,
                             int M, int K1, int N, int conv_C, int conv_H, int conv_W) {
     int cvs = 0;
@@ -227,7 +228,7 @@ int launch_gemm_tn_sb_tiles(hipStream_t st, const float* A, int lda, const float
     }
     if (M <= 0 || K1 <= 0 || (K1 % 128) || !gemm_tn_sb_usable(A, lda, Bm, ldb, 128, N)) return -1;
     const int tiles = (K1 / 128) * (N / 128);
-    int64_t splits = (768 + tiles - 1) / tiles;
+    int64_t splits = (g_tn_tile_blocks + tiles - 1) / tiles;
     splits = std::min<int64_t>(splits, slab_cap / ((int64_t)K1 * N));
     splits = std::min<int64_t>(splits, 128);
     splits = std::min<int64_t>(splits, (M + 127) / 128);         // at least four 32-row chunks per split
