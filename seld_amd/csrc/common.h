@@ -132,7 +132,7 @@ __device__ __forceinline__ void split2r_pair(float x0, float x1, unsigned& h, un
     const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
     m = __builtin_amdgcn_perm(__float_as_uint(r1) + 0x8000u, __float_as_uint(r0) + 0x8000u, 0x07060302);
 }
-extern int g_gsb_four_now;    // gemm_sb.hip
+extern thread_local int g_gsb_four_now;    // gemm_sb.hip
 extern int g_tn_tile_blocks;   // gemm_tn_sb.hip
 extern int g_bwd_four;        // conv_sb.hip: backward-only products on four of the six split-bf16 terms (option "bwd_four_products")
 // a backward-only launch_gemm_sb (input gradients: their B planes come from a transposed / flipped gemm_split_b job) inside this scope takes the four-product form

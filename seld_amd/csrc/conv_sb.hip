@@ -681,7 +681,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
 }
 
 int g_bwd_four = 1;        // option "bwd_four_products": backward-only products (input / kernel gradients) on four of the six split-bf16 terms
-static int s_sbd_four = 0; // set around an input-gradient launch (launch_conv64_dgrad_sb)
+static thread_local int s_sbd_four = 0; // set around an input-gradient launch (launch_conv64_dgrad_sb); per host thread: two contexts driven by two threads must not see each other's
 int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights) for W = 16 / 4; 0: conv64_fwd_sbr_kernel
 
 template <int WLOG2, int R>

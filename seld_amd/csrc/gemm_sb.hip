@@ -442,7 +442,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
 }
 
 int g_gsb_dbg = 0;
-int g_gsb_four_now = 0;       // set for the duration of a backward launch (common.h BwdFourScope)
+thread_local int g_gsb_four_now = 0;       // set for the duration of a backward launch (common.h BwdFourScope); per host thread: another thread's forward launch must not read it
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
                    const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
                    int accum, int conv_C, int conv_H, int conv_W) {
