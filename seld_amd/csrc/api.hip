@@ -121,6 +121,7 @@ struct seld_ctx {
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
     bool xc_fused_fwd = true;              // xception_block: depthwise + pointwise + BN statistics of a unit in one kernel
     int gram_parts = 2;                    // 2: the background Gram launch in two halves, one under each of the first two GRU layers' forward recurrences
+    bool conv2_pre_fused = true;           // the first block's BatchNorm + ReLU pass over its pooled tensor folded into the second block's region load
     bool gru_din_first = false;            // backward: a GRU layer's input-gradient product ahead of the side stream's release (measured: no gain, see backward_impl)
     bool gru_wgrad_batch = true;           // a GRU layer's four weight-gradient products in one launch (+ one combine)
     bool gram_active = false;              // the last training forward took that path
@@ -651,6 +652,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_din_first")) { c->gru_din_first = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv2_pre_fused")) { c->conv2_pre_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "gram_parts") && (value == 1 || value == 2)) { c->gram_parts = value; return SELD_OK; }
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
@@ -878,6 +880,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         }
     }
     const float* in = x;
+    bool pre_pending = false;
     for (size_t i = 0; i < c->conv.size(); ++i) {
         ConvL& L = c->conv[i];
         int npart = 0;
@@ -904,8 +907,12 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         } else {
             PROF2(c, tn);
             if (c->conv64_split_bf16) {
-                if (launch_conv64_fwd_sb(st, in, c->wsp_fwd[i], c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
+                // pre_pending: the first block's BatchNorm + ReLU ride in this block's region load (conv_sb.hip PRE), which also writes its pooled tensor
+                const ConvL& P = c->conv[i - 1];
+                if (launch_conv64_fwd_sb(st, pre_pending ? P.zext : in, c->wsp_fwd[i], c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W,
+                                         pre_pending ? P.scale : nullptr, pre_pending ? P.shift : nullptr, pre_pending ? P.p : nullptr))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd_sb");
+                pre_pending = false;
             } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
@@ -924,7 +931,12 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
         {
             PROF2(c, tn);
-            if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
+            // option "conv2_pre_fused" (default 1): with the Gram backward (zext kept beside p) and a second block on the double-buffered split-bf16
+            // kernel, the pass is folded into that block's region load; not with Dropout behind the pool (it reads p right away)
+            if (fused_pool && gram && c->conv2_pre_fused && !conv_drop && c->arch.first_kind == SELD_FIRST_SIMPLE_CONV && i + 1 < c->conv.size() &&
+                c->conv64_split_bf16 && !g_mfma_one && conv64_fwd_sb_takes_pre(c->conv[i + 1].W))
+                pre_pending = true;
+            else if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
                 launch_bn_relu_ext(st, gram ? L.zext : L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);
             else if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");

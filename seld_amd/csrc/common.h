@@ -141,8 +141,12 @@ struct BwdFourScope {
     ~BwdFourScope() { g_gsb_four_now = 0; }
 };
 int launch_conv64_dgrad_sb(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dx, int B, int H, int W);
+// pre_scale / pre_shift / pre_out (conv64_fwd_sb_takes_pre(W)): x holds the previous block's window extremes; its BatchNorm + ReLU are applied on load
+// and the activated tensor is written to pre_out (!= x)
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
-                         float* stat_partial, int* n_partial, int B, int H, int W);
+                         float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale = nullptr, const float* pre_shift = nullptr,
+                         float* pre_out = nullptr);
+int conv64_fwd_sb_takes_pre(int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
                         int64_t n, int accumulate);

@@ -469,10 +469,15 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
 // FOUR (round 4, backward products only: option "bwd_four_products"): four of the six products — hi*hi, hi*mid, mid*hi, mid*mid; the two with a lo
 // factor (2^-17 relative each) are dropped, the lo planes are neither staged nor read.  An input gradient feeds no MaxPool / ReLU decision, so the
 // error (~1.5e-5 relative per product, random in sign over a 576-term sum) stays one decade inside the 1e-4 bar; forward products keep all six.
-template <int WLOG2, int R, bool STATS, bool ONE, bool FOUR = false>
+// PRE (round 4): x is the PREVIOUS block's window-extreme tensor (conv_pool_sb.hip's zext) and the block's BatchNormalization + ReLU
+// are applied while the region is loaded — max(0, fmaf(v, scale[c], shift[c])), the arithmetic of bn_relu_ext, so the result is the same bits —
+// and every tile writes the activated values of the rows it owns to pre_out (the pooled tensor the backward pass reads): the separate
+// elementwise pass over the pooled tensor (24 us per step) is gone.  pre_out must not alias x (a neighbour's halo read would see activated values).
+template <int WLOG2, int R, bool STATS, bool ONE, bool FOUR = false, bool PRE = false>
 __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
-    float* __restrict__ z, float* __restrict__ stat_partial, int B, int H) {
+    float* __restrict__ z, float* __restrict__ stat_partial, int B, int H,
+    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr, float* __restrict__ pre_out = nullptr) {
     constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
     constexpr int RR = R + 2, NPIX = RR * W, ZROW = NPIX;               // region pixels; index of the all-zero row
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
@@ -507,6 +512,12 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     float4 rreg[NPF];
     u32x4 wreg0, wreg1, wreg2, wreg3;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // PRE: a thread's region slots all carry the same 4 channels (NT % 16 == 0); where the staged tile's rows go in pre_out
+    static_assert(!PRE || NT % 16 == 0, "one channel group per thread");
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRE) { psc = reinterpret_cast<const float4*>(pre_scale)[tid & 15]; psh = reinterpret_cast<const float4*>(pre_shift)[tid & 15]; }
+    float* pre_org = nullptr;
+    int pre_t0 = 0;
 #define SBD_ISSUE_REGION(tile_)                                                                         \
     {                                                                                                   \
         const int tb_ = (tile_) / tiles_per_img, tt0_ = ((tile_) - tb_ * tiles_per_img) * R;            \
@@ -514,13 +525,19 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
         _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                               \
             const int t_ = tt0_ - 1 + rrow[u];                                                          \
             const bool ok_ = rrow[u] >= 0 && t_ >= 0 && t_ < H;                                         \
-            const float4 v_ = *reinterpret_cast<const float4*>(ok_ ? org_ + roff[u] : x);               \
+            float4 v_ = *reinterpret_cast<const float4*>(ok_ ? org_ + roff[u] : x);                     \
+            if (PRE) v_ = make_float4(fmaxf(0.f, fmaf(v_.x, psc.x, psh.x)), fmaxf(0.f, fmaf(v_.y, psc.y, psh.y)),  \
+                                      fmaxf(0.f, fmaf(v_.z, psc.z, psh.z)), fmaxf(0.f, fmaf(v_.w, psc.w, psh.w)));  \
             rreg[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                       \
         }                                                                                               \
+        if (PRE) { pre_org = pre_out + (size_t)(tb_ * H + tt0_) * W * 64; pre_t0 = tt0_; }              \
     }
 #define SBD_COMMIT_REGION()                                                                             \
     _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                   \
         const int idx = tid + NT * u;                                                                   \
+        /* PRE: the rows this tile OWNS (region rows 1 .. R inside the image) leave as the previous block's pooled tensor */ \
+        if (PRE && idx < NREG4 && rrow[u] >= 1 && rrow[u] <= R && pre_t0 + rrow[u] - 1 < H)            \
+            *reinterpret_cast<float4*>(pre_org + roff[u]) = rreg[u];                                    \
         if (idx < NREG4) {                                                                              \
             unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
             if (ONE) {                                                                                  \
@@ -686,7 +703,8 @@ int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights)
 
 template <int WLOG2, int R>
 static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
-                      float* stat_partial, int* n_partial, int B, int H) {
+                      float* stat_partial, int* n_partial, int B, int H, const float* pre_scale = nullptr, const float* pre_shift = nullptr,
+                      float* pre_out = nullptr) {
     constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * W;
     const int ntiles = B * ((H + R - 1) / R);
     const int grid = ntiles < 256 ? ntiles : 256;      // one block per CU (LDS-limited), persistent
@@ -698,6 +716,21 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);   \
     }
+    if (pre_scale) {      // BatchNorm + ReLU of the previous block on load (six-product forward of the W = 16 block only: launch_conv64_fwd_sb checks)
+        if constexpr (WLOG2 == 4) {
+            if (g_mfma_one || !pre_shift || !pre_out || pre_out == x) return -3;
+            if (stat_partial) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, true, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H, pre_scale, pre_shift, pre_out);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H, pre_scale, pre_shift, pre_out);
+            }
+            if (n_partial) *n_partial = grid;
+            return 0;
+        } else
+            return -3;
+    }
     if (g_mfma_one) { if (stat_partial) SBD_GO(true, true) else SBD_GO(false, true) }
     else if (s_sbd_four && !stat_partial) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -708,9 +741,11 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
     return 0;
 }
 
+int conv64_fwd_sb_takes_pre(int W) { return W == 16 && g_conv64_dbuf && !g_mfma_one; }
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
-                         float* stat_partial, int* n_partial, int B, int H, int W) {
-    if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 8 waves, 156 KB
+                         float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale, const float* pre_shift, float* pre_out) {
+    if (pre_scale && !conv64_fwd_sb_takes_pre(W)) return -3;
+    if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out);   // 8 waves, 156 KB
     if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 6 waves
     if (W == 8 && g_conv64_dbuf) return launch_sbd<3, 32>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves (resnet50_block stage 1)
     if (W == 16) return launch_sbr<4, 16, true>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves, 153 KB
