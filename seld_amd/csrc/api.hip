@@ -121,6 +121,7 @@ struct seld_ctx {
     int conv1_gram = 1;                    // 1: first block's kernel gradient from the patch Gram matrix, no pre-BN tensor (conv_gram.hip)
     bool xc_fused_fwd = true;              // xception_block: depthwise + pointwise + BN statistics of a unit in one kernel
     int gram_parts = 2;                    // 2: the background Gram launch in two halves, one under each of the first two GRU layers' forward recurrences
+    bool conv3_pre_fused = true;           // ... and the second block's (1,4) pooling pass: window extremes in its epilogue, BatchNorm + ReLU in the third block's loader
     bool conv2_pre_fused = true;           // the first block's BatchNorm + ReLU pass over its pooled tensor folded into the second block's region load
     bool gru_din_first = false;            // backward: a GRU layer's input-gradient product ahead of the side stream's release (measured: no gain, see backward_impl)
     bool gru_wgrad_batch = true;           // a GRU layer's four weight-gradient products in one launch (+ one combine)
@@ -451,6 +452,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(L.z, nz); ALLOC(L.p, np); ALLOC(L.dp, np);
         if (a->conv_dropout > 0.f) ALLOC(L.pd, np);
         if (i == 0) { float* am = nullptr; ALLOC(am, (np + 3) / 4); L.amax = reinterpret_cast<unsigned char*>(am); ALLOC(L.zext, np); }
+        if (i == 1 && L.W == 16 && L.pt == 1 && L.pf == 4) ALLOC(L.zext, np);      // the (1,4) windows' extremes of z (conv_sb.hip EXT), when the third block's loader pools
         if (nz > zmax) zmax = nz;
         float* sm = c->small + (size_t)i * 64 * 6;
         L.mean = sm; L.invstd = sm + 64; L.scale = sm + 128; L.shift = sm + 192; L.c1c2 = sm + 256;
@@ -653,6 +655,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_din_first")) { c->gru_din_first = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv2_pre_fused")) { c->conv2_pre_fused = value != 0; return SELD_OK; }
+    if (!strcmp(key, "conv3_pre_fused")) { c->conv3_pre_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "gram_parts") && (value == 1 || value == 2)) { c->gram_parts = value; return SELD_OK; }
     if (!strcmp(key, "xc_fused_fwd")) { c->xc_fused_fwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
@@ -883,6 +886,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     bool pre_pending = false;
     for (size_t i = 0; i < c->conv.size(); ++i) {
         ConvL& L = c->conv[i];
+        bool ext_now = false;
         int npart = 0;
         float* stat = training ? c->stat_partial : nullptr;
         char tn[32];
@@ -909,8 +913,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             if (c->conv64_split_bf16) {
                 // pre_pending: the first block's BatchNorm + ReLU ride in this block's region load (conv_sb.hip PRE), which also writes its pooled tensor
                 const ConvL& P = c->conv[i - 1];
+                // ext_now (option "conv3_pre_fused"): this block's (1,4) pooling is split the same way — the epilogue keeps every window's extreme of z
+                // (EXT), the NEXT block's loader applies BatchNorm + ReLU to them and writes this block's pooled tensor: no pooling pass over z
+                ext_now = pre_pending && stat && c->conv3_pre_fused && L.zext && L.W == 16 && L.pt == 1 && L.pf == 4 && !conv_drop && i + 1 < c->conv.size() &&
+                          c->conv[i + 1].W == 4 && conv64_fwd_sb_takes_pre(4);
                 if (launch_conv64_fwd_sb(st, pre_pending ? P.zext : in, c->wsp_fwd[i], c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W,
-                                         pre_pending ? P.scale : nullptr, pre_pending ? P.shift : nullptr, pre_pending ? P.p : nullptr))
+                                         pre_pending ? P.scale : nullptr, pre_pending ? P.shift : nullptr, pre_pending ? P.p : nullptr,
+                                         ext_now ? c->params + L.g_off : nullptr, ext_now ? L.zext : nullptr))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd_sb");
                 pre_pending = false;
             } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
@@ -935,6 +944,8 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             // kernel, the pass is folded into that block's region load; not with Dropout behind the pool (it reads p right away)
             if (fused_pool && gram && c->conv2_pre_fused && !conv_drop && c->arch.first_kind == SELD_FIRST_SIMPLE_CONV && i + 1 < c->conv.size() &&
                 c->conv64_split_bf16 && !g_mfma_one && conv64_fwd_sb_takes_pre(c->conv[i + 1].W))
+                pre_pending = true;
+            else if (ext_now)       // the next block's loader pools: see the convolution's launch above
                 pre_pending = true;
             else if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
                 launch_bn_relu_ext(st, gram ? L.zext : L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);

@@ -145,7 +145,7 @@ int launch_conv64_dgrad_sb(hipStream_t st, const float* dz, const unsigned short
 // and the activated tensor is written to pre_out (!= x)
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale = nullptr, const float* pre_shift = nullptr,
-                         float* pre_out = nullptr);
+                         float* pre_out = nullptr, const float* ext_gamma = nullptr, float* ext_out = nullptr);      // ext_*: W = 16, with pre_*: the (1,4) windows' extremes of z
 int conv64_fwd_sb_takes_pre(int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,

@@ -473,11 +473,18 @@ static int launch_sbr(hipStream_t st, const float* x, const unsigned short* wsp,
 // are applied while the region is loaded — max(0, fmaf(v, scale[c], shift[c])), the arithmetic of bn_relu_ext, so the result is the same bits —
 // and every tile writes the activated values of the rows it owns to pre_out (the pooled tensor the backward pass reads): the separate
 // elementwise pass over the pooled tensor (24 us per step) is gone.  pre_out must not alias x (a neighbour's halo read would see activated values).
-template <int WLOG2, int R, bool STATS, bool ONE, bool FOUR = false, bool PRE = false>
+// EXT (round 4, W = 16 with a (1,4) pool behind the block): the epilogue also stores, per pooling window of four bins and channel, the
+// EXTREME of z that survives BatchNorm + ReLU + MaxPool — the maximum where gamma >= 0, the minimum where gamma < 0: BN is monotone in z
+// (fmaf is), so pool(relu(bn(z))) = relu(bn(extreme)) bit for bit (conv_pool.hip's argument) — into ext_out [B][H][W/4][64]: the NEXT block's
+// PRE loader turns them into this block's pooled tensor, and the separate pooling pass over z (16 us per step) is gone.  In the accumulator
+// layout a lane's registers 4q .. 4q + 3 are exactly one window of one channel.
+template <int WLOG2, int R, bool STATS, bool ONE, bool FOUR = false, bool PRE = false, bool EXT = false>
 __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wsp, const float* __restrict__ bias,
     float* __restrict__ z, float* __restrict__ stat_partial, int B, int H,
-    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr, float* __restrict__ pre_out = nullptr) {
+    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr, float* __restrict__ pre_out = nullptr,
+    const float* __restrict__ ext_gamma = nullptr, float* __restrict__ ext_out = nullptr) {
+    static_assert(!EXT || WLOG2 == 4, "window extremes: W = 16, windows of four bins");
     constexpr int W = 1 << WLOG2, TP = R * W, NW = TP / 32, NT = 64 * NW;
     constexpr int RR = R + 2, NPIX = RR * W, ZROW = NPIX;               // region pixels; index of the all-zero row
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
@@ -518,6 +525,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     if (PRE) { psc = reinterpret_cast<const float4*>(pre_scale)[tid & 15]; psh = reinterpret_cast<const float4*>(pre_shift)[tid & 15]; }
     float* pre_org = nullptr;
     int pre_t0 = 0;
+    bool ext_neg[2] = {false, false};
+    if (EXT) { ext_neg[0] = ext_gamma[li] < 0.f; ext_neg[1] = ext_gamma[32 + li] < 0.f; }
 #define SBD_ISSUE_REGION(tile_)                                                                         \
     {                                                                                                   \
         const int tb_ = (tile_) / tiles_per_img, tt0_ = ((tile_) - tb_ * tiles_per_img) * R;            \
@@ -659,6 +668,12 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
                         s2[c] = fmaf(v[j], v[j], s2[c]);
                     }
                 }
+                if (EXT) {      // pixels 8 q + 4 hi .. + 3 of this wave = four consecutive bins of one image row: one window
+                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                    const int p0 = wave * 32 + 8 * q + 4 * hi;
+                    const int te = t0 + (p0 >> WLOG2);
+                    if (te < H) ext_out[((size_t)(b * H + te) * (W / 4) + ((p0 & (W - 1)) >> 2)) * 64 + c * 32 + li] = ext_neg[c] ? mn : mx;
+                }
                 const float4 o = quad_transpose4(v[0], v[1], v[2], v[3], li);
                 const int p = wave * 32 + 8 * q + 4 * hi + (li & 3);      // pixel of the tile this lane stores
                 const int t = t0 + (p >> WLOG2);
@@ -704,7 +719,7 @@ int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights)
 template <int WLOG2, int R>
 static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                       float* stat_partial, int* n_partial, int B, int H, const float* pre_scale = nullptr, const float* pre_shift = nullptr,
-                      float* pre_out = nullptr) {
+                      float* pre_out = nullptr, const float* ext_gamma = nullptr, float* ext_out = nullptr) {
     constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * W;
     const int ntiles = B * ((H + R - 1) / R);
     const int grid = ntiles < 256 ? ntiles : 256;      // one block per CU (LDS-limited), persistent
@@ -716,21 +731,28 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);   \
     }
-    if (pre_scale) {      // BatchNorm + ReLU of the previous block on load (six-product forward of the W = 16 block only: launch_conv64_fwd_sb checks)
+    if (pre_scale) {      // BatchNorm + ReLU of the previous block on load (six-product forward; launch_conv64_fwd_sb checks the shapes)
+        if (g_mfma_one || !pre_shift || !pre_out || pre_out == x) return -3;
+#define SBD_PRE_GO(S_, E_)                                                                                                                  \
+        {                                                                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, S_, false, false, true, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, false, false, true, E_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H, pre_scale, pre_shift, \
+                               pre_out, ext_gamma, ext_out);                                                                                \
+        }
         if constexpr (WLOG2 == 4) {
-            if (g_mfma_one || !pre_shift || !pre_out || pre_out == x) return -3;
-            if (stat_partial) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, true, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H, pre_scale, pre_shift, pre_out);
-            } else {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H, pre_scale, pre_shift, pre_out);
-            }
-            if (n_partial) *n_partial = grid;
-            return 0;
+            if (ext_out) { if (!ext_gamma || !stat_partial) return -3; SBD_PRE_GO(true, true) }
+            else if (stat_partial) SBD_PRE_GO(true, false)
+            else SBD_PRE_GO(false, false)
+        } else if constexpr (WLOG2 == 2) {
+            if (ext_out || !stat_partial) return -3;
+            SBD_PRE_GO(true, false)
         } else
             return -3;
+#undef SBD_PRE_GO
+        if (n_partial) *n_partial = grid;
+        return 0;
     }
+    if (ext_out) return -3;      // window extremes come with the PRE loader only (the training step's second block)
     if (g_mfma_one) { if (stat_partial) SBD_GO(true, true) else SBD_GO(false, true) }
     else if (s_sbd_four && !stat_partial) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -741,12 +763,13 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
     return 0;
 }
 
-int conv64_fwd_sb_takes_pre(int W) { return W == 16 && g_conv64_dbuf && !g_mfma_one; }
+int conv64_fwd_sb_takes_pre(int W) { return (W == 16 || W == 4) && g_conv64_dbuf && !g_mfma_one; }      // W = 4: with BatchNorm statistics (training) only
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
-                         float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale, const float* pre_shift, float* pre_out) {
-    if (pre_scale && !conv64_fwd_sb_takes_pre(W)) return -3;
-    if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out);   // 8 waves, 156 KB
-    if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 6 waves
+                         float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale, const float* pre_shift, float* pre_out,
+                         const float* ext_gamma, float* ext_out) {
+    if ((pre_scale || ext_out) && !conv64_fwd_sb_takes_pre(W)) return -3;
+    if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out, ext_gamma, ext_out);   // 8 waves, 156 KB
+    if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out);    // 6 waves
     if (W == 8 && g_conv64_dbuf) return launch_sbd<3, 32>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves (resnet50_block stage 1)
     if (W == 16) return launch_sbr<4, 16, true>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves, 153 KB
     if (W == 4) return launch_sbr<2, 48, false>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);   // 6 waves (halo columns: no room for 8)
