@@ -897,10 +897,14 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         const bool fused_pool = i == 0 && c->conv1_pool_fused && L.pt == 5 && L.pf == 4 && L.W == 64;
         const bool gram = fused_pool && save && c->conv1_gram;      // backward without the pre-BN tensor: z is not stored
         if (i == 0) c->gram_active = gram;
+        // the pooled tensor's BatchNorm + ReLU pass folded into the next block's loader (conv_sb.hip PRE): training with the Gram backward (zext kept
+        // beside p), and inference (nobody reads p: the extremes go to zext and p is not written at all)
+        const bool pre_next = fused_pool && (gram || !save) && c->conv2_pre_fused && !conv_drop && c->arch.first_kind == SELD_FIRST_SIMPLE_CONV &&
+                              i + 1 < c->conv.size() && c->conv64_split_bf16 && !g_mfma_one && conv64_fwd_sb_takes_pre(c->conv[i + 1].W);
         if (fused_pool) {
             PROF(c, tn);   // level 1
             if (launch_conv_first_fwd_pool(st, in, c->params + L.w_off, c->params + L.b_off, c->params + L.g_off,
-                                           (save && !gram) ? L.z : nullptr, gram ? L.zext : L.p, save ? L.amax : nullptr, stat,
+                                           (save && !gram) ? L.z : nullptr, (gram || pre_next) ? L.zext : L.p, save ? L.amax : nullptr, stat,
                                            &npart, B, L.H, L.Cin, c->conv1_split_bf16))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv_first_fwd_pool");
         } else if (i == 0) {
@@ -915,10 +919,11 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 const ConvL& P = c->conv[i - 1];
                 // ext_now (option "conv3_pre_fused"): this block's (1,4) pooling is split the same way — the epilogue keeps every window's extreme of z
                 // (EXT), the NEXT block's loader applies BatchNorm + ReLU to them and writes this block's pooled tensor: no pooling pass over z
-                ext_now = pre_pending && stat && c->conv3_pre_fused && L.zext && L.W == 16 && L.pt == 1 && L.pf == 4 && !conv_drop && i + 1 < c->conv.size() &&
+                ext_now = pre_pending && c->conv3_pre_fused && L.zext && L.W == 16 && L.pt == 1 && L.pf == 4 && !conv_drop && i + 1 < c->conv.size() &&
                           c->conv[i + 1].W == 4 && conv64_fwd_sb_takes_pre(4);
+                // (inference: the previous block's activated tensor is read by nobody -> not written)
                 if (launch_conv64_fwd_sb(st, pre_pending ? P.zext : in, c->wsp_fwd[i], c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W,
-                                         pre_pending ? P.scale : nullptr, pre_pending ? P.shift : nullptr, pre_pending ? P.p : nullptr,
+                                         pre_pending ? P.scale : nullptr, pre_pending ? P.shift : nullptr, (pre_pending && save) ? P.p : nullptr,
                                          ext_now ? c->params + L.g_off : nullptr, ext_now ? L.zext : nullptr))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd_sb");
                 pre_pending = false;
@@ -942,8 +947,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             PROF2(c, tn);
             // option "conv2_pre_fused" (default 1): with the Gram backward (zext kept beside p) and a second block on the double-buffered split-bf16
             // kernel, the pass is folded into that block's region load; not with Dropout behind the pool (it reads p right away)
-            if (fused_pool && gram && c->conv2_pre_fused && !conv_drop && c->arch.first_kind == SELD_FIRST_SIMPLE_CONV && i + 1 < c->conv.size() &&
-                c->conv64_split_bf16 && !g_mfma_one && conv64_fwd_sb_takes_pre(c->conv[i + 1].W))
+            if (pre_next)
                 pre_pending = true;
             else if (ext_now)       // the next block's loader pools: see the convolution's launch above
                 pre_pending = true;

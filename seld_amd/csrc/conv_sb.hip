@@ -545,7 +545,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                   \
         const int idx = tid + NT * u;                                                                   \
         /* PRE: the rows this tile OWNS (region rows 1 .. R inside the image) leave as the previous block's pooled tensor */ \
-        if (PRE && idx < NREG4 && rrow[u] >= 1 && rrow[u] <= R && pre_t0 + rrow[u] - 1 < H)            \
+        if (PRE && pre_out && idx < NREG4 && rrow[u] >= 1 && rrow[u] <= R && pre_t0 + rrow[u] - 1 < H)  \
             *reinterpret_cast<float4*>(pre_org + roff[u]) = rreg[u];                                    \
         if (idx < NREG4) {                                                                              \
             unsigned short* d_ = Rp + (idx >> 4) * LD + SBD_CH(idx >> 4, (idx & 15) >> 1) * 8 + (idx & 1) * 4; \
@@ -732,7 +732,7 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
         hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, S_, O_>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);   \
     }
     if (pre_scale) {      // BatchNorm + ReLU of the previous block on load (six-product forward; launch_conv64_fwd_sb checks the shapes)
-        if (g_mfma_one || !pre_shift || !pre_out || pre_out == x) return -3;
+        if (g_mfma_one || !pre_shift || pre_out == x) return -3;      // pre_out == nullptr: inference (nobody reads the activated tensor)
 #define SBD_PRE_GO(S_, E_)                                                                                                                  \
         {                                                                                                                                   \
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, S_, false, false, true, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
@@ -740,12 +740,13 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
                                pre_out, ext_gamma, ext_out);                                                                                \
         }
         if constexpr (WLOG2 == 4) {
-            if (ext_out) { if (!ext_gamma || !stat_partial) return -3; SBD_PRE_GO(true, true) }
+            if (ext_out && !ext_gamma) return -3;
+            if (ext_out) { if (stat_partial) SBD_PRE_GO(true, true) else SBD_PRE_GO(false, true) }
             else if (stat_partial) SBD_PRE_GO(true, false)
             else SBD_PRE_GO(false, false)
         } else if constexpr (WLOG2 == 2) {
-            if (ext_out || !stat_partial) return -3;
-            SBD_PRE_GO(true, false)
+            if (ext_out) return -3;
+            if (stat_partial) SBD_PRE_GO(true, false) else SBD_PRE_GO(false, false)
         } else
             return -3;
 #undef SBD_PRE_GO
@@ -763,7 +764,7 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
     return 0;
 }
 
-int conv64_fwd_sb_takes_pre(int W) { return (W == 16 || W == 4) && g_conv64_dbuf && !g_mfma_one; }      // W = 4: with BatchNorm statistics (training) only
+int conv64_fwd_sb_takes_pre(int W) { return (W == 16 || W == 4) && g_conv64_dbuf && !g_mfma_one; }
 int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z,
                          float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale, const float* pre_shift, float* pre_out,
                          const float* ext_gamma, float* ext_out) {
