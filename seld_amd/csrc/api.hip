@@ -943,15 +943,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             launch_bn_eval_coeffs(st, c->params + L.g_off, c->params + L.be_off, c->state + L.mm_off, c->state + L.mv_off,
                                   L.scale, L.shift, 64);
         snprintf(tn, sizeof tn, "pool%d_fwd", (int)i + 1);
-        {
+        // options "conv2_pre_fused" / "conv3_pre_fused" (default 1): the pass is folded into the NEXT block's region load (pre_next: the first block's
+        // BatchNorm + ReLU over its window extremes; ext_now: the second block's (1,4) pooling, whose extremes its own epilogue kept) — no launch here
+        if (pre_next || ext_now)
+            pre_pending = true;
+        else {
             PROF2(c, tn);
-            // option "conv2_pre_fused" (default 1): with the Gram backward (zext kept beside p) and a second block on the double-buffered split-bf16
-            // kernel, the pass is folded into that block's region load; not with Dropout behind the pool (it reads p right away)
-            if (pre_next)
-                pre_pending = true;
-            else if (ext_now)       // the next block's loader pools: see the convolution's launch above
-                pre_pending = true;
-            else if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
+            if (fused_pool)     // elementwise over zext (in place unless the backward keeps zext)
                 launch_bn_relu_ext(st, gram ? L.zext : L.p, L.scale, L.shift, L.p, (int64_t)B * (L.H / 5) * 16 * 64);
             else if (launch_bn_relu_pool_fwd(st, L.z, L.scale, L.shift, L.p, B, L.H, L.W, 64, L.pt, L.pf))
                 return fail(c, SELD_ERR_UNSUPPORTED, "bn_relu_pool_fwd");
