@@ -3,6 +3,7 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (no launcher: bench.py starts its own N rank processes, spawn_ranks)
 
 A "step" is one reference train.trainstep (train.py:22-36: forward(training) + BCE/MSE losses +
 gradients + Adam) on one synthetic batch of B clips of [T=3000, F=64, C=7] per GPU (weak scaling:
@@ -137,6 +138,48 @@ def kernel_work(name, B, T, F=64, C=7):
 
 RESNET_BLOCKS = [3, 4, 6, 3]      # model_config/resnet50_gru.json:5
 N_PARAMS = 513840                 # seldnet.json; main() sets the timed model's count
+
+
+# profiles/traffic.json group -> the kernel source it was measured on (tools/pmc_traffic.py stores every source's hash beside the figures)
+TRAFFIC_SOURCE = {"conv1_fwd": "conv_pool_sb.hip", "conv1_fwd_f32": "conv_pool.hip", "conv1_wgrad": "conv_gram.hip", "conv1_gram": "conv_gram.hip",
+                  "conv1_wgrad_fused": "conv.hip", "gru_fwd": "gru.hip", "gru_bwd": "gru.hip", "conv64_fwd_dgrad_W16": "conv_sb.hip",
+                  "conv64_fwd_dgrad_W4": "conv_sb.hip", "conv64_fwd_dgrad_W16_sbr": "conv_sb.hip", "conv64_fwd_dgrad_W4_sbr": "conv_sb.hip",
+                  "conv2_wgrad": "conv_wgrad_sb.hip", "conv3_wgrad": "conv_wgrad_sb.hip", "conv2_wgrad_f32": "conv.hip", "conv3_wgrad_f32": "conv.hip",
+                  "pool1_fwd": "conv_pool.hip", "gemm": "gemm.hip", "gemm_tn": "gemm.hip", "gemm_sb_4wave": "gemm_sb.hip", "gemm_sb_16wave": "gemm_sb.hip",
+                  "feat_dft": "features.hip", "feat_frame": "features.hip", "feat_frame_workgroup": "features.hip", "feat_topdb": "features.hip"}
+
+
+def load_traffic(path=None, csrc=None):
+    """profiles/traffic.json (a STORED rocprofv3 --pmc pass: FETCH_SIZE / WRITE_SIZE cannot be collected inside a timed run) with every
+    figure whose kernel source (or common.h) has changed since that pass REMOVED: a stale byte count is worse than `traffic: null`.
+    A table without `_source_hashes` (collected before the hashes existed) cannot be checked and is dropped whole."""
+    import hashlib
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    csrc = csrc or os.path.join(ROOT, "seld_amd", "csrc")
+    if not os.path.exists(path):
+        return {}
+    tab = json.load(open(path))
+    stored = tab.get("_source_hashes")
+    if not isinstance(stored, dict):
+        return {"_dropped": sorted(k for k in tab if not k.startswith("_")), "_provenance": str(tab.get("_provenance", "")) + " (no source hashes: dropped)"}
+
+    def cur(f):
+        fp = os.path.join(csrc, f)
+        return hashlib.sha256(open(fp, "rb").read()).hexdigest()[:16] if os.path.exists(fp) else None
+
+    common_ok = cur("common.h") == stored.get("common.h")
+    out, dropped = {}, []
+    for k, v in tab.items():
+        if k.startswith("_"):
+            out[k] = v
+            continue
+        src = TRAFFIC_SOURCE.get(k)
+        if src and common_ok and cur(src) == stored.get(src):
+            out[k] = v
+        else:
+            dropped.append(k)
+    out["_dropped"] = dropped
+    return out
 
 
 def host_cores():
@@ -342,9 +385,11 @@ def rooflines(kernels, B, T, steps, opts, traffic_tab, valu_clock_mhz, per_step_
                      "frac_of_fp32_peak_of_used_cus": round(floor / cyc, 4),
                      "clock_MHz": round(valu_clock_mhz), "phase_split": "profiles/r03_gru_experiments.txt (in-kernel timeline: the two waves of a SIMD "
                      "queue; gate tail = a chain of ~20 dependent VALU ops at 8.3-17.6 cycles each)"}
-        tr = traffic_tab.get(name, {}).get("hbm_bytes_per_launch")
+        tr = (traffic_tab.get(name) or {}).get("hbm_bytes_per_launch") if isinstance(traffic_tab.get(name), dict) else None
         if tr is not None:      # a STORED counter pass (another run of the build named in the table), never this run's
             extra["traffic_source"] = "profiles/traffic.json: " + str(traffic_tab.get("_provenance", ""))[:90]
+        elif name in traffic_tab.get("_dropped", ()):
+            extra["traffic_source"] = "profiles/traffic.json: stored figure dropped (kernel source changed since the counter pass)"
         return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                 "frac": round(ach / peak, 4), "traffic": tr,
                 "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // steps, "ms_per_step": round(ms / steps, 4),
@@ -565,6 +610,50 @@ def conv_stack_mfma(per_kernel):
     return {"useful_frac_of_ceiling": round(fl / pk, 4), "TFLOPs_fp32_equivalent": round(fl / t, 1), "ms_per_step": round(t, 4)}
 
 
+def spawn_ranks(n):
+    """Launcher for `python bench.py --gpus N` run WITHOUT torch.distributed.run: N child processes of this same command line, one per
+    GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (rendezvous on 127.0.0.1, a free port).  The parent never
+    touches the GPU (children are fresh interpreters started before any HIP call; nothing is exec'd over an initialised process).  Rank 0's
+    stdout is passed through unchanged, so its compact record stays the LAST stdout line; the other ranks' stdout goes to stderr with a
+    rank prefix.  Returns the first non-zero exit code (the remaining ranks are then terminated), else 0."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.PIPE, stderr=None, text=True))
+
+    def relay(r, p):
+        for line in p.stdout:
+            sys.stderr.write(f"[rank {r}] {line}")
+
+    threads = [threading.Thread(target=relay, args=(r, p), daemon=True) for r, p in enumerate(procs) if r]
+    for t in threads:
+        t.start()
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                for q in live:
+                    procs[q].terminate()        # the exact children started above, by handle
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -601,11 +690,25 @@ def main():
     if args.batch is None:
         args.batch = 16 if args.model == "resnet50_gru" else 32
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: this process becomes the launcher (it has made no GPU call yet and makes
+        # none) and starts one fresh rank process per GPU; under torch.distributed.run WORLD_SIZE is set and this branch is not taken
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    probe = os.environ.get("SELD_BENCH_LAUNCH_PROBE")
+    if probe:       # tests/test_host_logic_cpu.py: what a rank was started with, before anything touches a GPU ("fail1": rank 1 fails, the rest linger)
+        print(json.dumps({"rank": rank, "local": local, "world": world, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "argv": sys.argv[1:]}), flush=True)
+        if probe == "fail1":
+            if rank == 1:
+                raise SystemExit(3)
+            time.sleep(60)
+        raise SystemExit(0)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or unset WORLD_SIZE and let "
+                         f"bench.py start its own ranks")
     # rehearsal of the N > 1 code path on a one-GPU box (tests/test_dp_gpu.py::test_bench_two_ranks_rehearsal): every rank on device
     # SELD_BENCH_DEVICE over the gloo backend (RCCL refuses two ranks on one device).  The driver's runs set neither variable.
     if os.environ.get("SELD_BENCH_DEVICE") is not None:
@@ -638,8 +741,7 @@ def main():
         model = res["model"]
         mhz = C.c_double()
         valu_clock_mhz = float(mhz.value) if model.lib.seld_k_valu_clock_mhz(2 * B, C.byref(mhz)) == 0 else None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
+        traffic_tab = load_traffic()
         out = record(args.model, B, T, args.steps, args.warmup, world, res, args.opt, traffic_tab, valu_clock_mhz, args.with_features)
         out["conv_stack_mfma"] = conv_stack_mfma(out["roofline_by_kernel"])
         out["peaks_on_box"] = box_peaks(model.lib, local)
@@ -648,9 +750,9 @@ def main():
         if world == 1 and not args.no_features:
             out["features"] = features_leg(dev)
             # PMC bytes of the extraction kernel per LAUNCH (tools/bench_features.py: 8 clips per launch) -> per clip, like `achieved`
-            ft = traffic_tab.get("feat_dft", traffic_tab.get("feat_frame", {})).get("hbm_bytes_per_launch")
-            out["features"]["roofline"]["traffic"] = None if ft is None else int(ft / (8 if "feat_dft" in traffic_tab else 1))
-            out["features"]["roofline"]["kernel"] = "feat_dft" if "feat_dft" in traffic_tab else "feat_frame"
+            ft = (traffic_tab.get("feat_dft") or {}).get("hbm_bytes_per_launch")
+            out["features"]["roofline"]["traffic"] = None if ft is None else int(ft / 8)
+            out["features"]["roofline"]["kernel"] = "feat_dft"
         del model
         res["model"] = None
         if world == 1 and args.model == "seldnet" and not args.no_inference and not args.opt:

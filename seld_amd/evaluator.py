@@ -23,6 +23,8 @@ def ensemble_outputs(model: SeldNet, xs: list, win_size: int = 300, step_size: i
         raise ValueError(f"model was built for {T_model}-frame windows, not {win_size}")
     batch_size = min(batch_size, Bm)
     lib, dev = model.lib, model._dev
+    fused = isinstance(model, SeldNet)      # a fused seld_ctx writes its outputs in place; a modules.ComposedSeldNet (FIRST = mother_block /
+                                            # mother_stage) has no ctx: its forward is called per batch and the outputs copied into place
     st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     L = model.S
     if L * step_size != win_size:
@@ -31,7 +33,10 @@ def ensemble_outputs(model: SeldNet, xs: list, win_size: int = 300, step_size: i
     # work buffers live with the model (one set per (windows, batch) geometry): a file costs its kernels, not three allocations and
     # two device-to-device copies per batch
     cache = model.__dict__.setdefault("_infer_bufs", {})
-    _lib.check(lib.seld_set_stream(model.ctx, st()), model.ctx)
+    if fused:
+        _lib.check(lib.seld_set_stream(model.ctx, st()), model.ctx)
+    elif not callable(model):
+        raise ValueError(f"ensemble_outputs: {type(model).__name__} is neither a SeldNet nor a composed model")
     for x in xs:
         x = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x).to(dev, torch.float32).contiguous()
         T = int(x.shape[0])
@@ -49,13 +54,20 @@ def ensemble_outputs(model: SeldNet, xs: list, win_size: int = 300, step_size: i
             w0 = i * batch_size
             n = min(batch_size, n_win - w0)
             _lib.check(lib.seld_frame_windows(x.data_ptr(), win.data_ptr(), T, F * Cc, win_size, step_size, w0, n, st()))
-            _lib.check(lib.seld_set_batch(model.ctx, n), model.ctx)
-            # the forward writes its outputs straight into rows [w0, w0 + n) of the per-window tensors
-            _lib.check(lib.seld_forward(model.ctx, win.data_ptr(), seds[w0:].data_ptr(), doas[w0:].data_ptr(), 0), model.ctx)
+            if fused:
+                _lib.check(lib.seld_set_batch(model.ctx, n), model.ctx)
+                # the forward writes its outputs straight into rows [w0, w0 + n) of the per-window tensors
+                _lib.check(lib.seld_forward(model.ctx, win.data_ptr(), seds[w0:].data_ptr(), doas[w0:].data_ptr(), 0), model.ctx)
+            else:
+                s_, d_ = model(win[:n], training=False)
+                seds[w0:w0 + n].copy_(s_)
+                doas[w0:w0 + n].copy_(d_)
         T_out = n_win - 1 + L
         sed = torch.empty((T_out, model.n_classes), dtype=torch.float32, device=dev)
         doa = torch.empty((T_out, 3 * model.n_classes), dtype=torch.float32, device=dev)
         _lib.check(lib.seld_overlap_average(seds.data_ptr(), sed.data_ptr(), n_win, L, model.n_classes, st()))
         _lib.check(lib.seld_overlap_average(doas.data_ptr(), doa.data_ptr(), n_win, L, 3 * model.n_classes, st()))
         out.append((sed, doa))
+    if fused:
+        _lib.check(lib.seld_set_batch(model.ctx, Bm), model.ctx)      # leave the context at the batch it was built for, as it was found
     return out

@@ -565,8 +565,10 @@ class ComposedSeldNet:
             x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self._dev)
         x = x.to(torch.float32).contiguous()
         Bm, T, Fq, Ch = self.input_shape
-        if tuple(x.shape[1:]) != (T, Fq, Ch) or x.shape[0] != Bm:
-            raise ValueError(f"x shape {tuple(x.shape)}: a composed model runs the batch it was built for, {self.input_shape}")
+        # any batch 1 <= B <= the one the buffers were sized for, as SeldNet._prep: train.main builds the model for the largest of the train /
+        # val / test batch sizes and every loader ends on a ragged batch (drop_remainder=False)
+        if tuple(x.shape[1:]) != (T, Fq, Ch) or not 1 <= x.shape[0] <= Bm:
+            raise ValueError(f"x shape {tuple(x.shape)}: a composed model built for {self.input_shape} runs batches of 1..{Bm} clips of {(T, Fq, Ch)}")
         return x
 
     def _forward(self, x, training: bool):
@@ -596,11 +598,11 @@ class ComposedSeldNet:
             for lay in Hd["layers"]:
                 lay["x"] = a
                 rt.gemm(a, rt.w(lay["n"] + ".kernel"), rt.w(lay["n"] + ".bias"), lay["pre"], R, lay["out"], lay["in"])
-                rt.act(lay["pre"], lay["y"], Hd["hact"])
+                rt.act(lay["pre"][:R], lay["y"][:R], Hd["hact"])         # the buffers hold the LARGEST batch's rows: this batch's R only
                 a = lay["y"]
             Hd["x"] = a
             rt.gemm(a, rt.w(Hd["name"] + ".out.kernel"), rt.w(Hd["name"] + ".out.bias"), Hd["pre"], R, Hd["out"], Hd["in"])
-            rt.act(Hd["pre"], out.view(R, -1), Hd["act"])
+            rt.act(Hd["pre"][:R], out.view(R, -1), Hd["act"])
         return sed, doa
 
     def __call__(self, x, training: bool = False):
@@ -622,7 +624,7 @@ class ComposedSeldNet:
                 rt.gemm(Hd["dpre"], rt.w(n + ".out.kernel"), None, self.dfeat, R, Hd["in"], Hd["out"], transb=1, accumulate=0 if first else 1)
             for j in range(len(Hd["layers"]) - 1, -1, -1):
                 lay = Hd["layers"][j]
-                rt.act_bwd(lay["pre"], lay["dy"], lay["dpre"], Hd["hact"])
+                rt.act_bwd(lay["pre"][:R], lay["dy"][:R], lay["dpre"][:R], Hd["hact"])
                 rt.gemm_tn(lay["x"], lay["dpre"], rt.g(lay["n"] + ".kernel"), rt.g(lay["n"] + ".bias"), R, lay["in"], lay["out"])
                 if j > 0:
                     rt.gemm(lay["dpre"], rt.w(lay["n"] + ".kernel"), None, Hd["layers"][j - 1]["dy"], R, lay["in"], lay["out"], transb=1)
@@ -643,7 +645,7 @@ class ComposedSeldNet:
                 rt.gemm_tn(G["h"][d], G["dgh"][d], rt.g(f"gru{i}.{dn}.recurrent_kernel"), gb[384:], R, 128, 384, seq=self.S, shift=-1 if d == 0 else 1)
                 rt.gemm(G["dgx"][d], rt.w(f"gru{i}.{dn}.kernel"), None, G["din"], R, G["in"], 384, transb=1, accumulate=d)
             dout = G["din"]
-        dy = dout.view(B, *self.blocks[-1].out_shape)
+        dy = dout[:R].view(B, *self.blocks[-1].out_shape)
         for bi in range(len(self.blocks) - 1, -1, -1):
             dy = self.blocks[bi].backward(dy, None, B)
 

@@ -104,21 +104,27 @@ def test_two_process_dp_step_equals_single_process_batch(mode, sync_bn):
             off += n
 
 
-@pytest.mark.parametrize("model", ["seldnet", "xception_gru", "resnet50_gru"])
-def test_bench_two_ranks_rehearsal(model):
+@pytest.mark.parametrize("launcher,model", [("torchrun", "seldnet"), ("torchrun", "xception_gru"), ("torchrun", "resnet50_gru"), ("self", "seldnet")])
+def test_bench_two_ranks_rehearsal(launcher, model):
     """bench.py's N > 1 code path (rank environment, barrier + max-over-ranks timing, the gradient buckets, the exposed-communication
     leg, rank 0's JSON line) run as the driver launches it — `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` —
     but with both ranks on the one test GPU over gloo (SELD_BENCH_DEVICE / SELD_BENCH_BACKEND): a crash in this path would cost the
     round its scaling curve.  The block models too: their kernel gradients finish on the side stream, which the last gradient bucket
-    has to wait for."""
+    has to wait for.  launcher = "self": the same run as plain `python bench.py --gpus 2` — bench.py starts its two ranks itself
+    (spawn_ranks), which is what a driver command without torch.distributed.run gets."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, SELD_BENCH_DEVICE="0", SELD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     port = 31500 + os.getpid() % 400 + 400 * ["seldnet", "xception_gru", "resnet50_gru"].index(model)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4", "--frames", "300", "--model", model]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4", "--frames", "300", "--model", model]
+    if launcher == "self":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

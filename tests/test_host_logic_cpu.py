@@ -243,3 +243,62 @@ def test_bench_last_line_is_a_compact_record():
     full["config"]["workload"] = "w" * 2500
     full["cpu_baseline"]["sample"] = "s" * 2500
     assert len(bench.compact_record(full, "x" * 200)) < 3072
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no outer launcher (VERDICT r4 #6): bench.py becomes the launcher — N fresh rank processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set on 127.0.0.1, rank 0's stdout last on the launcher's stdout, a failing rank's exit
+    code propagated and the lingering ranks stopped.  SELD_BENCH_LAUNCH_PROBE makes every rank report what it was started with and leave
+    before anything touches a GPU (the full two-rank run on a GPU is tests/test_dp_gpu.py::test_bench_two_ranks_rehearsal[self-...])."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=dict(env, SELD_BENCH_LAUNCH_PROBE="ok"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["rank"] == 0 and out[0]["world"] == 2 and out[0]["local"] == 0, "only rank 0 writes to the launcher's stdout"
+    assert out[0]["master"].startswith("127.0.0.1:") and out[0]["argv"] == cmd[2:]
+    other = [json.loads(l.split("] ", 1)[1]) for l in r.stderr.splitlines() if l.startswith("[rank 1] {")]
+    assert len(other) == 1 and other[0]["rank"] == 1 and other[0]["local"] == 1 and other[0]["master"] == out[0]["master"]
+    # under an outer launcher (WORLD_SIZE set) nothing is spawned: the process IS the rank
+    r = subprocess.run(cmd, env=dict(env, SELD_BENCH_LAUNCH_PROBE="ok", WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["rank"] == 1
+    # a failing rank: its code comes back, and the rank that would have lingered for a minute is stopped
+    t0 = time.time()
+    r = subprocess.run(cmd, env=dict(env, SELD_BENCH_LAUNCH_PROBE="fail1"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 3 and time.time() - t0 < 45, (r.returncode, time.time() - t0)
+
+
+def test_stored_traffic_figures_are_dropped_when_their_kernel_source_changes(tmp_path):
+    """bench.py's `roofline.traffic` comes from a STORED counter pass (profiles/traffic.json).  A figure survives only while the source
+    of its kernel (and common.h) hashes to what tools/pmc_traffic.py recorded beside it (VERDICT r4 weak #14)."""
+    import hashlib
+    import json
+    import bench
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    for f, body in (("gru.hip", b"gru v1"), ("conv_sb.hip", b"conv v1"), ("common.h", b"common")):
+        (csrc / f).write_bytes(body)
+    h = lambda b: hashlib.sha256(b).hexdigest()[:16]
+    tab = {"_provenance": "test", "_source_hashes": {"gru.hip": h(b"gru v1"), "conv_sb.hip": h(b"conv v1"), "common.h": h(b"common")},
+           "gru_fwd": {"hbm_bytes_per_launch": 1}, "conv64_fwd_dgrad_W4": {"hbm_bytes_per_launch": 2}, "unknown_group": {"hbm_bytes_per_launch": 3}}
+    p = tmp_path / "traffic.json"
+    p.write_text(json.dumps(tab))
+    got = bench.load_traffic(str(p), str(csrc))
+    assert got["gru_fwd"]["hbm_bytes_per_launch"] == 1 and "conv64_fwd_dgrad_W4" in got and got["_dropped"] == ["unknown_group"]
+    (csrc / "gru.hip").write_bytes(b"gru v2")
+    got = bench.load_traffic(str(p), str(csrc))
+    assert "gru_fwd" not in got and "conv64_fwd_dgrad_W4" in got and "gru_fwd" in got["_dropped"]
+    (csrc / "common.h").write_bytes(b"common v2")
+    assert [k for k in bench.load_traffic(str(p), str(csrc)) if not k.startswith("_")] == []
+    del tab["_source_hashes"]
+    p.write_text(json.dumps(tab))
+    assert [k for k in bench.load_traffic(str(p), str(csrc)) if not k.startswith("_")] == []
+    # the committed table is consistent with bench.py's group -> source map
+    real = json.load(open(os.path.join(bench.ROOT, "profiles", "traffic.json")))
+    assert all(k in bench.TRAFFIC_SOURCE for k in real if not k.startswith("_"))

@@ -142,3 +142,90 @@ def test_train_step_with_a_mother_stage_first_block(seldnet_config, doa_loss):
     check("mother_stage model BN state", st1, ref["new_state"])
     big = np.abs(ref["grad"]) > 1e-3 * np.abs(ref["grad"]).max()
     assert np.abs(w1 - ref["new_w"])[big].max() <= 2e-3 * 1e-3 + 1e-7       # Adam's first step moves a weight by lr g / (|g| + eps)
+
+
+STAGE_FIRST = {'depth': 2, 'filters0': 16, 'filters1': 24, 'filters2': 0, 'kernel_size0': 3, 'kernel_size1': 3, 'kernel_size2': 0,
+               'connect0': [1], 'connect1': [0, 1], 'connect2': [1, 0, 1], 'strides': [5, 4], 'activation': 'relu',
+               'squeeze_ratio': 0.5, 'se_activation': 'swish'}
+
+
+def test_composed_model_runs_any_batch_up_to_the_one_it_was_built_for(seldnet_config):
+    """train.main builds ONE model for max(train, val, test batch) and every loader ends on a ragged batch, so a
+    composed model must take 1 <= B <= Bmax like SeldNet does.  A model built for 5 clips, given 3 (train step) and 1 (test step), gives
+    bit for bit what models built for exactly 3 / 1 clips give; 6 clips are refused; the sliding-window inference path
+    (evaluator.ensemble_outputs) takes a composed model and equals the forward on hand-framed windows."""
+    from oracle import modules_oracle as M
+    from oracle import seldnet_oracle as O
+    from seld_amd import evaluator, losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST"], cfg["FIRST_ARGS"] = "mother_stage", STAGE_FIRST
+    T = 50
+    w, st = M.random_weights(cfg, (5, T, 64, 7), seed=3)
+    x, ys, yd = O.synthetic_batch(5, T, seed=9)
+    args = (losses.BinaryCrossentropy(), losses.MSE)
+
+    def run(Bm, B):
+        m = models.seldnet((Bm, T, 64, 7), cfg)
+        m.set_weights(w, st)
+        yt, _, dt = train.teststep(m, x[:1], (ys[:1], yd[:1]), *args)
+        yp, sl, dl = train.trainstep(m, x[:B], (ys[:B], yd[:B]), *args, (1.0, 1000.0), train.Adam(1e-3))
+        torch.cuda.synchronize()
+        return [t.cpu().numpy().copy() for t in (yt[0], yt[1], dt, yp[0], yp[1], sl, dl)] + [m.get_grads(), m.get_weights()[0]], m
+
+    big, m5 = run(5, 3)
+    exact, _ = run(3, 3)
+    assert big[3].shape == (3, T // 5, 12) and big[0].shape == (1, T // 5, 12)
+    for a, b in zip(big, exact):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        m5(np.zeros((6, T, 64, 7), np.float32))
+    # evaluator.ensemble_outputs on a composed model: windows of T frames, step 5, batches of 4 (the last one ragged)
+    clip = torch.as_tensor(np.random.default_rng(1).standard_normal((T + 45, 64, 7)).astype(np.float32)).cuda()
+    (sed, doa), = evaluator.ensemble_outputs(m5, [clip], win_size=T, step_size=5, batch_size=4)
+    wins = torch.stack([clip[5 * i:5 * i + T] for i in range(10)])
+    s_ref = torch.cat([m5(wins[i:i + 5], training=False)[0].clone() for i in (0, 5)])
+    L = T // 5
+    acc, cnt = torch.zeros((9 + L, 12), device="cuda"), torch.zeros((9 + L, 1), device="cuda")
+    for i in range(10):
+        acc[i:i + L] += s_ref[i]
+        cnt[i:i + L] += 1
+    check("composed ensemble_outputs sed", sed.cpu().numpy(), (acc / cnt).cpu().numpy())
+    assert tuple(doa.shape) == (9 + L, 36) and bool(torch.isfinite(doa).all())
+
+
+def test_main_loop_with_a_mother_stage_first_block(tmp_path, seldnet_config, monkeypatch):
+    """reference train.main (train.py:264-390) with FIRST = mother_stage: the epoch loop's train / val / test passes run batches smaller
+    than the one the model was built for (one file per val / test batch, ragged last batches) through the composed model; the loss
+    decreases, the best weights are saved and --resume loads them."""
+    import json
+    from seld_amd import params, train
+    root = tmp_path / "DCASE2021" / "feat_label"
+    feat, lab = root / "foa_dev_norm", root / "foa_dev_label"
+    feat.mkdir(parents=True), lab.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for fold in range(1, 7):
+        name = f"fold{fold}_room1_mix000.npy"
+        np.save(feat / name, rng.standard_normal((3000, 64, 7)).astype(np.float32))
+        sed = (rng.random((600, 12)) < 0.1).astype(np.float32)
+        vec = rng.standard_normal((600, 3, 12)); vec /= np.linalg.norm(vec, axis=1, keepdims=True)
+        np.save(lab / name, np.concatenate([sed, (vec * sed[:, None, :]).reshape(600, 36)], -1).astype(np.float32))
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST"], cfg["FIRST_ARGS"] = "mother_stage", dict(STAGE_FIRST, filters0=8, filters1=8)
+    mcd = tmp_path / "model_config"
+    mcd.mkdir()
+    (mcd / "seldnet.json").write_text(json.dumps(cfg))
+    monkeypatch.chdir(tmp_path)
+    config, mc = params.get_param(["--name", "ms", "--abspath", str(tmp_path) + "/", "--batch", "16", "--loop_time", "1", "--epoch", "2", "--lr", "0.001"],
+                                  model_config_dir=str(mcd))
+    ds = [train.get_dataset(config, m) for m in ("train", "val", "test")]
+    sizes = {int(np.asarray(b[0].shape[0] if hasattr(b[0], "shape") else len(b[0]))) for d in ds for b in d}
+    assert len(sizes) > 1, "the three passes must present more than one batch size for this test to mean anything"
+    model, hist = train.main((config, mc))
+    assert type(model).__name__ == "ComposedSeldNet" and len(hist) == 2
+    assert all(np.isfinite(h["score"]) and np.isfinite(h["test"][0]) for h in hist) and hist[-1]["train"][1] < hist[0]["train"][1]
+    saved = list((tmp_path / "saved_model" / config.name).glob("bestscore_*.npz"))
+    assert len(saved) == 1
+    config_r, _ = params.get_param(["--name", "ms", "--abspath", str(tmp_path) + "/", "--batch", "16", "--loop_time", "1", "--epoch", "1", "--resume"],
+                                   model_config_dir=str(mcd))
+    _, h2 = train.main((config_r, mc))
+    assert h2[0]["train"][1] < hist[0]["train"][1]

@@ -3,9 +3,20 @@
 (FETCH_SIZE/WRITE_SIZE count KiB; gfx950 reports half of a wide coalesced read stream).
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <provenance note> > traffic.json"""
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seld_amd", "csrc")
+
+
+def source_hashes():
+    """sha256 (16 hex) of every kernel source: bench.py drops a stored figure whose kernel's source has changed since the counter pass."""
+    return {f: hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()[:16]
+            for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))}
+
 
 GROUPS = {  # bench.py timer group -> kernel-name substring
     "conv1_fwd": "conv_first_fwd_pool_sb_kernel", "conv1_fwd_f32": "conv_first_fwd_pool_kernel",
@@ -33,7 +44,7 @@ def per_kernel(path, counter):
 
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_provenance": sys.argv[3]}
+out = {"_provenance": sys.argv[3], "_source_hashes": source_hashes()}
 for grp, pat in GROUPS.items():
     names = [k for k in fetch if pat in k]
     if not names:
