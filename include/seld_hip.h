@@ -132,7 +132,11 @@ int seld_sync(seld_ctx* ctx);
  * the f32-input MFMA GEMM.  "conv1_split_bf16" (default 1): the same scheme for the first
  * block's forward whenever its pre-BN tensor is not stored (conv_pool_sb.hip).  "conv1_pool_fused" / "conv1_gram" (default 1): first block's pooling inside the conv
  * epilogue / its kernel gradient from the patch Gram matrix.  "dropout_seed" / "dropout_step" (values): the key of the heads' dropout
- * draws and the step counter of the next training forward (seld_arch.sed_dropout / doa_dropout; INTEGRATION.md section 6 lists every key). */
+ * draws and the step counter of the next training forward (seld_arch.sed_dropout / doa_dropout; INTEGRATION.md section 6 lists every key).
+ * EVERY key is per context: the kernel choices the launchers read from library-wide variables ("bwd_four_products", "gru_var" 0..255,
+ * "conv64_dbuf", "tn_tile_blocks", "tn_lds_floor", "gram_bg_blocks", "bf16_single") are stored in the context and copied into those
+ * variables at the start of each forward / backward pass, so a six-product context and a four-product context coexist in one process
+ * (calls on one context are not thread-safe; two contexts driven from two threads at once are not supported for differing choices). */
 int seld_set_option(seld_ctx* ctx, const char* key, int value);
 
 /* ---- variables: replaces model.trainable_variables / get_weights / set_weights
@@ -184,6 +188,8 @@ int seld_set_sync_bn(seld_ctx* ctx, seld_allreduce_fn fn, void* user, int world)
 /* ---- data parallelism INSIDE the library: one process per GPU, a full weight replica per rank, the
  * batch sharded by clips; the reference has no counterpart (train.py:22-36 is single device).  The library owns an RCCL communicator
  * (RCCL is bound with dlopen at the first seld_dp_* call: no link-time dependency), a communication stream and the bucket order.
+ *   seld_dp_available()              : 1 if RCCL could be bound in this process, else 0 — what every rank OTHER than 0 calls before the
+ *                                      host's agreement step (ncclGetUniqueId starts a bootstrap listener: only rank 0 draws an id)
  *   seld_dp_unique_id(id)            : rank 0 fills 128 bytes (ncclUniqueId); the host carries them to every rank by its own means
  *   seld_dp_init(ctx, rank, world, id): ncclCommInitRank on the ctx's device (collective: every rank calls it)
  *   seld_dp_allreduce_grads(ctx)     : between seld_train_fwd_bwd and seld_adam_step — TWO in-place ncclAllReduce(SUM) over the flat
@@ -193,6 +199,7 @@ int seld_set_sync_bn(seld_ctx* ctx, seld_allreduce_fn fn, void* user, int world)
  *   MMSE loss: with a communicator and cfg.mmse_den <= 0 the mask count is all-reduced on the device inside seld_train_fwd_bwd /
  *              seld_test_step; the caller sets cfg.sed_grad_scale = 1 / world (loss-reduction rules: DESIGN.md section 5)
  * A failed collective is fatal for the process group: peers block in theirs — abort the job. */
+int seld_dp_available(void);
 int seld_dp_unique_id(void* id_out_128_bytes);
 int seld_dp_init(seld_ctx* ctx, int rank, int world, const void* unique_id_128_bytes);
 int seld_dp_world(const seld_ctx* ctx);
@@ -292,7 +299,10 @@ int seld_profile_reset(seld_ctx* ctx);
 /* ---- per-kernel entry points (unit parity tests; all device pointers, null stream) --------
  * Each cites what it computes in the reference.  Shapes are checked; SELD_ERR_UNSUPPORTED if
  * the build has no kernel for them. */
-int seld_k_set_option(const char* key, int value); /* same keys as seld_set_option, for the seld_k_* entry points */
+/* same keys as seld_set_option, for the seld_k_* entry points: PROCESS-WIDE (there is no context).  Defaults: the product's
+ * ("bwd_four_products" 1: the unit entry points' backward products also run on four of the six split terms); a forward / backward pass of
+ * any context overwrites them with that context's choices, so set them right before the seld_k_* calls they are meant for. */
+int seld_k_set_option(const char* key, int value);
 /* Conv2D(64, 3, padding='same', use_bias=True) on NHWC (layers.py:27-32); x [B,H,W,Cin], w HWIO, z [B,H,W,64].
  * stats (may be NULL): [2*64] = per-channel sum(z), sum(z^2) over B*H*W (BatchNormalization batch statistics). */
 int seld_k_conv3x3_fwd(const float* x, const float* w, const float* bias, float* z, float* stats,

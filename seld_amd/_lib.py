@@ -89,6 +89,7 @@ SIGNATURES = {
     "seld_grads_bucket_count": (_I, [_P]),
     "seld_grads_bucket_ready": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_L)]),
     "seld_set_sync_bn": (_I, [_P, _P, _P, _I]),
+    "seld_dp_available": (_I, []),
     "seld_dp_unique_id": (_I, [_P]),
     "seld_dp_init": (_I, [_P, _I, _I, _P]),
     "seld_dp_world": (_I, [_P]),

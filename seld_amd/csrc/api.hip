@@ -148,6 +148,9 @@ struct seld_ctx {
     double* sync_buf = nullptr;                   // [128] (resnet50_block: [16][128]) sums handed to sync_fn
     bool sync_failed = false;                     // the all-reduce callback failed inside a helper: reported at the end of the pass
     int bf16_single = 0;                          // SELD_DTYPE_BF16 / option "bf16_single": one bf16 MFMA product per fp32 product (common.h g_mfma_one)
+    // kernel choices the launchers read from process-wide variables (common.h): kept PER CONTEXT here and copied into those variables at the
+    // start of every forward / backward pass (apply_kernel_choices), so that setting one on a context never changes another context's arithmetic
+    int bwd_four_products = 1, gru_var = 11, conv64_dbuf = 1, tn_tile_blocks = 384, tn_lds_floor = 0, gram_bg_blocks = 192;
     // data parallelism inside the library (seld_dp_*): one RCCL communicator, a communication stream, two events
     void* dp_comm = nullptr;                      // ncclComm_t
     int dp_rank = 0, dp_world = 1;
@@ -649,7 +652,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "dropout_seed")) { c->dropout_seed = 0x5e1d5e1d00000000ull ^ (uint64_t)(unsigned)value; return SELD_OK; }      // the masks are a function of (seed, step, layer, element)
     if (!strcmp(key, "dropout_step")) { c->dropout_step = (unsigned)value; return SELD_OK; }                                         // the NEXT training forward's step counter
     if (!strcmp(key, "conv1_split_bf16")) { c->conv1_split_bf16 = value != 0; return SELD_OK; }
-    if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { g_gram_bg_blocks = value; return SELD_OK; }   // tuning knob (process-wide)
+    if (!strcmp(key, "gram_bg_blocks") && value >= 16 && value <= 512) { c->gram_bg_blocks = value; return SELD_OK; }   // tuning knob
     if (!strcmp(key, "conv1_pool_fused")) { c->conv1_pool_fused = value != 0; return SELD_OK; }
     if (!strcmp(key, "conv1_gram")) { c->conv1_gram = value != 0; return SELD_OK; }
     if (!strcmp(key, "gru_wgrad_batch")) { c->gru_wgrad_batch = value != 0; return SELD_OK; }
@@ -663,11 +666,15 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "rn_implicit3x3")) { c->rn_implicit3x3 = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
-    if (!strcmp(key, "bwd_four_products")) { g_bwd_four = value != 0; return SELD_OK; }
-    if (!strcmp(key, "tn_tile_blocks") && value >= 64 && value <= 4096) { g_tn_tile_blocks = value; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
-    if (!strcmp(key, "gru_var")) { g_gru_var = value; return SELD_OK; }
-    if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { g_tn_lds_floor_kb = value; return SELD_OK; }   // experiment (process-wide): gemm_tn_sb.hip     // kernel choice (process-wide): gru.hip
-    if (!strcmp(key, "conv64_dbuf")) { g_conv64_dbuf = value != 0; return SELD_OK; }     // kernel choice (process-wide): conv_sb.hip
+    // per-context kernel choices (apply_kernel_choices copies them into the launchers' variables at the start of each pass)
+    if (!strcmp(key, "bwd_four_products")) { c->bwd_four_products = value != 0; return SELD_OK; }
+    if (!strcmp(key, "tn_tile_blocks") && value >= 64 && value <= 4096) { c->tn_tile_blocks = value; return SELD_OK; }     // gemm_tn_sb.hip
+    if (!strcmp(key, "gru_var")) {      // gru.hip: bit 0 forward VAR 1, bit 1 backward VAR 1, bit 3 falling priority, bits 4.. experimental bodies
+        if (value < 0 || value > 255) return fail(c, SELD_ERR_INVALID, "gru_var: 0..255");
+        c->gru_var = value; return SELD_OK;
+    }
+    if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
+    if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
     if (!strcmp(key, "bf16_single")) { c->bf16_single = value != 0; return SELD_OK; }     // = SELD_DTYPE_BF16 at seld_create
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -816,8 +823,19 @@ static int heads_couple(seld_ctx* c, float* doa, int rows) {
     return check_launch(c, "forward");
 }
 
+// the launchers' kernel-choice variables (common.h) take THIS context's values for the pass that starts here
+static void apply_kernel_choices(const seld_ctx* c) {
+    g_mfma_one = c->bf16_single;
+    g_bwd_four = c->bwd_four_products;
+    g_gru_var = c->gru_var;
+    g_conv64_dbuf = c->conv64_dbuf;
+    g_tn_tile_blocks = c->tn_tile_blocks;
+    g_tn_lds_floor_kb = c->tn_lds_floor;
+    g_gram_bg_blocks = c->gram_bg_blocks;
+}
+
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
-    g_mfma_one = c->bf16_single;      // process-wide kernel choice, read by the launchers this pass calls (common.h)
+    apply_kernel_choices(c);
     c->last_training = training;
     if (training) c->dropout_cur = c->dropout_step++;      // every training forward draws new masks (Keras), backward or not
     const bool conv_drop = training && c->arch.conv_dropout > 0.f, gru_drop = training && c->arch.gru_dropout > 0.f;
@@ -1359,7 +1377,7 @@ static void heads_lin_side(seld_ctx* c, int rows) {
 }
 
 static int backward_impl(seld_ctx* c, const float* x) {
-    g_mfma_one = c->bf16_single;
+    apply_kernel_choices(c);
     hipStream_t st = c->stream;
     // test aid: injected routing decisions edit the tensors the backward kernels read their decisions from (the forward is done with them)
     for (const auto& o : c->overrides) {
@@ -1837,6 +1855,9 @@ int seld_set_sync_bn(seld_ctx* c, seld_allreduce_fn fn, void* user, int world) {
 // one process per GPU, a full weight replica per rank, clips sharded; the library owns the communicator.
 // RCCL is bound at run time (dlopen: a process that already carries an RCCL, e.g. PyTorch's, is joined to THAT copy by its SONAME;
 // a plain C host gets /opt/rocm/lib's) so that libseld_hip.so has no link-time dependency on it and loads where RCCL is absent.
+int seld_dp_destroy(seld_ctx* c);
+int seld_dp_available(void) { return rccl().ok ? 1 : 0; }
+
 int seld_dp_unique_id(void* id_out) {
     if (!id_out) return SELD_ERR_INVALID;
     if (!rccl().ok) return SELD_ERR_UNSUPPORTED;
@@ -1863,8 +1884,10 @@ int seld_dp_init(seld_ctx* c, int rank, int world, const void* unique_id) {
     // (system-scope) release, as the bucket events have
     if (hipStreamCreateWithFlags(&c->dp_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_dp_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_dp_done, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_dp_done, hipEventDisableTiming) != hipSuccess) {
+        seld_dp_destroy(c);      // the communicator exists already: give it back, the context is as it was before the call
         return fail(c, SELD_ERR_HIP, "seld_dp_init: stream / event creation failed");
+    }
     return SELD_OK;
 }
 

@@ -301,6 +301,10 @@ int launch_colsum(hipStream_t st, const float* X, int ld, float* slab, int* nsla
 int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
                    const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b,
                    int B, int S, const float* rm_f = nullptr, const float* rm_b = nullptr, float* hm_f = nullptr, float* hm_b = nullptr);
+// gru_df.hip: the same recurrences without a workgroup barrier between steps (two wave groups, LDS step counters); option "gru_var" bit 4 / 5
+int launch_gru_fwd_df(hipStream_t st, const float* gx_f, const float* gx_b, const float* U_f, const float* U_b,
+                      const float* brec_f, const float* brec_b, float* h_f, float* h_b, float* sv_f, float* sv_b, int B, int S);
+int gru_df_trace_read(int which, unsigned long long* out);
 int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const float* h_b, const float* sv_f,
                    const float* sv_b, const float* U_f, const float* U_b, float* dgx_f, float* dgx_b,
                    float* dgh_f, float* dgh_b, int B, int S, const float* rm_f = nullptr, const float* rm_b = nullptr, const float* hm_f = nullptr,

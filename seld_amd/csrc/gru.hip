@@ -362,6 +362,7 @@ int launch_gru_fwd(hipStream_t st, const float* gx_f, const float* gx_b, const f
     }
 #define GRUF_GO(V_, SV_) hipLaunchKernelGGL((gru_fwd_kernel<V_, SV_>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S)
     const bool save = sv_f != nullptr;
+    if (g_gru_var & 16) return launch_gru_fwd_df(st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, B, S);      // gru_df.hip: no barrier between steps
     if ((g_gru_var & 9) == 9) {
         if (save) hipLaunchKernelGGL((gru_fwd_kernel<1, true, true>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S);
         else hipLaunchKernelGGL((gru_fwd_kernel<1, false, true>), dim3(2 * B), dim3(512), 0, st, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, sv_f, sv_b, S);
@@ -679,6 +680,7 @@ int launch_gru_bwd(hipStream_t st, const float* dout, const float* h_f, const fl
 
 // per-phase cycle sums of the last gru_fwd (which = 0) / gru_bwd (1) launch: out[blocks][4]; -2 unless built with -DGRU_TIMING
 int gru_timing_read(int which, unsigned long long* out, int blocks) {
+    if ((which == 6 || which == 7) && blocks == 128) { const int r_ = gru_df_trace_read(which - 6, out); return r_ == 1 ? 0 : r_; }      // gru_df.hip, -DDF_TRACE: [wave][16 steps][8]
 #ifdef GRU_TRACE2
     if ((which == 4 || which == 5) && blocks == 64) {    // trace2 of workgroup 0: [wave][step][stamp 0..5]
         hipDeviceSynchronize();

@@ -69,11 +69,15 @@ def init_library_dp(model, group=None, force: bool = False) -> bool:
             raise RuntimeError(f"library-owned RCCL communicator: {what} failed on "
                                + (f"this rank ({err})" if not ok else "another rank") + "; no rank enables the library path")
 
-    # 1. every rank binds RCCL and draws an id (rank 0's is the one that is used): the availability check happens BEFORE the broadcast
+    # 1. every rank binds RCCL; ONLY rank 0 draws an id (ncclGetUniqueId starts a bootstrap listener thread + socket: an id drawn on the
+    #    other ranks and thrown away would leave world - 1 idle listeners per job).  The availability check happens BEFORE the broadcast
     buf = (C.c_ubyte * 128)()
     err = None
     try:
-        _lib.check(model.lib.seld_dp_unique_id(buf), model.ctx)
+        if rank == 0:
+            _lib.check(model.lib.seld_dp_unique_id(buf), model.ctx)
+        elif not model.lib.seld_dp_available():
+            raise RuntimeError("RCCL (librccl.so.1) could not be loaded")
     except Exception as e:      # noqa: BLE001 - reported collectively below
         err = e
     agree(err is None, "seld_dp_unique_id (binding RCCL)", err)
@@ -93,8 +97,7 @@ def init_library_dp(model, group=None, force: bool = False) -> bool:
     try:
         agree(err is None, "seld_dp_init", err)
     except RuntimeError:
-        if err is None:
-            model.lib.seld_dp_destroy(model.ctx)
+        model.lib.seld_dp_destroy(model.ctx)      # a no-op without a communicator; a rank that succeeded alone gives its own back
         raise
     model._lib_dp = True
     # the heads' dropout draws are a function of (seed, step, layer, element): every rank gets its own key, or all replicas would drop

@@ -15,8 +15,9 @@ Stored per model (inputs and weights are regenerated from seeds by the test):
     without an oracle on the GPU box.  A decision tensor is the first block's MaxPool(ReLU(.)) routing (value = 0 if the window
     passes 0, else 1 + argmax position), one of resnet50_block's 48 ReLU gates (value = gate), or — round 4 — one of xception_block's 24
     unit-input ReLU gates / its exit MaxPool(ReLU(.)) routing.  For each: `eps` (the margin
-    below which a decision counts as unresolvable: 1e-5, or for the deep resnet gates 8 x the fp32 oracle's own error on that
-    pre-activation, clamped to [1e-5, 2e-3]), `near` = the flat indices whose fp64 margin is below eps, `near_val` = the fp64
+    below which a decision counts as unresolvable — `margin_rule`: 8 x the fp32 oracle's own error on the value the decision is taken on
+    (`err32`, stored beside it), clamped to [1e-5, 2e-3]; since round 5 for the pooling routings too, which used a fixed 1e-5 and so
+    made the fixtures sensitive to the summation order of the first convolution), `near` = the flat indices whose fp64 margin is below eps, `near_val` = the fp64
     decision at each of them (round 4: injected by the test through seld_debug_set_routing / _set_relu_gates), and `digest` = (count,
     position-weighted checksum mod 2^64) of the fp64 decisions over all OTHER indices (`decision_digest`).  The library's
     decisions, digested with the same `near` indices excluded, must give the same pair: then every differing decision lies in
@@ -74,6 +75,18 @@ def decision_digest(values: np.ndarray, near: np.ndarray) -> np.ndarray:
     return np.array([nz.size, chk], dtype=np.uint64)
 
 
+EPS_MIN, EPS_MAX, EPS_FACTOR = 1e-5, 2e-3, 8.0
+
+
+def margin_rule(err32: float) -> float:
+    """The near-tie margin of ONE decision tensor (round 5: the same rule for MaxPool(ReLU) routings and for ReLU gates): a decision whose
+    fp64 margin is below EPS_FACTOR x the fp32 oracle's own error on the value it is taken on (`err32`: max |pre-activation_fp32 -
+    pre-activation_fp64| for a gate; max |window maximum_fp32 - window maximum_fp64| for a pooling window) is one that ANY fp32 evaluation —
+    any summation order of the products in front of it — may take either way; clamped to [1e-5, 2e-3].  The fixtures store `err32` beside
+    `eps`: tests/test_oracle_pins.py::test_fixture_margins_follow_the_rule holds every stored eps to this function."""
+    return float(min(max(EPS_FACTOR * err32, EPS_MIN), EPS_MAX))
+
+
 def pool_decisions(rec):
     """record_routing[0] of the oracle -> (value tensor, margin tensor): margin = top1 - top2 where the window passes,
     and |top1| everywhere (whichever is smaller decides)."""
@@ -100,14 +113,15 @@ def main(which: str):
         v.pop("windows", None)
     out = {"meta": np.array([Bn, T, 0])}
     # ---- decisions of the fp64 evaluation
-    dec64 = {}
-    val, margin = pool_decisions(rec64.pop(0))
-    dec64["pool0"] = (val, margin, None)
+    dec64, top64 = {}, {}
+    v0 = rec64.pop(0)
+    val, margin = pool_decisions(v0)
+    dec64["pool0"], top64["pool0"] = (val, margin, None), v0["top"].numpy().astype(np.float64)
     for key in list(rec64.keys()):
         v = rec64.pop(key)
         if "pos" in v:      # a MaxPool(ReLU(.)) routing (xception_block's exit)
             val, margin = pool_decisions(v)
-            dec64[key] = (val, margin, None)
+            dec64[key], top64[key] = (val, margin, None), v["top"].numpy().astype(np.float64)
         else:               # a ReLU gate (resnet50_block's 48; xception_block's 24 unit inputs)
             dec64[key] = (v["gate"].numpy(), np.abs(v["pre"].numpy()), v["pre"].numpy())
     t0 = time.time()
@@ -121,12 +135,12 @@ def main(which: str):
             rr = rec32.pop(0 if key == "pool0" else key)
             rr.pop("windows", None)
             v32, _ = pool_decisions(rr)
-            eps = 1e-5
+            err = float(np.abs(rr["top"].numpy().astype(np.float64) - top64[key]).max())
         else:
             rr = rec32.pop(key)
             v32 = rr["gate"].numpy()
             err = float(np.abs(rr["pre"].numpy().astype(np.float64) - pre64).max())
-            eps = float(min(max(8.0 * err, 1e-5), 2e-3))
+        eps = margin_rule(err)
         near = np.flatnonzero(margin.reshape(-1) < eps).astype(np.int64)
         diff = v32.reshape(-1) != val.reshape(-1)
         worst = float(margin.reshape(-1)[diff].max()) if diff.any() else 0.0
@@ -135,6 +149,7 @@ def main(which: str):
         out[f"dec.{k}.near_val"] = val.reshape(-1)[near].astype(np.uint8)      # the fp64 decisions AT the near-ties (round 4: injected by the test)
         out[f"dec.{k}.digest"] = decision_digest(val, near)
         out[f"dec.{k}.eps"] = np.float64(eps)
+        out[f"dec.{k}.err32"] = np.float64(err)
         names.append(k)
         flips.append((int(diff.sum()), worst, int((diff & (margin.reshape(-1) >= eps)).sum())))
         print(f"  {key:14s} {val.size:10d} decisions, eps {eps:.1e}: {near.size:7d} near, fp32 oracle flips {int(diff.sum()):5d} "
