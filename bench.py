@@ -321,6 +321,50 @@ def inference_leg(dev, local, files=4, reps=3, batch=271):
             "clip_equivalents_per_s": round(54.1 / per, 1)}
 
 
+MOTHER_STAGE_ARGS = {      # model_config/SS5.json's BLOCK0_ARGS (the reference's mother_stage configuration) — with the time stride of SS5's separate
+    # first_pool_size [5, 2] carried by the stage's own strides, because models.seldnet has no pooling in front of FIRST: [1, 3] -> [5, 3]
+    "depth": 2, "filters0": 0, "filters1": 96, "filters2": 0, "kernel_size0": 0, "kernel_size1": 3, "kernel_size2": 0,
+    "connect0": [1], "connect1": [1, 0], "connect2": [1, 0, 1], "strides": [5, 3]}
+
+
+def mother_stage_leg(dev, local, B=32, T=3000, steps=10, warmup=3):
+    """models.seldnet with FIRST = mother_stage (reference modules.py:15-43, 184-298, the only conv FIRST-stage block the snapshot
+    defines; SS5.json's BLOCK0 arguments) as a timed sub-record: the composed path (seld_amd/modules.py -> seld_m_* module operators, asynchronous
+    on one stream), train.trainstep on B clips of [T,64,7].  Phases from HIP events on the stream the operators are launched on; the dominant
+    phase is priced against the fp32 MFMA peak (its convolutions are im2col + v_mfma_f32_32x32x2_f32 products)."""
+    from seld_amd import losses, models, train
+    from seld_amd.synthetic import synthetic_batch
+    cfg = model_config_of("seldnet")
+    cfg["FIRST"], cfg["FIRST_ARGS"] = "mother_stage", dict(MOTHER_STAGE_ARGS)
+    model = models.seldnet((B, T, 64, 7), cfg, device=local)
+    x, ys, yd = (torch.as_tensor(a).to(dev) for a in synthetic_batch(B, T, seed=1234))
+    opt = train.Adam(1e-3)
+    args = (losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), opt)
+    for _ in range(warmup):
+        train.trainstep(model, x, (ys, yd), *args)
+    model.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, sl, _ = train.trainstep(model, x, (ys, yd), *args)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert np.isfinite(float(sl.item()))
+    ph = {k: round(v / steps, 4) for k, v in model.phase_ms().items()}
+    macs = model.conv_macs() * B
+    dom = max(("first_fwd", "first_bwd"), key=lambda k: ph.get(k, 0.0))
+    flop = 2 * macs * (1 if dom == "first_fwd" else 2)
+    ach = flop / (ph[dom] / 1e3) / 1e12
+    return {"value": round(B * steps / el, 2), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "config": {"workload": f"models.seldnet with FIRST = mother_stage (reference modules.py:15-43, 184-298; SS5.json BLOCK0_ARGS, strides [5,3]), "
+                                   f"train step, {B} clips of [T={T},64,7], composed from seld_m_* module operators on one stream",
+                       "n_params": int(model.n_params)},
+            "phase_ms_per_step": ph,
+            "roofline": {"kernel": dom + " (im2col + gemm_f32 products, BatchNorm / activation / concatenation passes)", "bound": "mfma",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": None, "ms_per_step": ph[dom]}}
+
+
 def model_config_of(name):
     import copy
     cfg = copy.deepcopy(SELDNET_CONFIG)
@@ -572,7 +616,7 @@ def compact_record(out, detail_path=None):
             c["cpu_baseline"]["b2_clips_s"] = cb["b2"].get("value")
         if cb.get("value"):
             c["gpu_over_cpu"] = round(out["value"] / cb["value"], 1)
-    for key in ("seldnet_bf16", "xception_gru", "resnet50_gru"):
+    for key in ("seldnet_bf16", "xception_gru", "resnet50_gru", "mother_stage"):
         sub = out.get("configs", {}).get(key)
         if sub:
             c[f"{key}_clips_s"] = sub.get("value")
@@ -773,6 +817,8 @@ def main():
                 out["configs"][key].pop("metric")
                 r["model"] = None
                 del r
+            torch.cuda.empty_cache()
+            out["configs"]["mother_stage"] = mother_stage_leg(dev, local, steps=sub_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, args.cpu_steps, args.cpu_warmup, args.cpu_budget_s, model_config_of(args.model))
         # DETAIL first (one long line + a file), the compact record LAST: the driver parses the last stdout line from an 8 KB tail

@@ -448,6 +448,17 @@ int seld_m_mean_hw(const float* x, float* out, int B, int HW, int C, void* strea
 int seld_m_scale_hw(const float* x, const float* s, float* y, int B, int HW, int C, void* stream);
 int seld_m_scale_hw_bwd_ds(const float* x, const float* dy, float* ds, int B, int HW, int C, void* stream);
 int seld_m_scale_hw_bwd_dx(const float* dy, const float* s, const float* dmean, float* dx, int B, int HW, int C, int accumulate, void* stream);
+/* The recurrent block (modules.py:302-319), the losses (train.py:26-34, losses.py:4-13) and Adam (train.py:311) as module operators: the same
+ * kernels as seld_k_gru_fwd / _bwd / seld_k_losses / seld_k_adam, enqueued on the caller's stream with no host synchronisation (round 5: a
+ * composed train step runs without one).  seld_m_losses takes its scratch from the caller: seld_m_losses_scratch(B * S) floats. */
+int seld_m_gru_fwd(const float* gx_f, const float* gx_b, const float* U_f, const float* U_b, const float* brec_f, const float* brec_b, float* h_f,
+                   float* h_b, float* saved_f, float* saved_b, float* out, int B, int S, int units, void* stream);
+int seld_m_gru_bwd(const float* dout, const float* h_f, const float* h_b, const float* saved_f, const float* saved_b, const float* U_f,
+                   const float* U_b, float* dgx_f, float* dgx_b, float* dgh_f, float* dgh_b, int B, int S, int units, void* stream);
+int64_t seld_m_losses_scratch(int rows);
+int seld_m_losses(const float* sed, const float* doa, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg, float* sloss, float* dloss,
+                  float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, void* stream);
+int seld_m_adam(float* theta, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 /* Measurement aid (bench.py, SURVEY.md §8(d) "state the step-latency floor"): the shader clock the card holds while `blocks`
  * workgroups of 512 threads run a VALU-only loop (the load shape of the GRU recurrence: 2B workgroups, no MFMA), from
  * s_memtime / s_memrealtime (100 MHz) inside the kernel.  No reference counterpart. */

@@ -429,7 +429,10 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
                 pre = f"xc{b}.{u}"
                 if record_routing is not None:       # the unit's ReLU gate and the pre-activation behind it (tests/golden/make_golden_blocks.py)
                     record_routing[f"{pre}.in"] = {"gate": y.detach() > 0, "pre": y.detach()}
-                y = torch.relu(y)
+                if routing is not None and f"{pre}.in" in routing:      # a GIVEN gate (round 5: the fp32 oracle evaluated on the fp64 decisions)
+                    y = torch.where(routing[f"{pre}.in"], y, torch.zeros((), dtype=y.dtype))
+                else:
+                    y = torch.relu(y)
                 dw = w[f"{pre}.depthwise_kernel"].permute(2, 3, 0, 1)           # [kh,kw,in,1] -> [in,1,kh,kw]
                 y = F.conv2d(y.permute(0, 3, 1, 2), dw, None, stride=1, padding=1, groups=C)
                 pw = w[f"{pre}.pointwise_kernel"][0, 0]                        # [in,out]
@@ -444,8 +447,14 @@ def forward(spec: Spec, w: Dict[str, torch.Tensor], st: Dict[str, torch.Tensor],
             Bq, Hq, Wq, Cq = h.shape
             yw = h.detach().reshape(Bq, Hq, Wq // 8, 8, Cq).permute(0, 1, 2, 4, 3)
             top, idx = yw.topk(2, dim=-1)
-            record_routing["exit"] = {"pos": idx[..., 0], "gate": top[..., 0] > 0, "gap": top[..., 0] - top[..., 1], "top": top[..., 0]}
-        h = maxpool_nhwc(torch.relu(h), (1, 8))
+            record_routing["exit"] = {"pos": idx[..., 0], "gate": top[..., 0] > 0, "gap": top[..., 0] - top[..., 1], "top": top[..., 0], "windows": yw}
+        if routing is not None and "exit" in routing:       # a GIVEN exit routing (pos, gate), as the conv blocks take theirs
+            pos, gate = routing["exit"]
+            Bq, Hq, Wq, Cq = h.shape
+            yw = h.reshape(Bq, Hq, Wq // 8, 8, Cq).permute(0, 1, 2, 4, 3)
+            h = torch.where(gate, yw.gather(-1, pos.unsqueeze(-1)).squeeze(-1), torch.zeros((), dtype=h.dtype))
+        else:
+            h = maxpool_nhwc(torch.relu(h), (1, 8))
     if spec.first == "resnet50_block":
         # spec/RESNET50_BLOCK.md: bottleneck blocks, strides on the frequency axis
         def conv_bn(t, pre, stride_f, k):

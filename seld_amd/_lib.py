@@ -165,6 +165,11 @@ SIGNATURES = {
     "seld_m_scale_hw": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "seld_m_scale_hw_bwd_ds": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "seld_m_scale_hw_bwd_dx": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "seld_m_gru_fwd": (_I, [_P] * 11 + [_I] * 3 + [_P]),
+    "seld_m_gru_bwd": (_I, [_P] * 11 + [_I] * 3 + [_P]),
+    "seld_m_losses_scratch": (_L, [_I]),
+    "seld_m_losses": (_I, [_P, _P, _P, _P, C.POINTER(LossCfg), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "seld_m_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _P]),
     "seld_k_rn_conv": (_I, [_P, _P, _P] + [_I] * 7),
     "seld_k_rn_conv_bwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 7),
     "seld_k_rn_bn": (_I, [_P] * 7 + [_L, _I, _I]),

@@ -35,7 +35,11 @@ __device__ __forceinline__ void cpsb_split3_pair(float x0, float x1, unsigned& h
 template <int CIN>
 struct PoolSbGeom {
     static constexpr int CP = CIN < 8 ? 8 : 16;              // channel slots per pixel (CIN values, 1.0, zeros)
-    static constexpr int KTOT = 9 * CP;
+    // PACK (CIN = 7, round 4): K = 64 instead of 72 (+ 8 of padding = five k-steps): the ninth tap's seven channels ride in the spare slot 7 of
+    // taps 0 .. 6 (a v_perm puts element t of the tap-8 pixel's vector into the fragment of tap t), the bias in slot 7 of tap 7 (which the
+    // patch already holds as 1.0): four k-steps, a fifth of the MFMAs gone
+    static constexpr bool PACK = CIN == 7;
+    static constexpr int KTOT = PACK ? 64 : 9 * CP;
     static constexpr int NS = (KTOT + 15) / 16;              // k-steps of 16
     // weight row stride in bf16: >= NS*16 and an odd number of 16-B slots, so the 16 lanes of a ds_read_b128 group
     // (co = lane) land on 16 different slots of the 256-B bank row
@@ -73,7 +77,8 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
         // everyone else's, with no per-value sign flip in the reduction; the stored extreme and the sum are flipped back
         const float v0_ = isb ? (bias ? bias[co] : 0.f) : w[idx];
         const float v = gamma[co] < 0.f ? -v0_ : v0_;
-        const int kk = isb ? 4 * CP + CIN : (k / CIN) * CP + (k % CIN);
+        const int kk = G::PACK ? (isb ? 63 : (k / CIN < 8 ? (k / CIN) * CP + (k % CIN) : (k % CIN) * CP + 7))
+                               : (isb ? 4 * CP + CIN : (k / CIN) * CP + (k % CIN));
         const unsigned u = __float_as_uint(v);
         const float r = v - __uint_as_float(u & 0xffff0000u);
         const unsigned vv = __float_as_uint(r);
@@ -144,13 +149,21 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
     const unsigned short* wbase = Wl + li * KW + 8 * kg;
     const int lane_e = kg * 64 + li;
 #define CPSB_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+    // PACK: slot 7 of the fragment <- element (2 s + kg) of the tap-8 pixel (row + 2, bin + 2): dword s of its vector, half kg
+#define CPSB_FRAG(ptr_, p8_)                                                                            \
+    ([&]() {                                                                                            \
+        u32x4 f_ = *reinterpret_cast<const u32x4*>(ptr_);                                               \
+        if (G::PACK) f_.w = __builtin_amdgcn_perm(*reinterpret_cast<const unsigned*>(p8_), f_.w, psel); \
+        return __builtin_bit_cast(bf16x8, f_);                                                          \
+    }())
 #define CPSB_ROW(j_, ACCA_, ACCB_)                                                                      \
     {                                                                                                   \
         const unsigned short* ap_ = pa + (j_) * 66 * CP;                                                \
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap_);                                        \
+        const unsigned short* p8_ = p8 + (j_) * 66 * CP;                                                \
+        const bf16x8 ah = CPSB_FRAG(ap_, p8_);                                                          \
         CPSB_MFMA(ah, bh0, ACCA_); CPSB_MFMA(ah, bh1, ACCB_);                                           \
         if (!ONE) {                                                                                     \
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap_ + PLANE), al = *reinterpret_cast<const bf16x8*>(ap_ + 2 * PLANE);   \
+        const bf16x8 am = CPSB_FRAG(ap_ + PLANE, p8_ + PLANE), al = CPSB_FRAG(ap_ + 2 * PLANE, p8_ + 2 * PLANE);   \
         CPSB_MFMA(ah, bm0, ACCA_); CPSB_MFMA(ah, bm1, ACCB_);                                           \
         CPSB_MFMA(am, bh0, ACCA_); CPSB_MFMA(am, bh1, ACCB_); CPSB_MFMA(ah, bl0, ACCA_); CPSB_MFMA(ah, bl1, ACCB_);   \
         CPSB_MFMA(al, bh0, ACCA_); CPSB_MFMA(al, bh1, ACCB_); CPSB_MFMA(am, bm0, ACCA_); CPSB_MFMA(am, bm1, ACCB_);   \
@@ -205,6 +218,12 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const unsigned short* pa = pbase + (kg ? CPSB_AOFF(s, 1) : CPSB_AOFF(s, 0));
+            // elements 2 s, 2 s + 1 of the tap-8 pixel.  The offset is laundered through an empty asm: seen as consecutive, the four k-steps' dwords
+            // were merged into one ds_read_b128 per (row, plane) that stayed live for the whole tile — 60 registers, 84 spill instructions, 462 us
+            int p8o = 2 * s;
+            asm volatile("" : "+s"(p8o));
+            const unsigned short* p8 = pbase + (2 * 66 + 2) * CP + p8o;
+            const unsigned psel = s == 3 ? (kg ? 0x03020100u : 0x05040100u) : (kg ? 0x07060100u : 0x05040100u);   // tap 7 keeps its 1.0 (the bias)
             const unsigned short* wp = wbase + 16 * s;
             const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(wp), bh1 = *reinterpret_cast<const bf16x8*>(wp + 32 * KW);
             bf16x8 bm0 = bh0, bm1 = bh1, bl0 = bh0, bl1 = bh1;       // (single-product mode: unused)
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(256, (CIN < 8 ? 2 : 1)) void conv_first_fwd_pool_sb
 #undef CPSB_DRAIN
 #undef CPSB_STATS
 #undef CPSB_ROW
+#undef CPSB_FRAG
 #undef CPSB_MFMA
 #undef CPSB_AOFF
 #undef CPSB_TAP

@@ -5,6 +5,7 @@
 // one dense product, which runs on the matrix cores; tuned forms exist for the shapes the BASELINE configurations use (conv_sb.hip,
 // resnet.hip), not for these.  C ABI "seld_m_*": asynchronous on the caller's stream, no allocation, caller-provided scratch.
 #include "common.h"
+#include <cmath>
 #include "../../include/seld_hip.h"
 #include <math.h>
 
@@ -341,6 +342,46 @@ int seld_m_scale_hw_bwd_dx(const float* dy, const float* s, const float* dmean, 
     if (!dy || !s || !dx) return SELD_ERR_INVALID;
     const int64_t n = (int64_t)B * HW * C;
     hipLaunchKernelGGL(scale_hw_bwd_dx_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, s, dmean, dx, n, HW, C, accumulate);
+    return ok();
+}
+
+/* ---- the recurrent block, the losses and Adam on the CALLER'S stream, asynchronous like every other module operator (round 5: the composed
+ * step makes no host synchronisation; the seld_k_* forms of these run on the null stream and synchronise the device) ---------------------- */
+int seld_m_gru_fwd(const float* gx_f, const float* gx_b, const float* U_f, const float* U_b, const float* brec_f, const float* brec_b, float* h_f,
+                   float* h_b, float* saved_f, float* saved_b, float* out, int B, int S, int units, void* stream) {
+    if (units != 128) return SELD_ERR_UNSUPPORTED;
+    if (!gx_f || !gx_b || !U_f || !U_b || !brec_f || !brec_b || !h_f || !h_b || B < 1 || S < 1) return SELD_ERR_INVALID;
+    launch_gru_fwd((hipStream_t)stream, gx_f, gx_b, U_f, U_b, brec_f, brec_b, h_f, h_b, saved_f, saved_b, B, S);
+    if (out) launch_mul((hipStream_t)stream, h_f, h_b, out, (int64_t)B * S * 128);
+    return ok();
+}
+int seld_m_gru_bwd(const float* dout, const float* h_f, const float* h_b, const float* saved_f, const float* saved_b, const float* U_f,
+                   const float* U_b, float* dgx_f, float* dgx_b, float* dgh_f, float* dgh_b, int B, int S, int units, void* stream) {
+    if (units != 128) return SELD_ERR_UNSUPPORTED;
+    if (!dout || !h_f || !h_b || !saved_f || !saved_b || !U_f || !U_b || !dgx_f || !dgx_b || !dgh_f || !dgh_b || B < 1 || S < 1) return SELD_ERR_INVALID;
+    launch_gru_bwd((hipStream_t)stream, dout, h_f, h_b, saved_f, saved_b, U_f, U_b, dgx_f, dgx_b, dgh_f, dgh_b, B, S);
+    return ok();
+}
+/* floats of caller scratch seld_m_losses needs for `rows` = B * S label frames */
+int64_t seld_m_losses_scratch(int rows) { return rows > 0 ? (int64_t)loss_scratch_floats(rows) + 4 : -1; }
+int seld_m_losses(const float* sed, const float* doa, const float* y_sed, const float* y_doa, const seld_loss_cfg* cfg, float* sloss, float* dloss,
+                  float* dsed_pre, float* ddoa_pre, float* scratch, int B, int S, int nc, void* stream) {
+    if (!sed || !doa || !y_sed || !y_doa || !cfg || !sloss || !dloss || !scratch || B < 1 || S < 1) return SELD_ERR_INVALID;
+    const int rows = B * S;
+    float* den = scratch + loss_scratch_floats(rows);
+    if (cfg->doa_loss == SELD_DOA_MMSE) {
+        if (cfg->mmse_den > 0.f) launch_fill((hipStream_t)stream, den, 1, cfg->mmse_den);
+        else launch_mmse_den((hipStream_t)stream, y_doa, den, scratch, rows, nc);
+    }
+    launch_losses((hipStream_t)stream, sed, doa, y_sed, y_doa, cfg->doa_loss, cfg->w_sed, cfg->w_doa, cfg->sed_grad_scale, den, sloss, dloss, dsed_pre,
+                  ddoa_pre, scratch, B, S, nc);
+    return ok();
+}
+int seld_m_adam(float* theta, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+    if (!theta || !g || !m || !v || n <= 0 || step < 1) return SELD_ERR_INVALID;
+    const double t = (double)step;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    launch_adam((hipStream_t)stream, theta, g, m, v, n, lr_t, beta1, beta2, eps);
     return ok();
 }
 

@@ -134,9 +134,6 @@ class _Rt:
     def axpy(self, dst, src, alpha=1.0):
         self.ck(self.lib.seld_m_axpy(self.p(dst), self.p(src), dst.numel(), alpha, self.st()))
 
-    def sync_null(self):
-        """seld_k_* entry points run on the null stream and synchronise the device themselves: what this stream has enqueued must be done first"""
-        torch.cuda.current_stream(self.dev).synchronize()
 
 
 class Conv2D:
@@ -498,8 +495,10 @@ class ComposedSeldNet:
         self.variables, self.state_variables = rt.variables, rt.state_variables
         self.n_params, self.n_state = rt.n_params, rt.n_state
         self.dfeat = rt.empty(B * self.S, 128)
+        self.loss_scratch = rt.empty(int(rt.lib.seld_m_losses_scratch(B * self.S)))
         self.dfirst = rt.empty(B, *shape)
         self.adam_step = 0
+        self._marks = None          # profile(True): [(group name, torch event)] of the current step (bench.py's mother_stage record)
         self._init_weights()
 
     # ---------------------------------------------------------------- weights
@@ -559,6 +558,39 @@ class ComposedSeldNet:
     def close(self) -> None:
         pass
 
+    # ---------------------------------------------------------------- measurement aid
+    def profile(self, on: bool) -> None:
+        """on: every step records a HIP event (torch's current stream) at its phase boundaries; `phase_ms()` gives the phases' durations"""
+        self._marks = [] if on else None
+
+    def _mark(self, name: str) -> None:
+        if self._marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self._dev))
+            self._marks.append((name, e))
+
+    def phase_ms(self) -> dict:
+        """{phase: ms summed over the recorded steps}; call after a synchronize.  A phase lasts from the previous mark to its own."""
+        out: Dict[str, float] = {}
+        marks, self._marks = self._marks or [], []
+        for (_, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            if n1 != "step_start":
+                out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    def conv_macs(self) -> int:
+        """multiply-adds of the FIRST stage's convolutions (main, projection and strided-concatenation convs) per clip, forward"""
+        tot = 0
+        for blk in self.blocks:
+            for lay in blk.layers:
+                convs = []
+                if lay["kind"] == "conv":
+                    convs = [lay["main"].conv] + [p.conv for _, p in lay["skips"] if p is not None]
+                elif lay["kind"] == "cat":
+                    convs = [cv for _, cv, _ in lay["parts"] if cv is not None]
+                tot += sum(cv.Ho * cv.Wo * cv.K * cv.N for cv in convs)
+        return tot
+
     # ---------------------------------------------------------------- forward / backward
     def _prep(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
@@ -577,6 +609,7 @@ class ComposedSeldNet:
         h = x
         for blk in self.blocks:
             h = blk.forward(h, B, training)
+        self._mark("first_fwd")
         R = B * self.S
         feat = h.reshape(R, -1)          # layers.force_1d_inputs (layers.py:41-47): feature = f * C + c
         self.feat0 = feat
@@ -585,11 +618,11 @@ class ComposedSeldNet:
             for d, dn in enumerate(("fwd", "bwd")):
                 b = rt.w(f"gru{i}.{dn}.bias")
                 rt.gemm(feat, rt.w(f"gru{i}.{dn}.kernel"), b[:384], G["gx"][d], R, 384, G["in"])
-            rt.sync_null()
             bf, bb = rt.w(f"gru{i}.fwd.bias"), rt.w(f"gru{i}.bwd.bias")
-            rt.ck(rt.lib.seld_k_gru_fwd(rt.p(G["gx"][0]), rt.p(G["gx"][1]), rt.p(rt.w(f"gru{i}.fwd.recurrent_kernel")),
+            rt.ck(rt.lib.seld_m_gru_fwd(rt.p(G["gx"][0]), rt.p(G["gx"][1]), rt.p(rt.w(f"gru{i}.fwd.recurrent_kernel")),
                                         rt.p(rt.w(f"gru{i}.bwd.recurrent_kernel")), rt.p(bf[384:]), rt.p(bb[384:]), rt.p(G["h"][0]), rt.p(G["h"][1]),
-                                        rt.p(G["sv"][0]) if training else None, rt.p(G["sv"][1]) if training else None, rt.p(G["out"]), B, self.S, 128))
+                                        rt.p(G["sv"][0]) if training else None, rt.p(G["sv"][1]) if training else None, rt.p(G["out"]), B, self.S, 128,
+                                        rt.st()))
             feat = G["out"]
         sed = rt.empty(B, self.S, self.n_classes)
         doa = rt.empty(B, self.S, 3 * self.n_classes)
@@ -603,6 +636,7 @@ class ComposedSeldNet:
             Hd["x"] = a
             rt.gemm(a, rt.w(Hd["name"] + ".out.kernel"), rt.w(Hd["name"] + ".out.bias"), Hd["pre"], R, Hd["out"], Hd["in"])
             rt.act(Hd["pre"][:R], out.view(R, -1), Hd["act"])
+        self._mark("gru_heads_fwd")
         return sed, doa
 
     def __call__(self, x, training: bool = False):
@@ -634,10 +668,9 @@ class ComposedSeldNet:
         dout = self.dfeat
         for i in range(len(self.gru) - 1, -1, -1):
             G = self.gru[i]
-            rt.sync_null()
-            rt.ck(rt.lib.seld_k_gru_bwd(rt.p(dout), rt.p(G["h"][0]), rt.p(G["h"][1]), rt.p(G["sv"][0]), rt.p(G["sv"][1]),
+            rt.ck(rt.lib.seld_m_gru_bwd(rt.p(dout), rt.p(G["h"][0]), rt.p(G["h"][1]), rt.p(G["sv"][0]), rt.p(G["sv"][1]),
                                         rt.p(rt.w(f"gru{i}.fwd.recurrent_kernel")), rt.p(rt.w(f"gru{i}.bwd.recurrent_kernel")), rt.p(G["dgx"][0]),
-                                        rt.p(G["dgx"][1]), rt.p(G["dgh"][0]), rt.p(G["dgh"][1]), B, self.S, 128))
+                                        rt.p(G["dgx"][1]), rt.p(G["dgh"][0]), rt.p(G["dgh"][1]), B, self.S, 128, rt.st()))
             for d, dn in enumerate(("fwd", "bwd")):
                 gb = rt.g(f"gru{i}.{dn}.bias")
                 rt.gemm_tn(G["x"], G["dgx"][d], rt.g(f"gru{i}.{dn}.kernel"), gb[:384], R, G["in"], 384)
@@ -645,9 +678,11 @@ class ComposedSeldNet:
                 rt.gemm_tn(G["h"][d], G["dgh"][d], rt.g(f"gru{i}.{dn}.recurrent_kernel"), gb[384:], R, 128, 384, seq=self.S, shift=-1 if d == 0 else 1)
                 rt.gemm(G["dgx"][d], rt.w(f"gru{i}.{dn}.kernel"), None, G["din"], R, G["in"], 384, transb=1, accumulate=d)
             dout = G["din"]
+        self._mark("heads_gru_bwd")
         dy = dout[:R].view(B, *self.blocks[-1].out_shape)
         for bi in range(len(self.blocks) - 1, -1, -1):
             dy = self.blocks[bi].backward(dy, None, B)
+        self._mark("first_bwd")
 
     def _labels(self, y, B):
         ys = torch.as_tensor(y[0], dtype=torch.float32, device=self._dev).contiguous()
@@ -662,10 +697,9 @@ class ComposedSeldNet:
         B = sed.shape[0]
         sloss = torch.empty((), dtype=torch.float32, device=self._dev)
         dloss = torch.empty((B, self.S) if cfg.doa_loss != 1 else (), dtype=torch.float32, device=self._dev)
-        rt.sync_null()
-        rt.ck(rt.lib.seld_k_losses(rt.p(sed), rt.p(doa), rt.p(ys), rt.p(yd), C.byref(cfg), rt.p(sloss), rt.p(dloss),
+        rt.ck(rt.lib.seld_m_losses(rt.p(sed), rt.p(doa), rt.p(ys), rt.p(yd), C.byref(cfg), rt.p(sloss), rt.p(dloss),
                                    rt.p(self.heads[0]["dpre"]) if want_grads else None, rt.p(self.heads[1]["dpre"]) if want_grads else None,
-                                   B, self.S, self.n_classes))
+                                   rt.p(self.loss_scratch), B, self.S, self.n_classes, rt.st()))
         return sloss, dloss
 
     def train_step(self, x, y, cfg, optimizer, agc: bool = False):
@@ -676,13 +710,15 @@ class ComposedSeldNet:
         x = self._prep(x)
         B = x.shape[0]
         ys, yd = self._labels(y, B)
+        self._mark("step_start")
         sed, doa = self._forward(x, True)
         sloss, dloss = self._losses(sed, doa, ys, yd, cfg, True)
+        self._mark("losses")
         self._backward(B)
         self.adam_step += 1
-        rt.sync_null()
-        rt.ck(rt.lib.seld_k_adam(rt.p(rt.params), rt.p(rt.grads), rt.p(rt.adam_m), rt.p(rt.adam_v), self.n_params, optimizer.learning_rate,
-                                 optimizer.beta_1, optimizer.beta_2, optimizer.epsilon, self.adam_step))
+        rt.ck(rt.lib.seld_m_adam(rt.p(rt.params), rt.p(rt.grads), rt.p(rt.adam_m), rt.p(rt.adam_v), self.n_params, optimizer.learning_rate,
+                                 optimizer.beta_1, optimizer.beta_2, optimizer.epsilon, self.adam_step, rt.st()))
+        self._mark("adam")
         return [sed, doa], sloss, dloss
 
     def test_step(self, x, y, cfg):

@@ -302,3 +302,54 @@ def test_first_and_second_block_dropout_in_the_oracle_forward(spec):
     np.testing.assert_array_equal(e0.numpy(), e1.numpy())
     np.testing.assert_array_equal(t1.numpy(), t1b.numpy())
     assert np.abs(t0.numpy() - t1.numpy()).max() > 1e-5 and np.abs(t1.numpy() - t2.numpy()).max() > 1e-5
+
+
+def test_fixture_margins_follow_the_rule():
+    """every decision tensor of the four full-size fixtures — the MaxPool(ReLU) routings as well as the ReLU gates — lists its
+    near-ties by ONE rule (tests/golden/make_golden_blocks.margin_rule: 8 x the fp32 oracle's own error on the value the decision is taken
+    on, clamped to [1e-5, 2e-3]), and the fixtures carry the rule's input (`err32`) beside its output (`eps`): a change of fp32 summation
+    order in a kernel re-rolls only decisions the rule already lists.  Also: the fp32 oracle itself takes no decision outside a list."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sp = importlib.util.spec_from_file_location("make_golden_blocks", os.path.join(here, "make_golden_blocks.py"))
+    mb = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mb)
+    assert mb.margin_rule(0.0) == 1e-5 and mb.margin_rule(1.0) == 2e-3 and abs(mb.margin_rule(1e-5) - 8e-5) < 1e-18
+    n = 0
+    for name in ("seldnet_full_b32_t3000_mse", "seldnet_full_b32_t3000_mmse", "xception_gru_full_b32_t3000_mse", "resnet50_gru_full_b16_t3000_mse"):
+        z = np.load(os.path.join(here, name + ".npz"))
+        keys = sorted({k.split(".")[1] for k in z.files if k.startswith("dec.") and k.endswith(".eps")})
+        assert keys, name
+        assert keys == sorted({k.split(".")[1] for k in z.files if k.startswith("dec.") and k.endswith(".near")}), f"{name}: a decision tensor without a stored margin"
+        for k in keys:
+            eps, err = float(z[f"dec.{k}.eps"]), float(z[f"dec.{k}.err32"])
+            assert eps == mb.margin_rule(err), (name, k, eps, err)
+            assert z[f"dec.{k}.near"].shape == z[f"dec.{k}.near_val"].shape
+            n += 1
+        if "fp32_flips" in z.files:      # [decisions the fp32 oracle takes differently, largest fp64 margin among them, how many outside eps]
+            assert (z["fp32_flips"][:, 2] == 0).all(), f"{name}: the fp32 oracle flips a decision outside its list"
+    assert n == 3 + 3 + 26 + 49
+
+
+def test_oracle_given_its_own_decisions_is_itself(xception_config):
+    """`routing=` (GIVEN decisions: the first block's MaxPool(ReLU) routing, xception_block's unit gates and exit routing — what the round-5
+    fixtures use to evaluate the fp32 oracle ON the fp64 decisions) fed with the free-running evaluation's own decisions reproduces that
+    evaluation bit for bit; with one gate complemented it does not."""
+    import copy
+    from oracle import seldnet_oracle as O
+    cfg = copy.deepcopy(xception_config)
+    cfg["FIRST_ARGS"]["block_num"] = 2
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 3)
+    x, ys, yd = O.synthetic_batch(2, 50, seed=5)
+    kw = dict(doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    rec = {}
+    free = O.train_step(spec, w, st, x, ys, yd, record_routing=rec, **kw)
+    routing = {k: ((v["pos"], v["gate"]) if "pos" in v else v["gate"]) for k, v in rec.items()}
+    assert set(routing) == {0, "exit"} | {f"xc{b}.{u}.in" for b in range(2) for u in range(3)}
+    given = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
+    assert np.array_equal(given["grad"], free["grad"]) and np.array_equal(given["sed"], free["sed"])
+    routing["xc1.0.in"] = ~routing["xc1.0.in"]
+    other = O.train_step(spec, w, st, x, ys, yd, routing=routing, **kw)
+    assert np.abs(other["grad"] - free["grad"]).max() > 1e-3 * np.abs(free["grad"]).max()
