@@ -257,6 +257,12 @@ def conv2d_same_nhwc(x, kernel_hwio, bias):
     return y.permute(0, 2, 3, 1)
 
 
+# Diagnostic aid (tools/diag_fp32_draws.py): "shifted" makes the FORWARD VALUE of a training-mode BatchNormalization z * scale + shift with
+# scale = gamma * invstd and shift = beta - mean * scale rounded to z's dtype first — the one-fma form a kernel applies — while the gradient
+# stays that of the centred form.  In fp32 the shifted form loses |mean| / std more digits than the centred one.  Never set by tests or fixtures.
+BN_FORM = "centred"
+
+
 def batchnorm(z, gamma, beta, mov_mean, mov_var, training: bool, sync=None):
     """Keras BatchNormalization(axis=-1) (layers.py:33), fused semantics. Returns y, new stats.
     `sync = (allreduce_sum, world)`: synchronised statistics for data parallelism (what seld_set_sync_bn computes): the
@@ -280,6 +286,11 @@ def batchnorm(z, gamma, beta, mov_mean, mov_var, training: bool, sync=None):
         mean = z.mean(dim=(0, 1, 2))
         var = ((z - mean) ** 2).mean(dim=(0, 1, 2))  # biased
         y = (z - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
+        if BN_FORM == "shifted":
+            with torch.no_grad():
+                sc = gamma * torch.rsqrt(var + BN_EPS)
+                alt = z * sc + (beta - mean * sc)
+            y = y + (alt - y).detach()
         with torch.no_grad():
             f = 1.0 - BN_MOMENTUM
             new_mean = mov_mean * (1 - f) + mean * f
