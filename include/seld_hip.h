@@ -427,7 +427,8 @@ int seld_m_gemm(const float* A, const float* Bm, const float* bias, float* Cm, i
 int64_t seld_m_gemm_tn_scratch(int K1, int N);
 int seld_m_gemm_tn(const float* A, const float* Bm, float* Cm, float* colsum, float* slab, int M, int K1, int N, int seq, int shift, void* stream);
 /* tf.keras.layers.BatchNormalization, training mode (layers.py:33, modules.py:232-268): batch mean / biased variance per channel ... */
-int seld_m_bn_stats(const float* z, int64_t npix, int C, float* mean, float* var, void* stream);
+int64_t seld_m_bn_scratch(int C);   /* floats of caller scratch seld_m_bn_stats / seld_m_bn_bwd take (two-stage sums that fill the card; NULL: one workgroup per channel) */
+int seld_m_bn_stats(const float* z, int64_t npix, int C, float* mean, float* var, float* scratch, void* stream);
 /* ... out (+)= (z - mean) rsqrt(var + eps) gamma + beta (inference: mean / var = the moving statistics) ... */
 int seld_m_bn_apply(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* out,
                     int64_t npix, int C, int accumulate, void* stream);
@@ -435,7 +436,7 @@ int seld_m_bn_apply(const float* z, const float* mean, const float* var, const f
 int seld_m_bn_moving(const float* mean, const float* var, float* mov_mean, float* mov_var, int C, float momentum, int64_t count, void* stream);
 /* ... and its gradient: dgamma, dbeta, dz */
 int seld_m_bn_bwd(const float* z, const float* dy, const float* mean, const float* var, const float* gamma, float eps, float* dz, float* dgamma,
-                  float* dbeta, int64_t npix, int C, void* stream);
+                  float* dbeta, int64_t npix, int C, float* scratch, void* stream);
 #define SELD_ACT_SWISH 4
 /* y = act(x); dx (+)= dy act'(x) from the pre-activation x.  kind: SELD_ACT_NONE / _SIGMOID / _TANH / _RELU / _SWISH */
 int seld_m_act(const float* x, float* y, int64_t n, int kind, void* stream);

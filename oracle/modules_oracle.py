@@ -75,6 +75,17 @@ def check_mother_config(cfg: dict) -> None:
         raise ValueError("if strides are set, the second layer must be active")
 
 
+def dead_layers(cfg: dict) -> Tuple[bool, bool]:
+    """(first layer dead, second layer dead): a layer whose output reaches neither the block's output nor a later layer.  The reference's checks
+    (modules.py:202-222) accept such configurations (e.g. filters1 > 0, filters2 = 0, connect2 = [1, 0, 0]); its Keras functional model then simply
+    does not contain the layer — no variables, no computation — and neither does this restatement."""
+    f = [int(cfg[f"filters{i}"]) for i in range(3)]
+    c1, c2 = cfg["connect1"], cfg["connect2"]
+    need2 = f[2] > 0 or c2[2] == 1                                  # outputs[2] (the second layer's) reaches the third layer / the output
+    need1 = c2[1] == 1 or (need2 and (f[1] > 0 or c1[1] == 1))      # outputs[1] (the first layer's)
+    return (f[0] > 0 and not need1), (not need2)
+
+
 def mother_block_plan(cfg: dict, in_shape: Tuple[int, int, int], prefix: str):
     """-> (trainable [(name, shape)], state [(name, shape)], out_shape (H, W, C)) in Keras creation order."""
     check_mother_config(cfg)
@@ -96,7 +107,11 @@ def mother_block_plan(cfg: dict, in_shape: Tuple[int, int, int], prefix: str):
     conn = [cfg["connect0"], cfg["connect1"], cfg["connect2"]]
     strides = safe_tuple(cfg.get("strides", (1, 1)))
     shapes = [tuple(in_shape)]       # outputs[i]
+    dead0, dead1 = dead_layers(cfg)
+    real_conv, real_bn = conv, bn
     # first layer
+    if dead0:
+        conv = bn = lambda *a: None       # a layer whose output reaches nothing has no variables (dead_layers)
     if f[0] > 0:
         conv("c0", k[0], shapes[-1][2], f[0]); bn("bn0", f[0])
         out = (shapes[-1][0], shapes[-1][1], f[0])
@@ -105,6 +120,7 @@ def mother_block_plan(cfg: dict, in_shape: Tuple[int, int, int], prefix: str):
     else:
         out = shapes[-1]
     shapes.append(out)
+    conv, bn = (lambda *a: None, lambda *a: None) if dead1 else (real_conv, real_bn)
     # second layer (strides)
     if f[1] > 0:
         conv("c1", k[1], shapes[-1][2], f[1]); bn("bn1", f[1])
@@ -116,6 +132,7 @@ def mother_block_plan(cfg: dict, in_shape: Tuple[int, int, int], prefix: str):
         cs = [shapes[i] for i in range(2) if conn[1][i] == 1]
         out = (cs[0][0], cs[0][1], sum(s[2] for s in cs))
     shapes.append(out)
+    conv, bn = real_conv, real_bn
     # third layer
     if f[2] > 0:
         conv("c2", k[2], shapes[-1][2], f[2]); bn("bn2", f[2])
@@ -158,8 +175,11 @@ def mother_block_forward(cfg: dict, w: Dict[str, torch.Tensor], st: Dict[str, to
         new_st[f"{prefix}.{name}.moving_mean"], new_st[f"{prefix}.{name}.moving_variance"] = m, v
         return y
 
+    dead0, dead1 = dead_layers(cfg)
     outputs = [x]
-    if f[0] > 0:
+    if dead0:
+        out = None
+    elif f[0] > 0:
         out = bn("bn0", conv("c0", outputs[-1]))
         if conn[0][0] == 1:
             skip = outputs[-1]
@@ -170,7 +190,9 @@ def mother_block_forward(cfg: dict, w: Dict[str, torch.Tensor], st: Dict[str, to
     else:
         out = outputs[-1]
     outputs.append(out)
-    if f[1] > 0:
+    if dead1:
+        out = None
+    elif f[1] > 0:
         out = bn("bn1", conv("c1", outputs[-1], strides))
         for i in range(2):
             if conn[1][i] == 1:

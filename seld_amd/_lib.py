@@ -153,10 +153,11 @@ SIGNATURES = {
     "seld_m_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "seld_m_gemm_tn_scratch": (_L, [_I, _I]),
     "seld_m_gemm_tn": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "seld_m_bn_stats": (_I, [_P, _L, _I, _P, _P, _P]),
+    "seld_m_bn_scratch": (_L, [_I]),
+    "seld_m_bn_stats": (_I, [_P, _L, _I, _P, _P, _P, _P]),
     "seld_m_bn_apply": (_I, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P]),
     "seld_m_bn_moving": (_I, [_P, _P, _P, _P, _I, _F, _L, _P]),
-    "seld_m_bn_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
+    "seld_m_bn_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P, _P]),
     "seld_m_act": (_I, [_P, _P, _L, _I, _P]),
     "seld_m_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "seld_m_axpy": (_I, [_P, _P, _L, _F, _P]),

@@ -151,6 +151,8 @@ struct seld_ctx {
     // kernel choices the launchers read from process-wide variables (common.h): kept PER CONTEXT here and copied into those variables at the
     // start of every forward / backward pass (apply_kernel_choices), so that setting one on a context never changes another context's arithmetic
     int bwd_four_products = 1, gru_var = 11, conv64_dbuf = 1, tn_tile_blocks = 384, tn_lds_floor = 0, gram_bg_blocks = 192;
+    int rn_epi_stats = 1;                  // resnet50_block: a convolution's BatchNorm statistics leave with its product's epilogue (round 5; 0: the separate pass over z)
+    int rn_epi_add = 1;                    // ... and the identity shortcut's gated gradient is added in the reduce convolution's input-gradient epilogue
     // data parallelism inside the library (seld_dp_*): one RCCL communicator, a communication stream, two events
     void* dp_comm = nullptr;                      // ncclComm_t
     int dp_rank = 0, dp_world = 1;
@@ -664,6 +666,8 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "rn_split_bf16")) { c->rn_split_bf16 = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_wgrad_side")) { c->rn_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_implicit3x3")) { c->rn_implicit3x3 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "rn_epi_stats")) { c->rn_epi_stats = value != 0; return SELD_OK; }
+    if (!strcmp(key, "rn_epi_add")) { c->rn_epi_add = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_wgrad_side")) { c->xc_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_pw_bwd")) { c->xc_fused_pw_bwd = value != 0; return SELD_OK; }
     // per-context kernel choices (apply_kernel_choices copies them into the launchers' variables at the start of each pass)
@@ -1034,6 +1038,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
         // ---- resnet50_block stages (spec/RESNET50_BLOCK.md): every convolution a product (resnet.hip: launch_rn_product_*)
         PROF(c, "rn_stages_fwd");
         const bool sb = c->rn_split_bf16 != 0;
+        const bool epi_stats = training && c->rn_epi_stats;      // BatchNorm statistics in the products' epilogues (common.h GemmEpi)
         if (sb) {      // this step's weight planes, 16 operands per launch
             PROF3(c, "rn_weight_prep");
             const float* src[16]; unsigned short* dst[16]; int ldb[16], tb[16], Ks[16], Ns[16];
@@ -1073,13 +1078,17 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             const bool sc_side = R.proj && c->rn_wgrad_side && !c->sync_fn;
             if (sc_side) {
                 hipEventRecord(c->ev_rn_ready, st); hipStreamWaitEvent(c->side, c->ev_rn_ready, 0);
-                launch_rn_product_fwd(c->side, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w);
-                rn_bn(c, c->side, R.sc, M, training, 0, c->rn_part_side);
+                int nb_ = 0;
+                launch_rn_product_fwd(c->side, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w,
+                                      epi_stats ? c->rn_part_side : nullptr, &nb_);
+                rn_bn(c, c->side, R.sc, M, training, nb_, c->rn_part_side);
                 hipEventRecord(c->ev_rn_free[0], c->side);
             }
             // 1x1 (frequency stride = doubled row stride of the operand), BN, ReLU
-            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w); }
-            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[0], M, training); }
+            int nb0 = 0;
+            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.c[0].w_off, sb ? R.c[0].wsp : nullptr, R.c[0].z, (int)M, R.Cin, w,
+                                                                 epi_stats ? c->rn_part : nullptr, &nb0); }
+            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[0], M, training, nb0); }
             { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply(st, R.c[0].z, R.c[0].coef, nullptr, R.y0, M, w, 1); }
             // 3x3, BN, ReLU: 64 -> 64 (stage 1) on the implicit-GEMM kernel of the conv blocks (BatchNorm's sums from its epilogue),
             // the other widths as a product on im2col rows
@@ -1095,24 +1104,31 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                     { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training, npart); }
                 }
             } else if (sb && rn_c1_implicit(c, R)) {
-                { PROF3(c, "rn_products_fwd"); launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w); }
-                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
+                int nb1 = 0;
+                { PROF3(c, "rn_products_fwd"); launch_rn_conv3_fwd(st, R.y0, R.c[1].wsp, R.c[1].z, B, S, R.Wout, w, w, epi_stats ? c->rn_part : nullptr, &nb1); }
+                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training, nb1); }
             } else {
                 // (only with rn_split_bf16 / rn_implicit3x3 off, or a width no direct kernel takes: the col tensor is allocated here, once)
                 if (!R.c[1].col && dalloc(c, &R.c[1].col, (size_t)M * 9 * w)) return fail(c, SELD_ERR_NOMEM, "im2col tensor");
                 launch_im2col3x3(st, R.y0, R.c[1].col, B, S, R.Wout, w);
-                { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w); }
-                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training); }
+                int nb1 = 0;
+                { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.c[1].col, 9 * w, c->params + R.c[1].w_off, sb ? R.c[1].wsp : nullptr, R.c[1].z, (int)M, 9 * w, w,
+                                                                     epi_stats ? c->rn_part : nullptr, &nb1); }
+                { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[1], M, training, nb1); }
             }
             { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply(st, R.c[1].z, R.c[1].coef, nullptr, R.y1, M, w, 1); }
             // 1x1 expand, BN; shortcut; out = ReLU(y + r)
-            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w); }
-            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[2], M, training); }
+            int nb2 = 0;
+            { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, R.y1, w, c->params + R.c[2].w_off, sb ? R.c[2].wsp : nullptr, R.c[2].z, (int)M, w, 4 * w,
+                                                                 epi_stats ? c->rn_part : nullptr, &nb2); }
+            { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.c[2], M, training, nb2); }
             if (R.proj) {
                 if (sc_side) hipStreamWaitEvent(st, c->ev_rn_free[0], 0);
                 else {
-                    { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w); }
-                    { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.sc, M, training); }
+                    int nbs = 0;
+                    { PROF3(c, "rn_products_fwd"); launch_rn_product_fwd(st, X, R.Cin * R.stride_f, c->params + R.sc.w_off, sb ? R.sc.wsp : nullptr, R.sc.z, (int)M, R.Cin, 4 * w,
+                                                                         epi_stats ? c->rn_part : nullptr, &nbs); }
+                    { PROF3(c, "rn_bn_fwd"); rn_bn(c, st, R.sc, M, training, nbs); }
                 }
                 { PROF3(c, "rn_bn_fwd"); launch_rn_bn_apply2(st, R.c[2].z, R.c[2].coef, R.sc.z, R.sc.coef, R.out, M, 4 * w, save ? R.gate : nullptr); }
             } else {
@@ -1623,14 +1639,20 @@ static int backward_impl(seld_ctx* c, const float* x) {
             { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.c[0], c->rn_ba, nullptr, dz0, M); }
             wgrad(bbi, X, ldx, dz0, (int)M, R.Cin, w, R.c[0].w_off);
             if (R.stride_f > 1) hipMemsetAsync(dX, 0, (size_t)B * S * R.Win * R.Cin * sizeof(float), st);
-            { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0); }
+            // identity block: the shortcut's gated gradient g [gate] is added in this product's epilogue (split-bf16 kernels; 1 = the shape took the
+            // fp32 GEMM and the separate pass below still runs)
+            const bool epi_add = !R.proj && c->rn_epi_add && R.stride_f == 1;
+            int added = 1;
+            { PROF3(c, "rn_products_dgrad"); added = launch_rn_product_dgrad(st, dz0, c->params + R.c[0].w_off, sb ? R.c[0].wsp_t : nullptr, dX, ldx, (int)M, R.Cin, w, 0,
+                                                                             epi_add ? g : nullptr, epi_add ? R.gate : nullptr); }
+            if (added < 0) return fail(c, SELD_ERR_INVALID, "resnet50_block: reduce convolution's input-gradient product");
             // shortcut
             if (R.proj) {
                 float* dzs = take(0, 2, zi);
                 { PROF3(c, "rn_bn_bwd"); rn_bn_bwd(c, st, R.sc, g, R.gate, dzs, M); }
                 wgrad(zi, X, ldx, dzs, (int)M, R.Cin, 4 * w, R.sc.w_off);
                 { PROF3(c, "rn_products_dgrad"); launch_rn_product_dgrad(st, dzs, c->params + R.sc.w_off, sb ? R.sc.wsp_t : nullptr, dX, ldx, (int)M, R.Cin, 4 * w, 1); }
-            } else {
+            } else if (!epi_add || added == 1) {
                 { PROF3(c, "rn_bn_bwd"); launch_rn_add_gated(st, dX, g, R.gate, M * 4 * w); }
             }
             g = dX;

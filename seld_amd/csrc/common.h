@@ -190,9 +190,10 @@ int launch_rn_add_masked(hipStream_t st, float* dst, const float* dy, const floa
 int rn_sb_fwd_ok(int K, int N);
 int rn_sb_dgrad_ok(int K, int N);
 int rn_sb_wgrad_ok(int K, int N);
-int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N);
+int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N,
+                          float* stat_part = nullptr, int* nbx = nullptr);
 int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, const unsigned short* wsp_t, float* dA, int ldd, int M, int K, int N,
-                            int accumulate);
+                            int accumulate, const float* addg = nullptr, const unsigned char* gate4 = nullptr);
 int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float* dz, float* slab, int64_t slab_cap, float* dw, int M, int K, int N,
                             int split_bf16);
 // 3x3 'same' convolution [B*H*W][C] -> [B*H*W][N] with the im2col rows formed on load (C, N powers of two >= 128: rn_conv3_sb_ok);
@@ -201,7 +202,8 @@ int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float
 int launch_rn_w32_embed(hipStream_t st, const float* w, float* w2);
 int launch_rn_w32_extract(hipStream_t st, const float* dw2, float* dw);
 int rn_conv3_sb_ok(int C, int N);
-int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N);
+int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N,
+                        float* stat_part = nullptr, int* nbx = nullptr);
 int launch_rn_conv3_dgrad(hipStream_t st, const float* dz, const unsigned short* wsp_flip, float* dimg, int B, int H, int W, int C, int N);
 int launch_rn_conv3_wgrad(hipStream_t st, const float* img, const float* dz, float* slab, int64_t slab_cap, float* dw, int B, int H, int W, int C, int N);
 // xception.hip: middle flow of xception_block (spec/XCEPTION_BLOCK.md)
@@ -241,6 +243,20 @@ int launch_bn_pool_bwd_dz(hipStream_t st, const float* z, const float* dp, const
                           int B, int H, int W, int C, int pt, int pf);
 int bn_partial_capacity();
 
+// Optional epilogue extras of the NEXT launch_gemm / launch_gemm_sb call of this host thread (resnet50_block, round 5), set by a GemmEpiScope
+// around the call the way BwdFourScope selects the four-product form:
+//   stat_part : the product's BatchNorm statistics leave with its epilogue — per (row block, column) [sum | sum of squares] in the layout
+//               rn_bn_finalize reads (partial[(chunk * nbx + row block) * 128 + {c, 64 + c}], chunk = column / 64, nbx = the launch's row
+//               blocks: gemm_epi_row_blocks) — instead of a separate pass over z.  Requires no bias, no activation, mode 0, no accumulate.
+//   addg, gate4: C += addg [gate bit]  (the identity shortcut's gated gradient added in the reduce convolution's input-gradient epilogue:
+//               gate4[(row * ldc + col) / 4] bit (col & 3), what rn_bn_apply wrote beside the block output; ldc % 4 == 0)
+struct GemmEpi { float* stat_part = nullptr; const float* addg = nullptr; const unsigned char* gate4 = nullptr; };
+extern thread_local GemmEpi g_gemm_epi;
+struct GemmEpiScope {
+    GemmEpiScope(float* stat_part, const float* addg = nullptr, const unsigned char* gate4 = nullptr) { g_gemm_epi.stat_part = stat_part; g_gemm_epi.addg = addg; g_gemm_epi.gate4 = gate4; }
+    ~GemmEpiScope() { g_gemm_epi = GemmEpi(); }
+};
+int gemm_epi_row_blocks(int M, int split_bf16);      // row blocks (= statistics partials per 64-channel chunk) of a launch: 128-row tiles (split-bf16) / 64-row tiles
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bm, int ldb, const float* bias, float* C,
                 int ldc, int M, int N, int K, int transb, int act, int accumulate);
 int launch_gemm_dual_n(hipStream_t st, const float* A, int lda, const float* B0, const float* B1, int ldb, const float* bias0,

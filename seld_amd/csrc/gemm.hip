@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int ldc, int M, int N, int K, int act, int accumulate,
                                                        const float* __restrict__ A1, const float* __restrict__ B1,
                                                        const float* __restrict__ bias1, float* __restrict__ C1, int mode,
-                                                       float* __restrict__ M0, float* __restrict__ M1, int nsplit) {
+                                                       float* __restrict__ M0, float* __restrict__ M1, int nsplit, GemmEpi epi) {
     // mode 0: C = act(A B + bias) (+C).   mode 1 (two products sharing A): column tiles >= ceil(N/64) compute
     // C1 = act(A B1 + bias1).   mode 2 (one product over a concatenated K): C = act(A B + A1 B1 + bias) (+C), K % 32 == 0.
     // mode 3: mode 0, and the result is also stored to C1 (same leading dimension): the caller's copy of a head output.
@@ -142,6 +142,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #undef GEMM_LOAD
 #undef GEMM_COMMIT
     const int col = n0 + wc * 32 + li;
+    if (epi.stat_part) {
+        // BatchNorm statistics of this 64 x 64 tile (common.h GemmEpi; the launcher admits mode 0 without bias / activation / accumulate only):
+        // a lane holds 16 rows of one column, the two row halves meet through a lane swap, the two row waves through LDS (As is free behind the
+        // last chunk's barrier), fixed order; one [sum | sum of squares] partial per (row block, column)
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (m0 + wr * 32 + mfma_row(r, hi) < M) ? acc[r] + acc1[r] : 0.f;
+            s_ += v; q_ = fmaf(v, v, q_);
+        }
+        s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
+        if (hi == 0) { As[(wr * 64 + wc * 32 + li) * 2] = s_; As[(wr * 64 + wc * 32 + li) * 2 + 1] = q_; }
+        lds_barrier();
+        if (tid < 64) {      // (columns past N: zeros, so that a 32-channel product leaves a clean 64-channel partial)
+            const bool in_ = n0 + tid < N;
+            float* pp = epi.stat_part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 128 + tid;
+            pp[0] = in_ ? As[tid * 2] + As[(64 + tid) * 2] : 0.f;
+            pp[64] = in_ ? As[tid * 2 + 1] + As[(64 + tid) * 2 + 1] : 0.f;
+        }
+    }
     if ((mode == 0 || mode == 3) && m0 + wr * 32 + 32 <= M && n0 + wc * 32 + 32 <= N && (ldc & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (mode == 0 || (reinterpret_cast<uintptr_t>(C1) & 15) == 0)) {
         // whole 32 x 32 tile: 4 dwordx4 stores per wave instead of 16 dword stores (common.h: quad_transpose4)
@@ -200,13 +220,16 @@ static int gemm_go(hipStream_t st, const float* A, int lda, const float* Bm, int
                    int mode, float* M0 = nullptr, float* M1 = nullptr, int nsplit = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
     if (mode == 2 && (K & 31)) return -2;
+    const GemmEpi epi = g_gemm_epi;
+    if (epi.stat_part && (bias || act || accumulate || mode)) return -3;
+    if (epi.addg) return -3;      // the gated add lives in the split-bf16 kernels' epilogues only
     dim3 grid((N + 63) / 64 * (mode == 1 ? 2 : 1), (M + 63) / 64);
     if (transb)
         hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
-                           bias1, C1, mode, M0, M1, nsplit);
+                           bias1, C1, mode, M0, M1, nsplit, epi);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, dim3(256), 0, st, A, lda, Bm, ldb, bias, C, ldc, M, N, K, act, accumulate, A1, B1,
-                           bias1, C1, mode, M0, M1, nsplit);
+                           bias1, C1, mode, M0, M1, nsplit, epi);
     return 0;
 }
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
-                                                         int K, int act, int mode, int dbg, int accum) {
+                                                         int K, int act, int mode, int dbg, int accum, GemmEpi epi) {
     __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 5, li = lane & 31;
@@ -233,6 +233,47 @@ __global__ __launch_bounds__(256, NG == 4 ? 2 : 3) void gemm_sb_kernel(const flo
     const bool full = m0 + 32 <= M;   // wave-uniform: every block but the last takes the unguarded stores
     float* crow = C + (size_t)(m0 + 4 * kg) * ldc + n0 + li;
     const int rows_left = M - m0 - 4 * kg;   // rows of this lane's stripe that exist
+    if (epi.stat_part) {
+        // BatchNorm statistics of this 128 x 128 tile (common.h GemmEpi): a lane holds 16 rows of one column per accumulator tile; the two
+        // row halves of a column meet through a lane swap, the four waves through LDS (the B buffers are free: the last chunk's barrier is
+        // behind us), fixed order.  One [sum | sum of squares] partial per (row block, column).
+        float* red = reinterpret_cast<float*>(&Bl[0][0]);
+#define GSB_STAT(ACC_, nt_)                                                                  \
+        {                                                                                    \
+            float s_ = 0.f, q_ = 0.f;                                                        \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                 \
+                const int dr = (r & 3) + 8 * (r >> 2);                                       \
+                const float v = (full || dr < rows_left) ? ACC_[r] : 0.f;                    \
+                s_ += v; q_ = fmaf(v, v, q_);                                                \
+            }                                                                                \
+            s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);                              \
+            if (kg == 0) { red[(wave * 128 + (nt_) * 32 + li) * 2] = s_; red[(wave * 128 + (nt_) * 32 + li) * 2 + 1] = q_; } \
+        }
+        GSB_STAT(acc0, 0) GSB_STAT(acc1, 1) GSB_STAT(acc2, 2) GSB_STAT(acc3, 3)
+#undef GSB_STAT
+        lds_barrier();
+        if (tid < 128) {
+            const float S_ = (red[tid * 2] + red[(128 + tid) * 2]) + (red[(256 + tid) * 2] + red[(384 + tid) * 2]);
+            const float Q_ = (red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]) + (red[(256 + tid) * 2 + 1] + red[(384 + tid) * 2 + 1]);
+            const int gc = n0 + tid;
+            float* pp = epi.stat_part + ((size_t)(gc >> 6) * gridDim.y + blockIdx.y) * 128 + (gc & 63);
+            pp[0] = S_; pp[64] = Q_;
+        }
+    }
+    if (epi.addg) {
+        // C += addg [gate bit]: the identity shortcut's gated gradient (one dword + one byte load per element, whole 128-B segments per row)
+#define GSB_ADDG(ACC_, nt_)                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+            const int dr = (r & 3) + 8 * (r >> 2);                                           \
+            if (full || dr < rows_left) {                                                    \
+                const size_t e_ = (size_t)(m0 + 4 * kg + dr) * ldc + n0 + (nt_) * 32 + li;   \
+                const unsigned g_ = epi.gate4[e_ >> 2];                                      \
+                ACC_[r] += ((g_ >> (e_ & 3)) & 1u) ? epi.addg[e_] : 0.f;                     \
+            }                                                                                \
+        }
+        GSB_ADDG(acc0, 0) GSB_ADDG(acc1, 1) GSB_ADDG(acc2, 2) GSB_ADDG(acc3, 3)
+#undef GSB_ADDG
+    }
 #define GSB_STORE(ACC_, nt_, BV_)                                                            \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
         const int dr = (r & 3) + 8 * (r >> 2);                                               \
@@ -271,7 +312,7 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
                                                          const unsigned short* __restrict__ Bs1,
                                                          const float* __restrict__ bias0, const float* __restrict__ bias1,
                                                          float* __restrict__ C0, float* __restrict__ C1, int ldc, int M, int N,
-                                                         int K, int act, int mode, int accum, int cvs, int cvH, int cvW) {
+                                                         int K, int act, int mode, int accum, int cvs, int cvH, int cvW, GemmEpi epi) {
     __shared__ __attribute__((aligned(16))) unsigned short Al[2][3 * 128 * GSB_KC];      // 2 x 24 KB
     __shared__ __attribute__((aligned(16))) unsigned short Bl[2][3 * GSB_BN * GSB_KC];   // 2 x 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,6 +448,28 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     const int rbase = m0 + wr * 32 + 4 * kg;
     float* crow = C + (size_t)rbase * ldc + col;
     const int rows_left = M - rbase;
+    if (epi.stat_part) {
+        // BatchNorm statistics of this 128 x 128 tile (see gemm_sb_kernel): wave (wr, wc) holds a 32 x 32 tile; row halves by a lane swap, the
+        // four row waves of a column through LDS (the A buffers are free behind the last chunk's barrier), fixed order
+        float* red = reinterpret_cast<float*>(&Al[0][0]);
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float v = dr < rows_left ? acc0[r] + acc1[r] : 0.f;
+            s_ += v; q_ = fmaf(v, v, q_);
+        }
+        s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
+        if (kg == 0) { red[(wr * 128 + wc * 32 + li) * 2] = s_; red[(wr * 128 + wc * 32 + li) * 2 + 1] = q_; }
+        lds_barrier();
+        if (tid < 128) {
+            const float S_ = (red[tid * 2] + red[(128 + tid) * 2]) + (red[(256 + tid) * 2] + red[(384 + tid) * 2]);
+            const float Q_ = (red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]) + (red[(256 + tid) * 2 + 1] + red[(384 + tid) * 2 + 1]);
+            const int gc = n0 + tid;
+            float* pp = epi.stat_part + ((size_t)(gc >> 6) * gridDim.y + blockIdx.y) * 128 + (gc & 63);
+            pp[0] = S_; pp[64] = Q_;
+        }
+    }
     if (m0 + wr * 32 + 32 <= M && ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
         // 4 dwordx4 stores per wave instead of 16 dword stores (common.h: quad_transpose4)
         float* cq = C + (size_t)(rbase + (li & 3)) * ldc + n0 + wc * 32 + (li & ~3);
@@ -425,6 +488,12 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
                 const float4 p_ = *reinterpret_cast<const float4*>(cq + (size_t)(8 * q) * ldc);
                 o_.x += p_.x; o_.y += p_.y; o_.z += p_.z; o_.w += p_.w;
             }
+            if (epi.addg) {      // C += addg [gate bit]: four consecutive columns of one row = one float4 of addg and ONE gate byte
+                const size_t e_ = (size_t)(cq - C) + (size_t)(8 * q) * ldc;
+                const float4 g_ = *reinterpret_cast<const float4*>(epi.addg + e_);
+                const unsigned b_ = epi.gate4[e_ >> 2];
+                o_.x += (b_ & 1) ? g_.x : 0.f; o_.y += (b_ & 2) ? g_.y : 0.f; o_.z += (b_ & 4) ? g_.z : 0.f; o_.w += (b_ & 8) ? g_.w : 0.f;
+            }
             *reinterpret_cast<float4*>(cq + (size_t)(8 * q) * ldc) = o_;
         }
         return;
@@ -437,11 +506,17 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
         else if (act == 2) v = tanhf(v);
         
         else if (act == 3) v = fmaxf(v, 0.f);
+        if (dr < rows_left && epi.addg) {
+            const size_t e_ = (size_t)(rbase + dr) * ldc + col;
+            v += ((epi.gate4[e_ >> 2] >> (e_ & 3)) & 1u) ? epi.addg[e_] : 0.f;
+        }
         if (dr < rows_left) crow[(size_t)dr * ldc] = accum ? v + crow[(size_t)dr * ldc] : v;
     }
 }
 
 int g_gsb_dbg = 0;
+thread_local GemmEpi g_gemm_epi;
+int gemm_epi_row_blocks(int M, int split_bf16) { return split_bf16 ? (M + 127) / 128 : (M + 63) / 64; }
 thread_local int g_gsb_four_now = 0;       // set for the duration of a backward launch (common.h BwdFourScope); per host thread: another thread's forward launch must not read it
 int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, const unsigned short* Bs0, const unsigned short* Bs1,
                    const float* bias0, const float* bias1, float* C0, float* C1, int ldc, int M, int N, int K, int act, int mode,
@@ -454,6 +529,9 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     }
     if (M <= 0 || N <= 0 || K <= 0 || !gemm_sb_usable(A0, lda, N, K)) return -1;
     if (mode == 2 && !gemm_sb_usable(A1, lda, N, K)) return -1;
+    const GemmEpi epi = g_gemm_epi;
+    if (epi.stat_part && (bias0 || act || mode || accum)) return -3;
+    if (epi.addg && (!epi.gate4 || (ldc & 3) || mode)) return -3;
     dim3 grid(N / GSB_BN * (mode == 1 ? 2 : 1), (M + 127) / 128);
     // few column groups: not enough row tiles to give every SIMD more than one wave -> the 16-wave form
     const bool wide = grid.x >= 2;
@@ -461,19 +539,19 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
     // N = 256: 198 us against 264 for the 4-wave form)
     if (cvs ? false : (g_gsb_dbg & 4) ? true : (g_gsb_dbg & 8) ? false : wide) {
 #define GSB_GO(NG_) { if (g_mfma_one) hipLaunchKernelGGL((gemm_sb_kernel<NG_, true>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
-                                       mode, g_gsb_dbg & 3, accum);                                                                                            \
+                                       mode, g_gsb_dbg & 3, accum, epi);                                                                                            \
                       else if (g_gsb_four_now) hipLaunchKernelGGL((gemm_sb_kernel<NG_, false, true>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
-                                       mode, g_gsb_dbg & 3, accum);                                                                                            \
+                                       mode, g_gsb_dbg & 3, accum, epi);                                                                                            \
                       else hipLaunchKernelGGL((gemm_sb_kernel<NG_, false>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
-                                       mode, g_gsb_dbg & 3, accum); }
+                                       mode, g_gsb_dbg & 3, accum, epi); }
         if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4)
         else GSB_GO(0)
 #undef GSB_GO
     } else {
         const int ng = K / GSB_KC * (mode == 2 ? 2 : 1);
-#define G16_GO(NG_, CV_) { if (g_gsb_four_now) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W); \
-                           else hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W); }
-#define G16_GO1(NG_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W)
+#define G16_GO(NG_, CV_) { if (g_gsb_four_now) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W, epi); \
+                           else hipLaunchKernelGGL((gemm_sb16_kernel<NG_, CV_>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W, epi); }
+#define G16_GO1(NG_) hipLaunchKernelGGL((gemm_sb16_kernel<NG_, false, true>), grid, dim3(1024), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, mode, accum, cvs, conv_H, conv_W, epi)
         // bf16 single-product mode: instantiated for the shapes of the headline model (the GRU input gradients, K = 128, and the generic loop);
         // the implicit-convolution and resnet50 shapes keep the exact products
         if (g_mfma_one && !cvs && !(g_gsb_dbg & 16) && (ng == 24 || ng == 4)) { if (ng == 24) G16_GO1(24); else G16_GO1(4); return 0; }

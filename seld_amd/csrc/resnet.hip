@@ -361,18 +361,35 @@ int rn_sb_fwd_ok(int K, int N) { return (K % 32) == 0 && (N % 128) == 0; }      
 int rn_sb_dgrad_ok(int K, int N) { return (N % 32) == 0 && (K % 128) == 0; }             // dA = dz w^T       [M,N] x [N,K]
 int rn_sb_wgrad_ok(int K, int N) { return (K % 128) == 0 && (N % 128) == 0; }            // dw = A^T dz       [K,M] x [M,N]
 
-int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N) {
-    if (wsp && rn_sb_fwd_ok(K, N) && gemm_sb_usable(A, lda, N, K))
+// stat_part (may be null) + nbx: the convolution's BatchNorm statistics leave with the product's epilogue (common.h GemmEpi) — *nbx receives the
+// number of [sum | sum of squares] partials per 64-channel chunk that rn_bn_finalize has to fold
+int launch_rn_product_fwd(hipStream_t st, const float* A, int lda, const float* w, const unsigned short* wsp, float* z, int M, int K, int N,
+                          float* stat_part, int* nbx) {
+    GemmEpiScope epi_(stat_part);
+    if (wsp && rn_sb_fwd_ok(K, N) && gemm_sb_usable(A, lda, N, K)) {
+        if (nbx) *nbx = stat_part ? gemm_epi_row_blocks(M, 1) : 0;
         return launch_gemm_sb(st, A, nullptr, lda, wsp, nullptr, nullptr, nullptr, z, nullptr, N, M, N, K, 0, 0);
+    }
+    if (nbx) *nbx = stat_part ? gemm_epi_row_blocks(M, 0) : 0;
     return launch_gemm(st, A, lda, w, N, nullptr, z, N, M, N, K, 0, 0, 0);
 }
 // wsp_t: the planes of w^T (launch_gemm_split_b with transb = 1, K' = N, N' = K)
+// addg + gate4 (may be null): dA += addg [gate bit] in the product's epilogue (the identity shortcut's gated gradient: common.h GemmEpi) — the
+// split-bf16 kernels only; returns 1 (and adds nothing) where the shape takes the fp32 GEMM: the caller then runs launch_rn_add_gated
 int launch_rn_product_dgrad(hipStream_t st, const float* dz, const float* w, const unsigned short* wsp_t, float* dA, int ldd, int M, int K, int N,
-                            int accumulate) {
+                            int accumulate, const float* addg, const unsigned char* gate4) {
     BwdFourScope four_;
-    if (wsp_t && rn_sb_dgrad_ok(K, N) && gemm_sb_usable(dz, N, K, N))
-        return launch_gemm_sb(st, dz, nullptr, N, wsp_t, nullptr, nullptr, nullptr, dA, nullptr, ldd, M, K, N, 0, 0, accumulate);
-    return launch_gemm(st, dz, N, w, N, nullptr, dA, ldd, M, K, N, 1, 0, accumulate);
+    if (wsp_t && rn_sb_dgrad_ok(K, N) && gemm_sb_usable(dz, N, K, N)) {
+        // the fused add pays in the 16-wave kernel only (one column group: its epilogue holds four consecutive columns of a row per lane = one
+        // float4 of addg and ONE gate byte); in the 4-wave kernel a lane holds 16 rows of one column — 64 dword + 64 byte loads per lane — and the
+        // resnet50_gru step was 0.78 ms SLOWER with it than with the separate three-pass add (round 5, same box)
+        const bool fuse = addg && K == 128;
+        GemmEpiScope epi_(nullptr, fuse ? addg : nullptr, fuse ? gate4 : nullptr);
+        const int rc = launch_gemm_sb(st, dz, nullptr, N, wsp_t, nullptr, nullptr, nullptr, dA, nullptr, ldd, M, K, N, 0, 0, accumulate);
+        return rc ? rc : (addg && !fuse ? 1 : 0);
+    }
+    const int rc = launch_gemm(st, dz, N, w, N, nullptr, dA, ldd, M, K, N, 1, 0, accumulate);
+    return rc ? rc : (addg ? 1 : 0);
 }
 // slab: scratch of slab_cap floats for the row splits, combined in a fixed order into dw
 int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float* dz, float* slab, int64_t slab_cap, float* dw, int M, int K, int N,
@@ -390,7 +407,10 @@ int launch_rn_product_wgrad(hipStream_t st, const float* A, int lda, const float
 // (gemm_sb.hip / gemm_tn_sb.hip: conv_C): no col / dcol tensors, no col2im.  C and N powers of two, multiples of 128 (stages 2-3).
 int rn_conv3_sb_ok(int C, int N) { return C >= 128 && N >= 128 && (C & (C - 1)) == 0 && (N & (N - 1)) == 0; }
 // wsp: launch_gemm_split_b(w [9 C][N], transb 0)
-int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N) {
+int launch_rn_conv3_fwd(hipStream_t st, const float* img, const unsigned short* wsp, float* z, int B, int H, int W, int C, int N, float* stat_part,
+                        int* nbx) {
+    GemmEpiScope epi_(stat_part);
+    if (nbx) *nbx = stat_part ? gemm_epi_row_blocks(B * H * W, 1) : 0;
     return launch_gemm_sb(st, img, nullptr, C, wsp, nullptr, nullptr, nullptr, z, nullptr, N, B * H * W, N, 9 * C, 0, 0, 0, C, H, W);
 }
 // input gradient = the convolution of dz [.][N] with the flipped, channel-swapped kernel; wsp_flip: launch_gemm_split_b(w, ldb N, transb 2, K 9 N, N C)

@@ -59,6 +59,16 @@ def check_mother_config(cfg: dict) -> None:
             raise ValueError(f"{key} {cfg.get(key)!r}: the module operators know {sorted(k for k in ACT if k)}")
 
 
+def dead_layers(cfg: dict):
+    """(first layer dead, second layer dead): a layer whose output reaches neither the block's output nor a later layer — configurations the
+    reference accepts (modules.py:202-222) and whose Keras functional model simply does not contain the layer: no variables, no computation"""
+    f = [int(cfg[f"filters{i}"]) for i in range(3)]
+    c1, c2 = cfg["connect1"], cfg["connect2"]
+    need2 = f[2] > 0 or c2[2] == 1
+    need1 = c2[1] == 1 or (need2 and (f[1] > 0 or c1[1] == 1))
+    return (f[0] > 0 and not need1), (not need2)
+
+
 class _Rt:
     """What every layer shares: the library, the device, the variable store and the operator calls (all on torch's current stream)."""
 
@@ -70,6 +80,7 @@ class _Rt:
         self._views: Dict[str, torch.Tensor] = {}
         self.params = self.grads = self.state = None
         self._slab = None
+        self._bn_scratch = None
 
     # ---- variables
     def var(self, name, shape, trainable=True):
@@ -104,6 +115,13 @@ class _Rt:
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def bn_scratch(self, C):
+        """the BatchNormalization sums' first-stage partials: one buffer per channel count, shared by every layer (calls are in stream order)"""
+        need = int(self.lib.seld_m_bn_scratch(int(C)))
+        if self._bn_scratch is None or self._bn_scratch.numel() < need:
+            self._bn_scratch = self.empty(need)        # (torch allocations are 256-byte aligned: the kernels read it as doubles)
+        return self._bn_scratch
 
     # ---- operator calls
     def st(self):
@@ -192,13 +210,14 @@ class BatchNorm:
         rt.var(f"{name}.moving_mean", (self.C,), trainable=False)
         rt.var(f"{name}.moving_variance", (self.C,), trainable=False)
         self.mean, self.var = rt.empty(self.C), rt.empty(self.C)
+        self.scratch = rt.bn_scratch(self.C)
 
     def forward(self, z, out, B, training, accumulate):
         rt, n = self.rt, self.name
         npix = B * self.H * self.W
         self.z = z
         if training:
-            rt.ck(rt.lib.seld_m_bn_stats(rt.p(z), npix, self.C, rt.p(self.mean), rt.p(self.var), rt.st()))
+            rt.ck(rt.lib.seld_m_bn_stats(rt.p(z), npix, self.C, rt.p(self.mean), rt.p(self.var), rt.p(self.scratch), rt.st()))
             mean, var = self.mean, self.var
             rt.ck(rt.lib.seld_m_bn_moving(rt.p(mean), rt.p(var), rt.p(rt.w(f"{n}.moving_mean")), rt.p(rt.w(f"{n}.moving_variance")), self.C,
                                           BN_MOMENTUM, npix, rt.st()))
@@ -210,7 +229,7 @@ class BatchNorm:
     def backward(self, dy, dz, B):
         rt, n = self.rt, self.name
         rt.ck(rt.lib.seld_m_bn_bwd(rt.p(self.z), rt.p(dy), rt.p(self.mean), rt.p(self.var), rt.p(rt.w(f"{n}.gamma")), BN_EPS, rt.p(dz),
-                                   rt.p(rt.g(f"{n}.gamma")), rt.p(rt.g(f"{n}.beta")), B * self.H * self.W, self.C, rt.st()))
+                                   rt.p(rt.g(f"{n}.gamma")), rt.p(rt.g(f"{n}.beta")), B * self.H * self.W, self.C, rt.p(self.scratch), rt.st()))
 
 
 class _ConvBN:
@@ -243,12 +262,17 @@ class MotherBlock:
         self.act = ACT[cfg.get("activation", "relu")]
         self.f, self.conn, self.strides = f, conn, strides
         shapes = [tuple(in_shape)]
-        self.layers = []      # per layer: dict(kind='conv'|'alias'|'cat', ...)
+        self.layers = []      # per layer: dict(kind='conv'|'alias'|'cat'|'dead', ...)
+        dead = dead_layers(cfg) + (False,)
         for L in range(3):
             src = shapes[-1]
             n_in = L + 1      # outputs[0..L] exist
             lay = {"L": L}
-            if f[L] > 0:
+            if dead[L]:
+                # the layer's output reaches nothing: Keras' functional model does not contain it: no variables, no computation
+                lay.update(kind="dead")
+                out = src if f[L] == 0 else (-(-src[0] // (strides[0] if L == 1 else 1)), -(-src[1] // (strides[1] if L == 1 else 1)), f[L])
+            elif f[L] > 0:
                 s = strides if L == 1 else (1, 1)
                 main = _ConvBN(rt, f"{prefix}.c{L}", f"{prefix}.bn{L}", src, f[L], k[L], s, B)
                 out = main.out_shape
@@ -307,7 +331,9 @@ class MotherBlock:
         res = None
         for lay in self.layers:
             L = lay["L"]
-            if lay["kind"] == "alias":
+            if lay["kind"] == "dead":
+                y = None
+            elif lay["kind"] == "alias":
                 y = outputs[-1]
             elif lay["kind"] == "conv":
                 pre = lay["pre"][:B]
@@ -382,8 +408,8 @@ class MotherBlock:
         for lay in reversed(self.layers):
             L = lay["L"]
             d_out = dy if L == 2 else (slots[slot_of(L + 1)] if written[slot_of(L + 1)] else None)
-            if lay["kind"] == "alias":
-                continue          # outputs[1] IS outputs[0]: its gradient already sits in slot 0
+            if lay["kind"] in ("alias", "dead"):
+                continue          # outputs[1] IS outputs[0]: its gradient already sits in slot 0 / a dead layer has neither variables nor a gradient
             if d_out is None:
                 raise RuntimeError("mother_block: a layer's output reaches nothing (the configuration checks should have refused it)")
             src_i = L             # the layer's main input is outputs[L]

@@ -92,3 +92,26 @@ def test_same_padding_is_tensorflows():
     # H = 5, stride 2: pad_total = (3-1)*2 + 3 - 5 = 2 -> 1 before; W = 6: pad_total = (3-1)*2+3-6 = 1 -> 0 before, 1 after
     # output (0,0) sees input rows -1..1, cols 0..2: the delta at (0,0) meets kernel tap (1,0) = 3
     assert float(y[0, 0, 0, 0]) == 3.0 and float(y.abs().sum()) == 3.0
+
+
+def test_layers_that_reach_nothing_have_no_variables():
+    """The reference's configuration checks (modules.py:202-222) accept blocks in which a layer's output reaches neither a later layer nor the
+    output; its Keras functional model then does not contain that layer.  The oracle's plan and the model's (same rule, tests/test_modules_gpu.py
+    runs both) create no variables for it."""
+    from oracle import modules_oracle as M
+    from seld_amd import modules
+    base = {'filters0': 8, 'filters1': 8, 'filters2': 8, 'kernel_size0': 3, 'kernel_size1': 1, 'kernel_size2': 3, 'connect0': [1], 'connect1': [1, 1],
+            'connect2': [1, 1, 1], 'strides': [1, 1], 'activation': 'relu'}
+    assert M.dead_layers(base) == (False, False) == modules.dead_layers(base)
+    d1 = dict(base, filters2=0, kernel_size2=0, connect2=[1, 1, 0])
+    assert M.dead_layers(d1) == (False, True) == modules.dead_layers(d1)
+    tr, nt, out = M.mother_block_plan(d1, (10, 12, 5), "mb0")
+    assert not any(".c1." in n or ".bn1." in n or ".p1_" in n for n, _ in tr) and any(".c0." in n for n, _ in tr) and out == (10, 12, 13)
+    d0 = dict(base, filters1=0, kernel_size1=0, connect1=[1, 0], connect2=[1, 0, 0])
+    assert M.dead_layers(d0) == (True, False) == modules.dead_layers(d0)
+    tr, nt, out = M.mother_block_plan(d0, (10, 12, 8), "mb0")
+    assert [n.split(".")[1] for n, _ in tr] == ["c2", "c2", "bn2", "bn2"] and out == (10, 12, 8)
+    both = dict(base, filters2=0, kernel_size2=0, connect2=[1, 0, 0])
+    assert M.dead_layers(both) == (True, True) and M.mother_block_plan(both, (10, 12, 5), "mb0")[0] == []
+    for c in (base, d1, d0, both):
+        modules.check_mother_config(c)      # accepted, as the reference accepts them

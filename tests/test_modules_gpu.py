@@ -93,6 +93,12 @@ def test_mother_block_every_branch_kind():
     _block_case([full], (4, 10, 12, 5), seed=5)
     strided = dict(full, strides=[2, 3], connect2=[1, 0, 1], activation='swish')
     _block_case([strided], (4, 10, 12, 8), seed=6)
+    # layers whose output reaches nothing (the reference's checks accept them, Keras' functional model drops them): no variables, no
+    # computation, and the backward pass no longer aborts
+    dead1 = dict(full, filters2=0, kernel_size2=0, connect2=[1, 1, 0], squeeze_ratio=0)          # second layer dead, output = concat(input, first layer)
+    _block_case([dead1], (4, 10, 12, 5), seed=8)
+    dead0 = dict(full, filters1=0, kernel_size1=0, connect1=[1, 0], connect2=[1, 0, 0])          # first layer dead, third layer on the input alone
+    _block_case([dead0], (4, 10, 12, 8), seed=9)
     alias = {'filters0': 0, 'filters1': 6, 'filters2': 0, 'kernel_size0': 0, 'kernel_size1': 3, 'kernel_size2': 0, 'connect0': [1],
              'connect1': [1, 0], 'connect2': [1, 0, 1], 'strides': [1, 3], 'activation': 'relu'}      # model_config/SS5.json's BLOCK0 pattern
     _block_case([alias, dict(alias, strides=[1, 1])], (4, 12, 9, 4), seed=7)
