@@ -142,6 +142,13 @@ __device__ __forceinline__ double rn_sum_partials(const float* __restrict__ part
     const float* p = partial + (size_t)chunk * nbx * 128 + v;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int i = part;
+    // (round 5: the products' epilogues leave up to 1 200 partials per chunk instead of 256 — eight loads in flight per thread, still a fixed order)
+    for (; i + 56 < nbx; i += 64) {
+        const float a = p[(size_t)i * 128], b = p[(size_t)(i + 8) * 128], c = p[(size_t)(i + 16) * 128], d = p[(size_t)(i + 24) * 128];
+        const float e = p[(size_t)(i + 32) * 128], f = p[(size_t)(i + 40) * 128], g = p[(size_t)(i + 48) * 128], h = p[(size_t)(i + 56) * 128];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+        s0 += (double)e; s1 += (double)f; s2 += (double)g; s3 += (double)h;
+    }
     for (; i + 24 < nbx; i += 32) {
         const float a = p[(size_t)i * 128], b = p[(size_t)(i + 8) * 128], c = p[(size_t)(i + 16) * 128], d = p[(size_t)(i + 24) * 128];
         s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
