@@ -97,6 +97,7 @@ struct seld_ctx {
     std::vector<XcUnit> xc;
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
+    size_t xc_slab_per = 0;      // floats per depthwise-slab buffer (xc_slab holds two)
     float *xc_g[4] = {}, *xc_dz2 = nullptr;  // gradient ping-pong buffers [B,S,16,64] (X, F1, F2, second F1); second dz buffer
     int xc_fused_pw_bwd = 1;                 // a unit's BatchNorm' + pointwise input / kernel gradients in one kernel (xc_pw_bwd)
     int xc_wgrad_side = 1;                   // xception_block backward: kernel gradients on the side stream (as rn_wgrad_side)
@@ -151,6 +152,9 @@ struct seld_ctx {
     // kernel choices the launchers read from process-wide variables (common.h): kept PER CONTEXT here and copied into those variables at the
     // start of every forward / backward pass (apply_kernel_choices), so that setting one on a context never changes another context's arithmetic
     int bwd_four_products = 1, gru_var = 11, conv64_dbuf = 1, tn_tile_blocks = 384, tn_lds_floor = 0, gram_bg_blocks = 192;
+    int xc_fused_dw_bwd = 1;               // xception_block: the depthwise kernel gradient's slabs come out of the input-gradient pass (round 5; 0: dw3x3_bwd_w on the side stream)
+    int xc_w16 = 1;                        // xception_block: the row-per-workgroup depthwise kernels for W = 16 (0: the generic kernel)
+    int xc_xcd_map = 1;                    // xception_block: XCD-contiguous row ranges in the depthwise kernels (xception.hip; 0: identity map, for A/B)
     int rn_epi_stats = 1;                  // resnet50_block: a convolution's BatchNorm statistics leave with its product's epilogue (round 5; 0: the separate pass over z)
     int rn_epi_add = 1;                    // ... and the identity shortcut's gated gradient is added in the reduce convolution's input-gradient epilogue
     // data parallelism inside the library (seld_dp_*): one RCCL communicator, a communication stream, two events
@@ -488,7 +492,12 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         ALLOC(c->xc_dz2, npx);
         ALLOC(c->xc_feat, (size_t)B * S * 128);
         ALLOC(c->xc_part, (size_t)xc_partial_capacity() * 128);
-        ALLOC(c->xc_slab, (size_t)xc_partial_capacity() * 576);
+        {   // depthwise kernel-gradient slabs: dw3x3_bwd_w's (<= xc_partial_capacity()) or, with xc_fused_dw_bwd, one per 4 image rows, two buffers
+            // (a unit's combine on the side stream reads one while the next unit's input-gradient kernel fills the other)
+            const size_t per = (size_t)std::max(xc_partial_capacity(), xc_dw_fused_slabs(c->Bmax, c->S)) * 576;
+            ALLOC(c->xc_slab, 2 * per);
+            c->xc_slab_per = per;
+        }
     }
     if (resn) {
         size_t mx_out = 0, mx_w = 0, mx_col = 0, mx_in = (size_t)B * S * 16 * 64;
@@ -679,6 +688,9 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
     if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
+    if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_w16")) { c->xc_w16 = value != 0; return SELD_OK; }               // xception.hip
+    if (!strcmp(key, "xc_xcd_map")) { c->xc_xcd_map = value != 0; return SELD_OK; }       // xception.hip
     if (!strcmp(key, "bf16_single")) { c->bf16_single = value != 0; return SELD_OK; }     // = SELD_DTYPE_BF16 at seld_create
     return fail(c, SELD_ERR_INVALID, std::string("unknown option: ") + key);
 }
@@ -836,6 +848,8 @@ static void apply_kernel_choices(const seld_ctx* c) {
     g_tn_tile_blocks = c->tn_tile_blocks;
     g_tn_lds_floor_kb = c->tn_lds_floor;
     g_gram_bg_blocks = c->gram_bg_blocks;
+    g_xc_xcd_map = c->xc_xcd_map;
+    g_xc_w16 = c->xc_w16;
 }
 
 static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int training, bool save) {
@@ -1733,13 +1747,23 @@ static int backward_impl(seld_ctx* c, const float* x) {
                     launch_gemm(st, dz, 64, c->params + U.pw_off, 64, nullptr, F1c, 64, (int)npix, 64, 64, 1, 0, 0);
                 }
                 PROF2(c, "xc_depthwise_bwd");
-                fork();
-                launch_dw3x3_bwd_w(ws, uin, F1c, c->xc_slab, &ns, B, S, 16, aff);
-                launch_reduce_slabs(ws, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
-                done(sf);
                 // gradient w.r.t. the unit's input, through its ReLU; the module's first unit adds the residual branch's X
                 float* gin = (u == 0 && b == 0) ? c->conv[0].dp : F2;
-                launch_dw3x3_bwd_data(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16, aff);
+                if (c->xc_fused_dw_bwd) {
+                    // ... and the kernel-gradient slabs from the same pass (slab buffer fi: slot `sf` was taken above, i.e. its last combine is done)
+                    float* sl = c->xc_slab + (size_t)fi * c->xc_slab_per;
+                    if (launch_dw3x3_bwd_fused(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, sl, &ns, B, S, 16, aff))
+                        return fail(c, SELD_ERR_UNSUPPORTED, "dw3x3_bwd_fused");
+                    fork();
+                    launch_reduce_slabs(ws, sl, ns, 576, c->grads + U.dw_off, 576, 0);
+                    done(sf);
+                } else {
+                    fork();
+                    launch_dw3x3_bwd_w(ws, uin, F1c, c->xc_slab, &ns, B, S, 16, aff);
+                    launch_reduce_slabs(ws, c->xc_slab, ns, 576, c->grads + U.dw_off, 576, 0);
+                    done(sf);
+                    launch_dw3x3_bwd_data(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, B, S, 16, aff);
+                }
                 gY = gin;
             }
             if (b > 0) { float* t_ = X; X = F2; F2 = t_; }      // the module's input gradient is the next module's output gradient

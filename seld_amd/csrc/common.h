@@ -101,6 +101,8 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
                                   int Cin, int pt, int pf);
 int conv_gram_dim(int Cin);
 extern int g_gram_bg_blocks;
+extern int g_xc_w16;          // xception.hip: row-per-workgroup depthwise kernels for W = 16
+extern int g_xc_xcd_map;      // xception.hip: XCD-contiguous row ranges in the depthwise kernels
 int conv_gram_slab_capacity();
 int conv_msparse_slab_capacity();
 int launch_conv_first_gram(hipStream_t st, const float* x, float* slab, int* n_slab, int B, int H, int Cin, int background = 0, int part = 0, int nparts = 1);
@@ -214,6 +216,10 @@ int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, i
 int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H, int W,
                           const float* aff = nullptr);
 int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W, const float* aff = nullptr);
+// input gradient + kernel-gradient slabs in one pass (W = 16): slab [xc_dw_fused_slabs(B, H)][576]
+int xc_dw_fused_slabs(int B, int H);
+int launch_dw3x3_bwd_fused(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, float* slab, int* nslab,
+                           int B, int H, int W, const float* aff = nullptr);
 int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npartial, int64_t npix);
 int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
                             int* npartial, int64_t npix);

@@ -514,6 +514,132 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
     }
 }
 
+// ---- K = 128, B stationary (round 5) -----------------------------------------------------------------
+// The K = 128 products (GRU input projections: M = 19 200, N = 2 x 384; resnet50_block's 128 -> N convolutions) spend their time around the
+// MFMAs in gemm_sb_kernel<4>: every 128 x 128 tile re-stages its 96 KB of B through a double buffer (4 barriers), and a workgroup's prologue
+// (first loads) and epilogue (64 dword stores per lane) overlap nothing of its own.  Here the WHOLE K extent of a column group's B — 4 chunks x
+// 3 planes x 8 KB = 96 KB — is copied into LDS once per workgroup and stays; the workgroup (8 waves, one per CU) is persistent and its waves are
+// independent from then on: each walks its own 32-row tiles — A rows global -> registers in MFMA layout, split there, 192 MFMAs against the
+// resident B, 16 dwordx4 stores (quad transpose) — with the next tile's rows requested chunk by chunk into the registers the current tile has
+// just consumed.  No barrier after the prologue: one wave's loads and stores sit under another's MFMAs.  The order of the products and of the
+// k-steps is gemm_sb_kernel's, so the results are the same bits.
+template <bool FOUR>
+__device__ __forceinline__ void sbp_step(const float4& x0, const float4& x1, const unsigned short* bb, f32x16& acc0, f32x16& acc1, f32x16& acc2, f32x16& acc3) {
+#define SBP_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
+#define SBP_B4(p_, n0_, n1_, n2_, n3_)                                                                                           \
+    const bf16x8 n0_ = *reinterpret_cast<const bf16x8*>(bb + (p_) * 4096), n1_ = *reinterpret_cast<const bf16x8*>(bb + (p_) * 4096 + 1024), \
+                 n2_ = *reinterpret_cast<const bf16x8*>(bb + (p_) * 4096 + 2048), n3_ = *reinterpret_cast<const bf16x8*>(bb + (p_) * 4096 + 3072);
+    if (FOUR) {
+        unsigned h0, h1, h2, h3, m0, m1, m2, m3;
+        split2r_pair(x0.x, x0.y, h0, m0); split2r_pair(x0.z, x0.w, h1, m1);
+        split2r_pair(x1.x, x1.y, h2, m2); split2r_pair(x1.z, x1.w, h3, m3);
+        const u32x4 h_ = {h0, h1, h2, h3}, m_ = {m0, m1, m2, m3};
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h_), am = __builtin_bit_cast(bf16x8, m_);
+        SBP_B4(0, bh0, bh1, bh2, bh3)
+        SBP_B4(1, bm0, bm1, bm2, bm3)
+        SBP_MFMA(ah, bh0, acc0); SBP_MFMA(ah, bh1, acc1); SBP_MFMA(ah, bh2, acc2); SBP_MFMA(ah, bh3, acc3);
+        SBP_MFMA(ah, bm0, acc0); SBP_MFMA(ah, bm1, acc1); SBP_MFMA(ah, bm2, acc2); SBP_MFMA(ah, bm3, acc3);
+        SBP_MFMA(am, bh0, acc0); SBP_MFMA(am, bh1, acc1); SBP_MFMA(am, bh2, acc2); SBP_MFMA(am, bh3, acc3);
+        SBP_MFMA(am, bm0, acc0); SBP_MFMA(am, bm1, acc1); SBP_MFMA(am, bm2, acc2); SBP_MFMA(am, bm3, acc3);
+    } else {
+        unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+        gsb_split3_pair(x0.x, x0.y, h0, m0, l0); gsb_split3_pair(x0.z, x0.w, h1, m1, l1);
+        gsb_split3_pair(x1.x, x1.y, h2, m2, l2); gsb_split3_pair(x1.z, x1.w, h3, m3, l3);
+        const u32x4 h_ = {h0, h1, h2, h3}, m_ = {m0, m1, m2, m3}, l_ = {l0, l1, l2, l3};
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h_), am = __builtin_bit_cast(bf16x8, m_), al = __builtin_bit_cast(bf16x8, l_);
+        SBP_B4(0, bh0, bh1, bh2, bh3)
+        SBP_B4(1, bm0, bm1, bm2, bm3)
+        SBP_B4(2, bl0, bl1, bl2, bl3)
+        SBP_MFMA(ah, bh0, acc0); SBP_MFMA(ah, bh1, acc1); SBP_MFMA(ah, bh2, acc2); SBP_MFMA(ah, bh3, acc3);   // hi*hi
+        SBP_MFMA(ah, bm0, acc0); SBP_MFMA(ah, bm1, acc1); SBP_MFMA(ah, bm2, acc2); SBP_MFMA(ah, bm3, acc3);   // hi*mid
+        SBP_MFMA(am, bh0, acc0); SBP_MFMA(am, bh1, acc1); SBP_MFMA(am, bh2, acc2); SBP_MFMA(am, bh3, acc3);   // mid*hi
+        SBP_MFMA(ah, bl0, acc0); SBP_MFMA(ah, bl1, acc1); SBP_MFMA(ah, bl2, acc2); SBP_MFMA(ah, bl3, acc3);   // hi*lo
+        SBP_MFMA(al, bh0, acc0); SBP_MFMA(al, bh1, acc1); SBP_MFMA(al, bh2, acc2); SBP_MFMA(al, bh3, acc3);   // lo*hi
+        SBP_MFMA(am, bm0, acc0); SBP_MFMA(am, bm1, acc1); SBP_MFMA(am, bm2, acc2); SBP_MFMA(am, bm3, acc3);   // mid*mid
+    }
+#undef SBP_B4
+#undef SBP_MFMA
+}
+
+template <bool FOUR>
+__global__ __launch_bounds__(512) void gemm_sbp_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Bs0,
+                                                       const unsigned short* __restrict__ Bs1, const float* __restrict__ bias0,
+                                                       const float* __restrict__ bias1, float* __restrict__ C0, float* __restrict__ C1, int ldc, int M,
+                                                       int N, int ngroups, int dbg) {
+    constexpr int NPL = FOUR ? 2 : 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned short sbp_smem[];      // [4 chunks][3 planes][128 columns x 32 k] (FOUR: plane 2 unused)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 5, li = lane & 31;
+    const int ngrp = N / GSB_BN;
+    int grp = blockIdx.x % ngroups;
+    const int wig = blockIdx.x / ngroups, wpg = gridDim.x / ngroups;      // this workgroup among those of its column group
+    const unsigned short* Bs = Bs0;
+    const float* bias = bias0;
+    float* C = C0;
+    if (grp >= ngrp) { grp -= ngrp; Bs = Bs1; bias = bias1; C = C1; }
+    const int n0 = grp * GSB_BN;
+    // B: (chunk c, plane p) of this column group is 8 KB contiguous in the pre-split image, already swizzled
+    if (!(dbg & 8))
+#pragma unroll
+    for (int j = 0; j < 4 * NPL; ++j) {
+        const int c = j / NPL, p = j - c * NPL;
+        reinterpret_cast<u32x4*>(sbp_smem)[(c * 3 + p) * 512 + tid] =
+            reinterpret_cast<const u32x4*>(Bs + ((size_t)(c * 3 + p) * N + n0) * GSB_KC)[tid];
+    }
+    const int ntile = (M + 31) / 32, slots = wpg * 8;
+    int t = wave * wpg + wig;
+    float4 pa[4][4];
+#define SBP_LDA(tile_)                                                                                            \
+    {                                                                                                             \
+        const float4* ap_ = reinterpret_cast<const float4*>(A + (size_t)min((tile_) * 32 + li, M - 1) * lda + 16 * kg); \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                        \
+            pa[c_][0] = ap_[8 * c_]; pa[c_][1] = ap_[8 * c_ + 1]; pa[c_][2] = ap_[8 * c_ + 2]; pa[c_][3] = ap_[8 * c_ + 3]; \
+        }                                                                                                         \
+    }
+    if (t < ntile) SBP_LDA(t)
+#undef SBP_LDA
+    const float4 bv0 = bias ? *reinterpret_cast<const float4*>(bias + n0 + (li & ~3)) : make_float4(0.f, 0.f, 0.f, 0.f),
+                 bv1 = bias ? *reinterpret_cast<const float4*>(bias + n0 + 32 + (li & ~3)) : make_float4(0.f, 0.f, 0.f, 0.f),
+                 bv2 = bias ? *reinterpret_cast<const float4*>(bias + n0 + 64 + (li & ~3)) : make_float4(0.f, 0.f, 0.f, 0.f),
+                 bv3 = bias ? *reinterpret_cast<const float4*>(bias + n0 + 96 + (li & ~3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int swz = (li >> 2) & 3;
+    const int bo0 = li * GSB_KC + (((2 * kg) ^ swz) << 3), bo1 = li * GSB_KC + (((2 * kg + 1) ^ swz) << 3);
+    for (; t < ntile; t += slots) {
+        const int m0 = t * 32;
+        const int tn = t + slots < ntile ? t + slots : t;      // always request (the last tile re-reads itself): no phi on the staged registers
+        const float4* an = reinterpret_cast<const float4*>(A + (size_t)min(tn * 32 + li, M - 1) * lda + 16 * kg);
+        f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16(), acc3 = zero16();
+        // the resident B is loop-invariant: without this the compiler hoists all 96 fragment reads out of the tile loop (and spills them)
+        int o0 = bo0, o1 = bo1;
+        asm volatile("" : "+v"(o0), "+v"(o1));
+        const unsigned short *b0 = sbp_smem + o0, *b1 = sbp_smem + o1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (!(dbg & 1)) sbp_step<FOUR>(pa[g][0], pa[g][1], b0 + g * 3 * 4096, acc0, acc1, acc2, acc3);
+            __builtin_amdgcn_sched_barrier(0);      // one k-step's fragments at a time: two in flight do not fit beside the 64 + 64 registers of acc / A
+            if (!(dbg & 1)) sbp_step<FOUR>(pa[g][2], pa[g][3], b1 + g * 3 * 4096, acc0, acc1, acc2, acc3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 4)) { pa[g][0] = an[8 * g]; pa[g][1] = an[8 * g + 1]; pa[g][2] = an[8 * g + 2]; pa[g][3] = an[8 * g + 3]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (dbg & 2) continue;
+        // a lane holds column li of rows 4 kg + (r & 3) + 8 (r >> 2): 4 x 4 transposes inside each quad of lanes -> one row, 4 columns per lane
+        float* crow = C + (size_t)(m0 + 4 * kg + (li & 3)) * ldc + n0 + (li & ~3);
+        const int rows_left = M - m0 - 4 * kg - (li & 3);
+        const bool full = m0 + 32 <= M;      // wave-uniform: every tile but a ragged last one takes the unguarded stores
+#define SBP_STORE(ACC_, nt_, BV_, GUARD_)                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+            float4 o = quad_transpose4(ACC_[4 * q], ACC_[4 * q + 1], ACC_[4 * q + 2], ACC_[4 * q + 3], li);      \
+            o.x += BV_.x; o.y += BV_.y; o.z += BV_.z; o.w += BV_.w;                                               \
+            if (!(GUARD_) || 8 * q < rows_left) *reinterpret_cast<float4*>(crow + (size_t)(8 * q) * ldc + (nt_) * 32) = o; \
+        }
+        if (full) { SBP_STORE(acc0, 0, bv0, false) SBP_STORE(acc1, 1, bv1, false) SBP_STORE(acc2, 2, bv2, false) SBP_STORE(acc3, 3, bv3, false) }
+        else { SBP_STORE(acc0, 0, bv0, true) SBP_STORE(acc1, 1, bv1, true) SBP_STORE(acc2, 2, bv2, true) SBP_STORE(acc3, 3, bv3, true) }
+#undef SBP_STORE
+    }
+}
+
 int g_gsb_dbg = 0;
 thread_local GemmEpi g_gemm_epi;
 int gemm_epi_row_blocks(int M, int split_bf16) { return split_bf16 ? (M + 127) / 128 : (M + 63) / 64; }
@@ -544,6 +670,22 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
                                        mode, g_gsb_dbg & 3, accum, epi);                                                                                            \
                       else hipLaunchKernelGGL((gemm_sb_kernel<NG_, false>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
                                        mode, g_gsb_dbg & 3, accum, epi); }
+        // K = 128, plain epilogue: B stationary in LDS, persistent workgroups (gemm_sbp_kernel); gsb_dbg bit 6 keeps the tiled form
+        if (K == 128 && mode != 2 && !act && !accum && !epi.stat_part && !epi.addg && !g_mfma_one && !(g_gsb_dbg & (64 | 3)) && /* bits 8-11: ablations */ (int)grid.x <= 128 &&
+            !(ldc & 3) && !(reinterpret_cast<uintptr_t>(C0) & 15) && !(reinterpret_cast<uintptr_t>(C1) & 15)) {
+            const int ngroups = (int)grid.x, wpg = 256 / ngroups;
+            const int need = ((M + 31) / 32 + 7) / 8;      // workgroups per column group that still have a tile for every wave
+            const int w = wpg < need ? wpg : need;
+            const size_t smem = (size_t)4 * 3 * 4096 * sizeof(unsigned short);
+            if (g_gsb_four_now) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sbp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL((gemm_sbp_kernel<true>), dim3(ngroups * w), dim3(512), smem, st, A0, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, ngroups, g_gsb_dbg >> 8);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sbp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL((gemm_sbp_kernel<false>), dim3(ngroups * w), dim3(512), smem, st, A0, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, ngroups, g_gsb_dbg >> 8);
+            }
+            return 0;
+        }
         if (K == 128 && mode != 2 && !(g_gsb_dbg & 32)) GSB_GO(4)
         else GSB_GO(0)
 #undef GSB_GO

@@ -38,8 +38,16 @@ __device__ __forceinline__ float4 fma4v(float4 a, float4 b, float4 c) {
 template <bool BWD, bool AFF>
 __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ src, const float* __restrict__ k, const float* __restrict__ xin,
                                                     const float* __restrict__ add, float* __restrict__ dst, int64_t npix, int H, int W,
-                                                    const float* __restrict__ aff) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                    const float* __restrict__ aff, int xcd_map) {
+    // Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8), and a workgroup of 16 pixels is one image row when W = 16: rows r - 1, r, r + 1
+    // would sit on three different XCDs and every row of src would be fetched into three L2s (measured: 2.3 TB/s of algorithmic bytes with the
+    // identity map).  XCD x takes the x-th CONTIGUOUS eighth of the rows instead: the halo rows hit in its own L2.
+    unsigned lb = blockIdx.x;
+    if (xcd_map) {
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, j = lb >> 3;
+        lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int64_t gid = (int64_t)lb * 256 + threadIdx.x;
     if (gid >= npix * 16) return;
     const int g = (int)(gid & 15);
     const int64_t p = gid >> 4;
@@ -69,17 +77,198 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ sr
     *reinterpret_cast<float4*>(dst + p * 64 + 4 * g) = acc;
 }
 
+// W = 16 (the block's geometry): one workgroup = one image row (16 pixels x 16 channel groups), so the row index, the time index and the row's
+// validity are workgroup-uniform (scalar unit), a lane's offset inside a row is 4 tid floats, and the nine taps are one scalar row base + a
+// 32-bit lane offset each.  The generic kernel above spends ~300 vector + ~300 scalar instructions per float4 of output on 64-bit index
+// arithmetic (p % W, p / W % H), per-tap bounds tests and branches — it ran at 2.3 TB/s of algorithmic bytes, instruction-bound; this form is
+// ~60 vector instructions.  Same taps in the same order, the same fmaf per tap: the same bits.
+template <bool BWD, bool AFF, bool EDGE>
+__device__ __forceinline__ void dw3x3_w16_row(const float* __restrict__ srow, const float4 (&kk)[9], int tid, int t, int H, float4& acc) {
+    const int f = tid >> 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dt = tap / 3 - 1, df = tap % 3 - 1;
+        const int tt = BWD ? t - dt : t + dt, ff = BWD ? f - df : f + df;      // tt: uniform
+        if (EDGE && (tt < 0 || tt >= H)) continue;
+        const bool okf = df == 0 || (ff >= 0 && ff < 16);
+        const float* q = srow + (BWD ? -1 : 1) * (dt * 1024 + df * 64) + 4 * tid;
+        const float4 v = okf ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = fma4v(kk[tap], v, acc);
+    }
+}
+template <bool BWD, bool AFF>
+__global__ __launch_bounds__(256) void dw3x3_w16_kernel(const float* __restrict__ src, const float* __restrict__ k, const float* __restrict__ xin,
+                                                        const float* __restrict__ add, float* __restrict__ dst, int nrows, int H,
+                                                        const float* __restrict__ aff, int xcd_map) {
+    unsigned lb = blockIdx.x;
+    if (xcd_map) {      // XCD x takes the x-th contiguous eighth of the rows (see dw3x3_kernel)
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, j = lb >> 3;
+        lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tid = threadIdx.x, g = tid & 15;
+    const int t = (int)(lb % (unsigned)H);
+    const float* srow = src + (size_t)lb * 1024;
+    float4 kk[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) kk[tap] = reinterpret_cast<const float4*>(k + tap * 64)[g];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv = make_float4(1.f, 1.f, 1.f, 1.f), av = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BWD) {
+        xv = *reinterpret_cast<const float4*>(xin + (size_t)lb * 1024 + 4 * tid);
+        if (add) av = *reinterpret_cast<const float4*>(add + (size_t)lb * 1024 + 4 * tid);
+    }
+    if (!BWD && AFF) {
+        // forward with the previous unit's BatchNormalization folded into the loads: relu(x scale + shift) per tap (fallback path: xc_fused_fwd = 0)
+        const float4 sc = reinterpret_cast<const float4*>(aff)[g], sh = reinterpret_cast<const float4*>(aff + 64)[g];
+        const int f = tid >> 4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dt = tap / 3 - 1, df = tap % 3 - 1;
+            const int tt = t + dt, ff = f + df;
+            if (tt < 0 || tt >= H) continue;
+            if (ff >= 0 && ff < 16) {
+                float4 v = *reinterpret_cast<const float4*>(srow + dt * 1024 + df * 64 + 4 * tid);
+                v = relu4(fma4v(v, sc, sh));
+                acc = fma4v(kk[tap], v, acc);
+            }
+        }
+    } else if (t > 0 && t < H - 1) {
+        if (BWD) dw3x3_w16_row<true, AFF, false>(srow, kk, tid, t, H, acc);
+        else {
+            // forward on a stored activation: ReLU on load
+            const int f = tid >> 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dt = tap / 3 - 1, df = tap % 3 - 1, ff = f + df;
+                const bool okf = df == 0 || (ff >= 0 && ff < 16);
+                const float4 v = okf ? relu4(*reinterpret_cast<const float4*>(srow + dt * 1024 + df * 64 + 4 * tid)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = fma4v(kk[tap], v, acc);
+            }
+        }
+    } else {
+        if (BWD) dw3x3_w16_row<true, AFF, true>(srow, kk, tid, t, H, acc);
+        else {
+            const int f = tid >> 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dt = tap / 3 - 1, df = tap % 3 - 1, tt = t + dt, ff = f + df;
+                if (tt < 0 || tt >= H) continue;
+                const bool okf = df == 0 || (ff >= 0 && ff < 16);
+                const float4 v = okf ? relu4(*reinterpret_cast<const float4*>(srow + dt * 1024 + df * 64 + 4 * tid)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = fma4v(kk[tap], v, acc);
+            }
+        }
+    }
+    if (BWD) {
+        if (AFF) xv = fma4v(xv, reinterpret_cast<const float4*>(aff)[g], reinterpret_cast<const float4*>(aff + 64)[g]);
+        acc = make_float4(xv.x > 0.f ? acc.x : 0.f, xv.y > 0.f ? acc.y : 0.f, xv.z > 0.f ? acc.z : 0.f, xv.w > 0.f ? acc.w : 0.f);
+        if (add) acc = make_float4(acc.x + av.x, acc.y + av.y, acc.z + av.z, acc.w + av.w);
+    }
+    *reinterpret_cast<float4*>(dst + (size_t)lb * 1024 + 4 * tid) = acc;
+}
+
+// Input gradient AND kernel-gradient slabs of the depthwise convolution in one pass (W = 16; round 5).  dk[tap][c] = sum_p a[p + tap][c] dy[p][c]
+// is, summed over q = p + tap instead,  sum_q a[q][c] dy[q - tap][c]:  the thread that forms dx[q] = [a[q] > 0] sum_tap k[tap] dy[q - tap] already
+// holds all nine dy[q - tap] and its own a[q] (the ReLU gate's source) in registers, so the kernel gradient costs nine more float4 FMAs per
+// output and NO loads: the separate pass over (unit input, dy) — 157 MB per unit, dw3x3_bwd_w at 1.6 TB/s on the side stream — is gone.
+// A workgroup takes XD_R consecutive image rows (256 threads = 16 pixels x 16 channel groups, one row at a time, each row's nine loads
+// independent of the previous row's), keeps dk in 36 registers across them and leaves ONE slab [9][64]: columns combined through LDS in a
+// fixed order, slabs by reduce_slabs in a fixed order.  The tap weights sit in LDS (re-read per row: registers are what bounds the occupancy
+// this load-latency-bound kernel lives on).
+#define XD_R 4
+template <bool AFF>
+__global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ k, const float* __restrict__ xin,
+                                                                  const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ slab,
+                                                                  int nrows, int H, const float* __restrict__ aff, int xcd_map) {
+    __shared__ __attribute__((aligned(16))) float ks[9 * 64];
+    __shared__ __attribute__((aligned(16))) float red[16][9 * 64 + 4];
+    unsigned lb = blockIdx.x;
+    if (xcd_map) {
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, j = lb >> 3;
+        lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tid = threadIdx.x, g = tid & 15, f = tid >> 4;
+    for (int i = tid; i < 9 * 16; i += 256) reinterpret_cast<float4*>(ks)[i] = reinterpret_cast<const float4*>(k)[i];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AFF) { sc = reinterpret_cast<const float4*>(aff)[g]; sh = reinterpret_cast<const float4*>(aff + 64)[g]; }
+    float4 dk[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) dk[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int r0 = (int)lb * XD_R;
+#pragma unroll 1
+    for (int i = 0; i < XD_R; ++i) {
+        const int r = r0 + i;
+        if (r >= nrows) break;
+        const int t = r % H;                                        // uniform
+        const float* srow = dy + (size_t)r * 1024 + 4 * tid;
+        float4 xv = *reinterpret_cast<const float4*>(xin + (size_t)r * 1024 + 4 * tid);
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add) av = *reinterpret_cast<const float4*>(add + (size_t)r * 1024 + 4 * tid);
+        float4 v[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {                         // dy[q - tap]: all nine loads in flight before the first FMA
+            const int dt = tap / 3 - 1, df = tap % 3 - 1;
+            const int tt = t - dt, ff = f - df;
+            const bool ok = tt >= 0 && tt < H && (df == 0 || (ff >= 0 && ff < 16));
+            v[tap] = ok ? *reinterpret_cast<const float4*>(srow - (dt * 1024 + df * 64)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (AFF) xv = fma4v(xv, sc, sh);
+        const float4 a = relu4(xv);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc = fma4v(reinterpret_cast<const float4*>(ks)[tap * 16 + g], v[tap], acc);
+            dk[tap] = fma4v(a, v[tap], dk[tap]);
+        }
+        acc = make_float4(xv.x > 0.f ? acc.x : 0.f, xv.y > 0.f ? acc.y : 0.f, xv.z > 0.f ? acc.z : 0.f, xv.w > 0.f ? acc.w : 0.f);
+        if (add) acc = make_float4(acc.x + av.x, acc.y + av.y, acc.z + av.z, acc.w + av.w);
+        *reinterpret_cast<float4*>(dx + (size_t)r * 1024 + 4 * tid) = acc;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<float4*>(&red[f][tap * 64 + 4 * g]) = dk[tap];
+    __syncthreads();
+    for (int i = tid; i < 9 * 64; i += 256) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) s_ += red[sl][i];
+        slab[(size_t)lb * 576 + i] = s_;
+    }
+}
+int xc_dw_fused_slabs(int B, int H) { return (B * H + XD_R - 1) / XD_R; }
+int launch_dw3x3_bwd_fused(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, float* slab, int* nslab,
+                           int B, int H, int W, const float* aff) {
+    if (W != 16 || (int64_t)B * H >= (1 << 30)) return -3;
+    const int nb = xc_dw_fused_slabs(B, H);
+    if (aff) hipLaunchKernelGGL(dw3x3_w16_bwd_fused_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map);
+    else hipLaunchKernelGGL(dw3x3_w16_bwd_fused_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map);
+    *nslab = nb;
+    return 0;
+}
+
+int g_xc_w16 = 1;          // option "xc_w16": the row-per-workgroup depthwise kernels for W = 16 (0: the generic kernel, for A/B)
+int g_xc_xcd_map = 1;      // option "xc_xcd_map": XCD-contiguous row ranges in the depthwise kernels (0: identity map, for A/B)
 int launch_dw3x3_fwd(hipStream_t st, const float* x, const float* k, float* y, int B, int H, int W, const float* aff) {
     const int64_t npix = (int64_t)B * H * W;
-    if (aff) hipLaunchKernelGGL((dw3x3_kernel<false, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff);
-    else hipLaunchKernelGGL((dw3x3_kernel<false, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff);
+    if (W == 16 && g_xc_w16 && (int64_t)B * H < (1 << 30)) {
+        if (aff) hipLaunchKernelGGL((dw3x3_w16_kernel<false, true>), dim3((unsigned)(B * H)), dim3(256), 0, st, x, k, nullptr, nullptr, y, B * H, H, aff, g_xc_xcd_map);
+        else hipLaunchKernelGGL((dw3x3_w16_kernel<false, false>), dim3((unsigned)(B * H)), dim3(256), 0, st, x, k, nullptr, nullptr, y, B * H, H, aff, g_xc_xcd_map);
+        return 0;
+    }
+    if (aff) hipLaunchKernelGGL((dw3x3_kernel<false, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff, g_xc_xcd_map);
+    else hipLaunchKernelGGL((dw3x3_kernel<false, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, k, nullptr, nullptr, y, npix, H, W, aff, g_xc_xcd_map);
     return 0;
 }
 int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, int B, int H,
                           int W, const float* aff) {
     const int64_t npix = (int64_t)B * H * W;
-    if (aff) hipLaunchKernelGGL((dw3x3_kernel<true, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff);
-    else hipLaunchKernelGGL((dw3x3_kernel<true, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff);
+    if (W == 16 && g_xc_w16 && (int64_t)B * H < (1 << 30)) {
+        if (aff) hipLaunchKernelGGL((dw3x3_w16_kernel<true, true>), dim3((unsigned)(B * H)), dim3(256), 0, st, dy, k, xin, add, dx, B * H, H, aff, g_xc_xcd_map);
+        else hipLaunchKernelGGL((dw3x3_w16_kernel<true, false>), dim3((unsigned)(B * H)), dim3(256), 0, st, dy, k, xin, add, dx, B * H, H, aff, g_xc_xcd_map);
+        return 0;
+    }
+    if (aff) hipLaunchKernelGGL((dw3x3_kernel<true, true>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff, g_xc_xcd_map);
+    else hipLaunchKernelGGL((dw3x3_kernel<true, false>), dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, dy, k, xin, add, dx, npix, H, W, aff, g_xc_xcd_map);
     return 0;
 }
 
