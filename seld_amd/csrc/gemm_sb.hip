@@ -521,8 +521,10 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const float* __restrict
 // 3 planes x 8 KB = 96 KB — is copied into LDS once per workgroup and stays; the workgroup (8 waves, one per CU) is persistent and its waves are
 // independent from then on: each walks its own 32-row tiles — A rows global -> registers in MFMA layout, split there, 192 MFMAs against the
 // resident B, 16 dwordx4 stores (quad transpose) — with the next tile's rows requested chunk by chunk into the registers the current tile has
-// just consumed.  No barrier after the prologue: one wave's loads and stores sit under another's MFMAs.  The order of the products and of the
-// k-steps is gemm_sb_kernel's, so the results are the same bits.
+// just consumed.  No barrier after the prologue.  The order of the products and of the k-steps is gemm_sb_kernel's, so the results are the same
+// bits.  MEASURED (M = 19 200, N = 2 x 384): 31.6 us against the tiled form's 32.6 — with 600 row tiles per column group a wave gets 1.8 tiles, all
+// waves start in phase, and the first tile's loads (7 us of A through L2, six column groups re-reading it) and the last tile's stores (59 MB, 11 us)
+// overlap nothing: base 5.3 + B 1.6 + A 7 + MFMA 11 + stores 11 us add up almost serially in BOTH forms.  Kept as an opt-in (gsb_dbg bit 6).
 template <bool FOUR>
 __device__ __forceinline__ void sbp_step(const float4& x0, const float4& x1, const unsigned short* bb, f32x16& acc0, f32x16& acc1, f32x16& acc2, f32x16& acc3) {
 #define SBP_MFMA(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC_, 0, 0, 0)
@@ -670,8 +672,9 @@ int launch_gemm_sb(hipStream_t st, const float* A0, const float* A1, int lda, co
                                        mode, g_gsb_dbg & 3, accum, epi);                                                                                            \
                       else hipLaunchKernelGGL((gemm_sb_kernel<NG_, false>), grid, dim3(256), 0, st, A0, A1, lda, Bs0, Bs1, bias0, bias1, C0, C1, ldc, M, N, K, act, \
                                        mode, g_gsb_dbg & 3, accum, epi); }
-        // K = 128, plain epilogue: B stationary in LDS, persistent workgroups (gemm_sbp_kernel); gsb_dbg bit 6 keeps the tiled form
-        if (K == 128 && mode != 2 && !act && !accum && !epi.stat_part && !epi.addg && !g_mfma_one && !(g_gsb_dbg & (64 | 3)) && /* bits 8-11: ablations */ (int)grid.x <= 128 &&
+        // K = 128, plain epilogue: B stationary in LDS, persistent workgroups (gemm_sbp_kernel) — an opt-in (gsb_dbg bit 6): measured equal to the tiled form
+        // (31.6 against 32.6 us at the GRU input projections' shape, the same bits; profiles/r05_gru_experiments.txt)
+        if (K == 128 && mode != 2 && !act && !accum && !epi.stat_part && !epi.addg && !g_mfma_one && (g_gsb_dbg & 64) && !(g_gsb_dbg & 3) && /* bits 8-11: ablations */ (int)grid.x <= 128 &&
             !(ldc & 3) && !(reinterpret_cast<uintptr_t>(C0) & 15) && !(reinterpret_cast<uintptr_t>(C1) & 15)) {
             const int ngroups = (int)grid.x, wpg = 256 / ngroups;
             const int need = ((M + 31) / 32 + 7) / 8;      // workgroups per column group that still have a tile for every wave

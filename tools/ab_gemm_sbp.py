@@ -1,4 +1,4 @@
-"""A/B of the K = 128 products: gemm_sbp_kernel (B stationary, persistent workgroups; the default) against gemm_sb_kernel<4> (option gsb_dbg bit 6),
+"""A/B of the K = 128 products: gemm_sbp_kernel (B stationary, persistent workgroups; option gsb_dbg bit 6) against gemm_sb_kernel<4> (the default),
 same inputs: bit equality of the results and HIP-event timings.  Shapes: the GRU input projections (mode 1, N = 2 x 384), resnet50_block's
 128 -> 512 product (mode 0), ragged row counts."""
 import ctypes as C
@@ -38,8 +38,8 @@ def run(M, N, mode, dbg, reps):
 
 
 for M, N, mode in [(19200, 384, 1), (38400, 512, 0), (19200, 256, 0), (19200 - 13, 384, 1), (100, 256, 0), (33, 384, 1)]:
-    n0, n1, t_new, a, b0, bias0 = run(M, N, mode, 0, 20)
-    o0, o1, t_old, _, _, _ = run(M, N, mode, 64, 20)
+    n0, n1, t_new, a, b0, bias0 = run(M, N, mode, 64, 20)
+    o0, o1, t_old, _, _, _ = run(M, N, mode, 0, 20)
     same = torch.equal(n0, o0) and (not mode or torch.equal(n1, o1))
     ref = a.double() @ b0.double() + bias0.double()
     err = float((n0.double() - ref).abs().max() / ref.abs().max())

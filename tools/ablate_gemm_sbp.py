@@ -16,8 +16,8 @@ b0, b1 = torch.randn(128, N, device="cuda"), torch.randn(128, N, device="cuda")
 bias = torch.randn(N, device="cuda")
 c0, c1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
 args = (P(a), None, P(b0), P(b1), P(bias), P(bias), P(c0), P(c1), M, N, 128, 0, 0, 1)
-for name, dbg in [("tiled", 64), ("stationary", 0), ("no mfma", 1 << 8), ("no stores", 2 << 8), ("no next loads", 4 << 8), ("no B staging", 8 << 8),
-                  ("no mfma, no stores", 3 << 8), ("nothing but staging", 7 << 8), ("nothing", 15 << 8)]:
+for name, dbg in [("tiled", 0), ("stationary", 64), ("no mfma", 64 | 1 << 8), ("no stores", 64 | 2 << 8), ("no next loads", 64 | 4 << 8), ("no B staging", 64 | 8 << 8),
+                  ("no mfma, no stores", 64 | 3 << 8), ("nothing but staging", 64 | 7 << 8), ("nothing", 64 | 15 << 8)]:
     lib.seld_k_set_option(b"gsb_dbg", dbg)
     for _ in range(3):
         assert lib.seld_k_gemm_sb(*args) == 0
