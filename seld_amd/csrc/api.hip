@@ -97,6 +97,7 @@ struct seld_ctx {
     std::vector<XcUnit> xc;
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
+    float* xc_part_dw = nullptr;      // BatchNorm-backward partials left by the fused depthwise input-gradient pass, one [128] per workgroup
     size_t xc_slab_per = 0;      // floats per depthwise-slab buffer (xc_slab holds two)
     float *xc_g[4] = {}, *xc_dz2 = nullptr;  // gradient ping-pong buffers [B,S,16,64] (X, F1, F2, second F1); second dz buffer
     int xc_fused_pw_bwd = 1;                 // a unit's BatchNorm' + pointwise input / kernel gradients in one kernel (xc_pw_bwd)
@@ -152,6 +153,7 @@ struct seld_ctx {
     // kernel choices the launchers read from process-wide variables (common.h): kept PER CONTEXT here and copied into those variables at the
     // start of every forward / backward pass (apply_kernel_choices), so that setting one on a context never changes another context's arithmetic
     int bwd_four_products = 1, gru_var = 11, conv64_dbuf = 1, tn_tile_blocks = 384, tn_lds_floor = 0, gram_bg_blocks = 192;
+    int xc_fused_bn_sums = 1;              // ... and, for a folded unit, the previous BatchNormalization's backward sums too (0: xc_reduce's pass over (z, gY))
     int xc_fused_dw_bwd = 1;               // xception_block: the depthwise kernel gradient's slabs come out of the input-gradient pass (round 5; 0: dw3x3_bwd_w on the side stream)
     int xc_w16 = 1;                        // xception_block: the row-per-workgroup depthwise kernels for W = 16 (0: the generic kernel)
     int xc_xcd_map = 1;                    // xception_block: XCD-contiguous row ranges in the depthwise kernels (xception.hip; 0: identity map, for A/B)
@@ -497,6 +499,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             const size_t per = (size_t)std::max(xc_partial_capacity(), xc_dw_fused_slabs(c->Bmax, c->S)) * 576;
             ALLOC(c->xc_slab, 2 * per);
             c->xc_slab_per = per;
+            ALLOC(c->xc_part_dw, (size_t)xc_dw_fused_slabs(c->Bmax, c->S) * 128);
         }
     }
     if (resn) {
@@ -688,6 +691,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
     if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
+    if (!strcmp(key, "xc_fused_bn_sums")) { c->xc_fused_bn_sums = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_w16")) { c->xc_w16 = value != 0; return SELD_OK; }               // xception.hip
     if (!strcmp(key, "xc_xcd_map")) { c->xc_xcd_map = value != 0; return SELD_OK; }       // xception.hip
@@ -1703,6 +1707,8 @@ static int backward_impl(seld_ctx* c, const float* x) {
         };
         auto fork = [&]() { if (aside) { hipEventRecord(c->ev_rn_ready, st); hipStreamWaitEvent(c->side, c->ev_rn_ready, 0); } };
         auto done = [&](int slot) { if (aside) { hipEventRecord(c->ev_rn_free[slot], c->side); busy[slot] = true; } };
+        bool have_sums = false;      // the running unit's BatchNorm-backward partials are in xc_part_dw (n_dw_part rows)
+        int n_dw_part = 0;
         for (int b = (int)c->arch.xc_blocks - 1; b >= 0; --b) {
             const float* gY = X;
             for (int u = 2; u >= 0; --u) {
@@ -1717,7 +1723,10 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 if (!fpw) { sd = take(0, di); dz = dzb[di]; }
                 {
                     PROF2(c, "xc_bn_bwd");
-                    launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
+                    // the sums [sum gY | sum gY xhat]: left by the depthwise input-gradient pass that produced gY (have_sums), else a pass over (z, gY)
+                    if (have_sums) launch_xc_fold_partials(st, c->xc_part_dw, n_dw_part, c->xc_part, &np);
+                    else launch_xc_bn_bwd_reduce(st, U.z, gY, U.mean, U.invstd, c->xc_part, &np, npix);
+                    have_sums = false;
                     if (c->sync_fn) {
                         launch_bn_partials_to_sums(st, c->xc_part, np, c->sync_buf, (double)npix);
                         launch_bn_bwd_local(st, c->sync_buf, c->grads + U.g_off, c->grads + U.be_off);
@@ -1752,8 +1761,13 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 if (c->xc_fused_dw_bwd) {
                     // ... and the kernel-gradient slabs from the same pass (slab buffer fi: slot `sf` was taken above, i.e. its last combine is done)
                     float* sl = c->xc_slab + (size_t)fi * c->xc_slab_per;
-                    if (launch_dw3x3_bwd_fused(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, sl, &ns, B, S, 16, aff))
+                    // a folded unit's input is the previous unit's pre-BN tensor and gin that BatchNormalization's output gradient: its backward sums ride along
+                    const bool sums = fold && c->xc_fused_bn_sums;
+                    const XcUnit* Pv = sums ? &c->xc[(size_t)b * 3 + u - 1] : nullptr;
+                    if (launch_dw3x3_bwd_fused(st, F1c, c->params + U.dw_off, uin, u == 0 ? X : nullptr, gin, sl, &ns, B, S, 16, aff,
+                                               sums ? Pv->mean : nullptr, sums ? Pv->invstd : nullptr, sums ? c->xc_part_dw : nullptr))
                         return fail(c, SELD_ERR_UNSUPPORTED, "dw3x3_bwd_fused");
+                    if (sums) { have_sums = true; n_dw_part = ns; }
                     fork();
                     launch_reduce_slabs(ws, sl, ns, 576, c->grads + U.dw_off, 576, 0);
                     done(sf);

@@ -218,8 +218,11 @@ int launch_dw3x3_bwd_data(hipStream_t st, const float* dy, const float* k, const
 int launch_dw3x3_bwd_w(hipStream_t st, const float* x, const float* dy, float* slab, int* nslab, int B, int H, int W, const float* aff = nullptr);
 // input gradient + kernel-gradient slabs in one pass (W = 16): slab [xc_dw_fused_slabs(B, H)][576]
 int xc_dw_fused_slabs(int B, int H);
+// bn_partial (aff units only): + the backward sums of the BatchNormalization whose pre-BN tensor is xin, [xc_dw_fused_slabs][128]; fold with launch_xc_fold_partials
 int launch_dw3x3_bwd_fused(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, float* slab, int* nslab,
-                           int B, int H, int W, const float* aff = nullptr);
+                           int B, int H, int W, const float* aff = nullptr, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
+                           float* bn_partial = nullptr);
+int launch_xc_fold_partials(hipStream_t st, const float* partial, int n, float* out, int* nout);
 int launch_xc_bn_stats(hipStream_t st, const float* z, float* partial, int* npartial, int64_t npix);
 int launch_xc_bn_bwd_reduce(hipStream_t st, const float* z, const float* dy, const float* mean, const float* invstd, float* partial,
                             int* npartial, int64_t npix);

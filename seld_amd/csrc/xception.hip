@@ -175,13 +175,20 @@ __global__ __launch_bounds__(256) void dw3x3_w16_kernel(const float* __restrict_
 // independent of the previous row's), keeps dk in 36 registers across them and leaves ONE slab [9][64]: columns combined through LDS in a
 // fixed order, slabs by reduce_slabs in a fixed order.  The tap weights sit in LDS (re-read per row: registers are what bounds the occupancy
 // this load-latency-bound kernel lives on).
+// STATS (AFF units: xin is the PREVIOUS unit's pre-BN tensor z and dx is that BatchNormalization's output gradient): the backward sums of that
+// BatchNormalization — [sum dx | sum dx xhat], xhat = (z - mean) invstd, xc_reduce_kernel<true>'s arithmetic per element — leave with the slab, one
+// [128] partial per workgroup (bn_partial; folded 64 to 1 by xc_fold_partials before the finalisation): its separate pass over (z, dx) is gone too.
 #define XD_R 4
-template <bool AFF>
+#define XD_ROW (9 * 64 + 128 + 4)
+template <bool AFF, bool STATS>
 __global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ k, const float* __restrict__ xin,
                                                                   const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ slab,
-                                                                  int nrows, int H, const float* __restrict__ aff, int xcd_map) {
+                                                                  int nrows, int H, const float* __restrict__ aff, int xcd_map,
+                                                                  const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
+                                                                  float* __restrict__ bn_partial) {
+    static_assert(!STATS || AFF, "the sums belong to the BatchNormalization folded into this unit's loads");
     __shared__ __attribute__((aligned(16))) float ks[9 * 64];
-    __shared__ __attribute__((aligned(16))) float red[16][9 * 64 + 4];
+    __shared__ __attribute__((aligned(16))) float red[16][XD_ROW];
     unsigned lb = blockIdx.x;
     if (xcd_map) {
         const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, j = lb >> 3;
@@ -194,6 +201,8 @@ __global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* _
     float4 dk[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) dk[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
+    if (STATS) { mu = reinterpret_cast<const float4*>(bn_mean)[g]; is = reinterpret_cast<const float4*>(bn_invstd)[g]; }
     __syncthreads();
     const int r0 = (int)lb * XD_R;
 #pragma unroll 1
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* _
             const bool ok = tt >= 0 && tt < H && (df == 0 || (ff >= 0 && ff < 16));
             v[tap] = ok ? *reinterpret_cast<const float4*>(srow - (dt * 1024 + df * 64)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const float4 zv = xv;
         if (AFF) xv = fma4v(xv, sc, sh);
         const float4 a = relu4(xv);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -224,24 +234,56 @@ __global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* _
         acc = make_float4(xv.x > 0.f ? acc.x : 0.f, xv.y > 0.f ? acc.y : 0.f, xv.z > 0.f ? acc.z : 0.f, xv.w > 0.f ? acc.w : 0.f);
         if (add) acc = make_float4(acc.x + av.x, acc.y + av.y, acc.z + av.z, acc.w + av.w);
         *reinterpret_cast<float4*>(dx + (size_t)r * 1024 + 4 * tid) = acc;
+        if (STATS) {
+            s1 = make_float4(s1.x + acc.x, s1.y + acc.y, s1.z + acc.z, s1.w + acc.w);
+            s2 = make_float4(s2.x + acc.x * (zv.x - mu.x) * is.x, s2.y + acc.y * (zv.y - mu.y) * is.y, s2.z + acc.z * (zv.z - mu.z) * is.z,
+                             s2.w + acc.w * (zv.w - mu.w) * is.w);
+        }
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<float4*>(&red[f][tap * 64 + 4 * g]) = dk[tap];
+    if (STATS) {
+        *reinterpret_cast<float4*>(&red[f][576 + 4 * g]) = s1;
+        *reinterpret_cast<float4*>(&red[f][640 + 4 * g]) = s2;
+    }
     __syncthreads();
-    for (int i = tid; i < 9 * 64; i += 256) {
+    for (int i = tid; i < (STATS ? 9 * 64 + 128 : 9 * 64); i += 256) {
         float s_ = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 16; ++sl) s_ += red[sl][i];
-        slab[(size_t)lb * 576 + i] = s_;
+        if (i < 576) slab[(size_t)lb * 576 + i] = s_;
+        else bn_partial[(size_t)lb * 128 + (i - 576)] = s_;
     }
+}
+// partial [n][128] -> out [(n + 63) / 64][128]: 64 workgroup partials per output row, double accumulation, fixed order
+__global__ __launch_bounds__(128) void xc_fold_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    const int j0 = blockIdx.x * 64, j1 = j0 + 64 < n ? j0 + 64 : n;
+    double s_ = 0.0;
+    for (int j = j0; j < j1; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? partial[(size_t)(j + u) * 128 + threadIdx.x] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s_ += (double)v[u];
+    }
+    out[(size_t)blockIdx.x * 128 + threadIdx.x] = (float)s_;
+}
+int launch_xc_fold_partials(hipStream_t st, const float* partial, int n, float* out, int* nout) {
+    const int nb = (n + 63) / 64;
+    hipLaunchKernelGGL(xc_fold_partials_kernel, dim3((unsigned)nb), dim3(128), 0, st, partial, n, out);
+    *nout = nb;
+    return 0;
 }
 int xc_dw_fused_slabs(int B, int H) { return (B * H + XD_R - 1) / XD_R; }
 int launch_dw3x3_bwd_fused(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, float* slab, int* nslab,
-                           int B, int H, int W, const float* aff) {
+                           int B, int H, int W, const float* aff, const float* bn_mean, const float* bn_invstd, float* bn_partial) {
     if (W != 16 || (int64_t)B * H >= (1 << 30)) return -3;
+    if (bn_partial && (!aff || !bn_mean || !bn_invstd || add)) return -3;
     const int nb = xc_dw_fused_slabs(B, H);
-    if (aff) hipLaunchKernelGGL(dw3x3_w16_bwd_fused_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map);
-    else hipLaunchKernelGGL(dw3x3_w16_bwd_fused_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map);
+    if (xc_dw_fused_slabs(B, H) > xc_partial_capacity() * 64) return -3;      // the folded partials must fit the finalisation's buffer
+    if (bn_partial) hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, bn_mean, bn_invstd, bn_partial);
+    else if (aff) hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<true, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<false, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, nullptr, nullptr, nullptr);
     *nslab = nb;
     return 0;
 }
