@@ -97,6 +97,7 @@ struct seld_ctx {
     std::vector<XcUnit> xc;
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
+    float* xc_slab_tmp = nullptr;     // first-stage sums of the fused pass's slabs (launch_reduce_slabs_2stage)
     float* xc_part_dw = nullptr;      // BatchNorm-backward partials left by the fused depthwise input-gradient pass, one [128] per workgroup
     size_t xc_slab_per = 0;      // floats per depthwise-slab buffer (xc_slab holds two)
     float *xc_g[4] = {}, *xc_dz2 = nullptr;  // gradient ping-pong buffers [B,S,16,64] (X, F1, F2, second F1); second dz buffer
@@ -500,6 +501,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             ALLOC(c->xc_slab, 2 * per);
             c->xc_slab_per = per;
             ALLOC(c->xc_part_dw, (size_t)xc_dw_fused_slabs(c->Bmax, c->S) * 128);
+            ALLOC(c->xc_slab_tmp, (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576);
         }
     }
     if (resn) {
@@ -1769,7 +1771,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         return fail(c, SELD_ERR_UNSUPPORTED, "dw3x3_bwd_fused");
                     if (sums) { have_sums = true; n_dw_part = ns; }
                     fork();
-                    launch_reduce_slabs(ws, sl, ns, 576, c->grads + U.dw_off, 576, 0);
+                    launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, c->xc_slab_tmp);      // side stream: its launches are ordered, one tmp
                     done(sf);
                 } else {
                     fork();

@@ -152,6 +152,9 @@ int conv64_fwd_sb_takes_pre(int W);
 int conv_sb_partial_capacity();  // [3,3,64,64] -> dgrad weights
 int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out,
                         int64_t n, int accumulate);
+// thousands of slabs: groups of 64 into tmp [reduce_slabs_groups(nslab)][n], then the groups (gemm.hip)
+int reduce_slabs_groups(int nslab);
+int launch_reduce_slabs_2stage(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out, int64_t n, float* tmp);
 
 int launch_bn_finalize(hipStream_t st, const float* partial, int npartial, double count, const float* gamma,
                        const float* beta, float* mov_mean, float* mov_var, float* mean, float* invstd,

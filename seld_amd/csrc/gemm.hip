@@ -590,6 +590,33 @@ int launch_reduce_slabs(hipStream_t st, const float* slab, int nslab, int64_t sl
     return 0;
 }
 
+// Many slabs (thousands: one per workgroup of a streaming kernel): a single launch of reduce_slabs_kernel is n / 32 workgroups each walking ALL slabs
+// (576 outputs x 4 800 slabs: 18 workgroups, ~100 us).  Two stages instead: blockIdx.y = a group of `per` slabs summed into tmp[y][n] (double inside,
+// float out), then the groups by reduce_slabs_kernel.  Fixed order in both stages.
+__global__ __launch_bounds__(256) void reduce_slabs_stage_kernel(const float* __restrict__ slab, int nslab, int per, int64_t stride,
+                                                                 float* __restrict__ tmp, int64_t n) {
+    __shared__ double red[256];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
+    const int z0 = blockIdx.y * per, cnt = nslab - z0 < per ? nslab - z0 : per;
+    const double s = i < n ? slab_group_sum(slab + (size_t)z0 * stride, cnt, stride, i, g) : 0.0;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + o];
+        tmp[(size_t)blockIdx.y * n + i] = (float)t;
+    }
+}
+int reduce_slabs_groups(int nslab) { return (nslab + 63) / 64; }      // rows of `tmp` launch_reduce_slabs_2stage needs ([groups][n] floats)
+int launch_reduce_slabs_2stage(hipStream_t st, const float* slab, int nslab, int64_t slab_stride, float* out, int64_t n, float* tmp) {
+    if (n <= 0) return 0;
+    const int groups = reduce_slabs_groups(nslab);
+    hipLaunchKernelGGL(reduce_slabs_stage_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)groups), dim3(256), 0, st, slab, nslab, 64, slab_stride, tmp, n);
+    return launch_reduce_slabs(st, tmp, groups, n, out, n, 0);
+}
+
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -255,9 +255,10 @@ __global__ __launch_bounds__(256) void dw3x3_w16_bwd_fused_kernel(const float* _
         else bn_partial[(size_t)lb * 128 + (i - 576)] = s_;
     }
 }
-// partial [n][128] -> out [(n + 63) / 64][128]: 64 workgroup partials per output row, double accumulation, fixed order
-__global__ __launch_bounds__(128) void xc_fold_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
-    const int j0 = blockIdx.x * 64, j1 = j0 + 64 < n ? j0 + 64 : n;
+// partial [n][128] -> out [(n + per - 1) / per][128]: `per` workgroup partials per output row (a multiple of 8: eight loads in flight), double
+// accumulation, fixed order
+__global__ __launch_bounds__(128) void xc_fold_partials_kernel(const float* __restrict__ partial, int n, int per, float* __restrict__ out) {
+    const int j0 = blockIdx.x * per, j1 = j0 + per < n ? j0 + per : n;
     double s_ = 0.0;
     for (int j = j0; j < j1; j += 8) {
         float v[8];
@@ -269,18 +270,20 @@ __global__ __launch_bounds__(128) void xc_fold_partials_kernel(const float* __re
     out[(size_t)blockIdx.x * 128 + threadIdx.x] = (float)s_;
 }
 int launch_xc_fold_partials(hipStream_t st, const float* partial, int n, float* out, int* nout) {
-    const int nb = (n + 63) / 64;
-    hipLaunchKernelGGL(xc_fold_partials_kernel, dim3((unsigned)nb), dim3(128), 0, st, partial, n, out);
+    int per = (n + xc_partial_capacity() - 1) / xc_partial_capacity();      // the finalisation's buffer holds xc_partial_capacity() rows
+    per = per < 16 ? 16 : (per + 7) & ~7;
+    const int nb = (n + per - 1) / per;
+    hipLaunchKernelGGL(xc_fold_partials_kernel, dim3((unsigned)nb), dim3(128), 0, st, partial, n, per, out);
     *nout = nb;
     return 0;
 }
+
 int xc_dw_fused_slabs(int B, int H) { return (B * H + XD_R - 1) / XD_R; }
 int launch_dw3x3_bwd_fused(hipStream_t st, const float* dy, const float* k, const float* xin, const float* add, float* dx, float* slab, int* nslab,
                            int B, int H, int W, const float* aff, const float* bn_mean, const float* bn_invstd, float* bn_partial) {
     if (W != 16 || (int64_t)B * H >= (1 << 30)) return -3;
     if (bn_partial && (!aff || !bn_mean || !bn_invstd || add)) return -3;
     const int nb = xc_dw_fused_slabs(B, H);
-    if (xc_dw_fused_slabs(B, H) > xc_partial_capacity() * 64) return -3;      // the folded partials must fit the finalisation's buffer
     if (bn_partial) hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, bn_mean, bn_invstd, bn_partial);
     else if (aff) hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<true, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((dw3x3_w16_bwd_fused_kernel<false, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, k, xin, add, dx, slab, B * H, H, aff, g_xc_xcd_map, nullptr, nullptr, nullptr);
