@@ -96,8 +96,11 @@ def kernel_work(name, B, T, F=64, C=7):
         # backward of a unit on the main stream: BatchNorm' sums (read gY, z), then xc_pw_bwd (dz formed on load: reads gY, z, the depthwise
         # output; writes the gradient w.r.t. the depthwise output; two 64 x 64 products on the f32 MFMA), then the depthwise input gradient
         # (reads that gradient, the unit's input for the ReLU mask, the residual gradient; writes the input gradient)
-        "xc_bn_bwd": ("hbm", 4 * 2 * px2 * 64),
-        "xc_pointwise_bwd": ("hbm", 4 * 4 * px2 * 64), "xc_depthwise_bwd": ("hbm", 4 * 4 * px2 * 64),
+        # (round 5, the default: that pass also leaves the depthwise kernel gradient's slabs and, for 16 of the 24 units, the previous BatchNormalization's
+        # backward sums — a scope of xc_bn_bwd then only folds partials: 8 of 24 scopes read gY and z -> a third of 2 tensors on average; the
+        # depthwise scope reads the gradient and the unit's input, writes the input gradient, 8 of 24 also read the residual gradient)
+        "xc_bn_bwd": ("hbm", 4 * 2 * px2 * 64 / 3),
+        "xc_pointwise_bwd": ("hbm", 4 * 4 * px2 * 64), "xc_depthwise_bwd": ("hbm", 4 * (3 + 1 / 3) * px2 * 64),
     }
     if name.startswith("rn_") and name not in ("rn_stages_fwd", "rn_stages_bwd"):
         # level-3 groups of resnet50_block, per SCOPE sums are not meaningful (one scope per launch of very different sizes): work per STEP

@@ -152,14 +152,33 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         if (c < C) { out[c] = a[k]; out[C + c] = b[k]; }
     }
 }
-// stage 2.  BWD: o0 = dbeta, o1 = dgamma; else o0 = mean, o1 = biased variance
+// stage 2.  BWD: o0 = dbeta, o1 = dgamma; else o0 = mean, o1 = biased variance.  Workgroup = 32 channels x 32 slices of the partial rows (a thread walks
+// rows s, s + 32, ... with four loads of each sum in flight; the slices meet through LDS in a fixed order): one thread per channel walking all 1 024 rows
+// took 266 us per call, 10 % of the mother_stage step.
 template <bool BWD>
-__global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __restrict__ part, int nb, int64_t npix, int C, float* __restrict__ o0,
-                                                              float* __restrict__ o1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_partial_fold_kernel(const double* __restrict__ part, int nb, int64_t npix, int C, float* __restrict__ o0,
+                                                               float* __restrict__ o1) {
+    __shared__ double ra[1024], rb[1024];
+    const int lc = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lc;
     double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < nb; ++k) { sa += part[(size_t)k * 2 * C + c]; sb += part[(size_t)k * 2 * C + C + c]; }
+    if (c < C) {
+        int k = sl;
+        for (; k + 96 < nb; k += 128) {
+            const double a0 = part[(size_t)k * 2 * C + c], a1 = part[(size_t)(k + 32) * 2 * C + c], a2 = part[(size_t)(k + 64) * 2 * C + c],
+                         a3 = part[(size_t)(k + 96) * 2 * C + c];
+            const double b0 = part[(size_t)k * 2 * C + C + c], b1 = part[(size_t)(k + 32) * 2 * C + C + c], b2 = part[(size_t)(k + 64) * 2 * C + C + c],
+                         b3 = part[(size_t)(k + 96) * 2 * C + C + c];
+            sa += (a0 + a1) + (a2 + a3);
+            sb += (b0 + b1) + (b2 + b3);
+        }
+        for (; k < nb; k += 32) { sa += part[(size_t)k * 2 * C + c]; sb += part[(size_t)k * 2 * C + C + c]; }
+    }
+    ra[threadIdx.x] = sa; rb[threadIdx.x] = sb;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    sa = 0.0; sb = 0.0;
+    for (int j = 0; j < 32; ++j) { sa += ra[j * 32 + lc]; sb += rb[j * 32 + lc]; }
     if (BWD) { o0[c] = (float)sa; o1[c] = (float)sb; }
     else {
         const double m = sa / (double)npix;
@@ -361,7 +380,7 @@ int seld_m_bn_stats(const float* z, int64_t npix, int C, float* mean, float* var
     const int nb = bnp_blocks(npix);
     double* part = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL((bn_partial_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, nullptr, nullptr, nullptr, 0.f, npix, C, part);
-    hipLaunchKernelGGL((bn_partial_fold_kernel<false>), dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nb, npix, C, mean, var);
+    hipLaunchKernelGGL((bn_partial_fold_kernel<false>), dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nb, npix, C, mean, var);
     return ok();
 }
 int seld_m_bn_apply(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* out,
@@ -384,7 +403,7 @@ int seld_m_bn_bwd(const float* z, const float* dy, const float* mean, const floa
         const int nb = bnp_blocks(npix);
         double* part = reinterpret_cast<double*>(scratch);
         hipLaunchKernelGGL((bn_partial_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, z, dy, mean, var, eps, npix, C, part);
-        hipLaunchKernelGGL((bn_partial_fold_kernel<true>), dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nb, npix, C, dbeta, dgamma);
+        hipLaunchKernelGGL((bn_partial_fold_kernel<true>), dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nb, npix, C, dbeta, dgamma);
     }
     hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, dy, mean, var, gamma, eps, dgamma, dbeta, dz,
                        npix * C, C, 1.0 / (double)npix);

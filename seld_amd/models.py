@@ -196,7 +196,7 @@ class SeldNet:
 
     def set_option(self, key: str, value: int) -> None:
         """Kernel-selection knobs of the C library (`seld_set_option`): "conv64_split_bf16", "gemm_split_bf16", "conv1_split_bf16",
-        "conv1_pool_fused", "conv1_gram", "conv64_dbuf", "gru_wgrad_batch", "xc_fused_fwd", "xc_fused_pw_bwd", "xc_wgrad_side", "rn_split_bf16", "rn_wgrad_side"."""
+        "conv1_pool_fused", "conv1_gram", "conv64_dbuf", "gru_wgrad_batch", "xc_fused_fwd", "xc_fused_pw_bwd", "xc_fused_dw_bwd", "xc_fused_bn_sums", "xc_w16", "xc_xcd_map", "xc_wgrad_side", "rn_split_bf16", "rn_wgrad_side", "rn_epi_stats", "rn_epi_add"."""
         _lib.check(self.lib.seld_set_option(self.ctx, key.encode(), int(value)), self.ctx)
 
     def get_grads(self) -> np.ndarray:

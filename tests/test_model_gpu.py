@@ -751,6 +751,62 @@ def test_folded_passes_are_bit_identical_to_the_stand_alone_ones(seldnet_config,
             assert np.array_equal(a, b), f"item {i} differs with {opt}: max |d| = {d:.3e}"
 
 
+@pytest.mark.gpu
+def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_config):
+    """Round 5: a unit's depthwise input-gradient pass also leaves the kernel-gradient slabs (`xc_fused_dw_bwd`) and, for a folded unit, the
+    previous BatchNormalization's backward sums (`xc_fused_bn_sums`); the W = 16 depthwise kernels take one image row per workgroup
+    (`xc_w16`) in XCD-contiguous ranges (`xc_xcd_map`).  One train step from the same weights under each choice:
+    * `xc_w16` / `xc_xcd_map` change where an element is computed, not how: with the separate passes (`xc_fused_dw_bwd` = 0) every gradient
+      is bit for bit the generic kernel's;
+    * `xc_fused_dw_bwd` = 1 with `xc_fused_bn_sums` = 0 forms every input gradient with the same taps in the same order — every gradient
+      EXCEPT the depthwise kernels' is bit-identical to the separate passes — and sums the depthwise kernel gradients in another association:
+      held to 2e-6 of each tensor's maximum;
+    * `xc_fused_bn_sums` = 1 sums [sum dy | sum dy xhat] per workgroup of four image rows instead of per strided pixel set: every gradient
+      within 2e-5 of its maximum (a BatchNorm backward's c1 / c2 feed everything upstream)."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(xception_config)
+    cfg["FIRST_ARGS"]["block_num"] = 2
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 5)
+    B, T = 3, 200
+    x, ys, yd = O.synthetic_batch(B, T, seed=29)
+
+    def run(options):
+        model = models.seldnet((B, T, 64, 7), cfg)
+        for k, v in options.items():
+            model.set_option(k, v)
+        model.set_weights(w, st)
+        y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), train.Adam(1e-3))
+        flat = model.get_grads()
+        g = {n: flat[o:o + int(np.prod(sh))].copy() for n, o, sh in model.variables}
+        out = (y_p[0].cpu().numpy().copy(), y_p[1].cpu().numpy().copy(), g)
+        model.close()
+        return out
+
+    sep = run({"xc_fused_dw_bwd": 0, "xc_w16": 0, "xc_xcd_map": 0})
+    for alt in ({"xc_fused_dw_bwd": 0, "xc_w16": 1, "xc_xcd_map": 0}, {"xc_fused_dw_bwd": 0, "xc_w16": 1, "xc_xcd_map": 1}):
+        got = run(alt)
+        np.testing.assert_array_equal(got[0], sep[0])
+        for name in sep[2]:
+            np.testing.assert_array_equal(got[2][name], sep[2][name], err_msg=f"{name} with {alt}")
+    fused = run({"xc_fused_dw_bwd": 1, "xc_fused_bn_sums": 0})
+    np.testing.assert_array_equal(fused[1], sep[1])
+    n_dw = 0
+    for name, a in sep[2].items():
+        b = fused[2][name]
+        if name.endswith(".depthwise_kernel"):
+            n_dw += 1
+            assert np.abs(a.astype(np.float64) - b).max() <= 2e-6 * np.abs(a).max(), name
+        else:
+            np.testing.assert_array_equal(b, a, err_msg=name)
+    assert n_dw == 6, sorted(sep[2])
+    both = run({})      # the default: both folds
+    for name, a in sep[2].items():
+        assert np.abs(a.astype(np.float64) - both[2][name]).max() <= 2e-5 * np.abs(a).max(), name
+
+
 @pytest.mark.parametrize("which", ["xception", "resnet50"])
 def test_block_models_bitwise_reproducible_over_steps(xception_config, resnet50_config, which):
     """xception_block / resnet50_block run their kernel gradients (and the projection shortcuts) on the side stream with rotating
