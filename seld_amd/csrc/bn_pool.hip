@@ -169,20 +169,18 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
     const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
     const bool degenerate = (sc[0] == 0.f) | (sc[1] == 0.f) | (sc[2] == 0.f) | (sc[3] == 0.f);
     float sdy[4] = {0.f, 0.f, 0.f, 0.f}, sdx[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t pp = (int64_t)blockIdx.x * 16 + slot; pp < npool; pp += (int64_t)gridDim.x * 16) {
-        const float4 d4 = reinterpret_cast<const float4*>(dp)[pp * 16 + g];
+    // one pooled pixel's terms into the running sums, always in ascending pixel order (the same bits whatever the number of loads in flight)
+    auto add = [&](int64_t pp, const float4& d4, const float4& q4) {      // q4: zext (EXT) or p
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
         float pv[4], zsel[4];
         if (EXT) {
             // the routed element itself; the pooled activation is max(0, fmaf(zext, scale, shift)) (bn_relu_ext), so its sign —
             // all that is needed of it here — comes from the same fmaf: one 79 MB read fewer than loading p
-            const float4 ze = reinterpret_cast<const float4*>(z)[pp * 16 + g];
-            zsel[0] = ze.x; zsel[1] = ze.y; zsel[2] = ze.z; zsel[3] = ze.w;
+            zsel[0] = q4.x; zsel[1] = q4.y; zsel[2] = q4.z; zsel[3] = q4.w;
 #pragma unroll
             for (int c = 0; c < 4; ++c) pv[c] = fmaf(zsel[c], sc[c], sh[c]);
         } else {
-            const float4 pv4 = reinterpret_cast<const float4*>(p)[pp * 16 + g];
-            pv[0] = pv4.x; pv[1] = pv4.y; pv[2] = pv4.z; pv[3] = pv4.w;
+            pv[0] = q4.x; pv[1] = q4.y; pv[2] = q4.z; pv[3] = q4.w;
 #pragma unroll
             for (int c = 0; c < 4; ++c) zsel[c] = (pv[c] - sh[c]) / sc[c];
         }
@@ -202,7 +200,23 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
             sdy[c] += dy;
             sdx[c] += dy * (zsel[c] - mu[c]) * is[c];
         }
+    };
+    // four pooled pixels' loads in flight per thread (round 5: with <= BN_MAX_PARTIAL workgroups a wave has little company on its SIMD and the
+    // one-pixel loop paid a memory round trip per pixel — the third block's 19.7 MB took 19 us)
+    const float* q = EXT ? z : p;
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    int64_t pp = (int64_t)blockIdx.x * 16 + slot;
+    for (; pp + 3 * stride < npool; pp += 4 * stride) {
+        float4 d4[4], q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d4[u] = reinterpret_cast<const float4*>(dp)[(pp + u * stride) * 16 + g];
+            q4[u] = reinterpret_cast<const float4*>(q)[(pp + u * stride) * 16 + g];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(pp + u * stride, d4[u], q4[u]);
     }
+    for (; pp < npool; pp += stride) add(pp, reinterpret_cast<const float4*>(dp)[pp * 16 + g], reinterpret_cast<const float4*>(q)[pp * 16 + g]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         red[tid * 8 + c] = sdy[c];

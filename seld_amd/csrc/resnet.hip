@@ -82,19 +82,16 @@ __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict_
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1, gsc = s1, gsh = s1;
     if (BWD && gok) { mu = *reinterpret_cast<const float4*>(coef + c0); is = *reinterpret_cast<const float4*>(coef + C + c0); }
     if (MASKM == 1 && gok) { gsc = *reinterpret_cast<const float4*>(coef + 2 * C + c0); gsh = *reinterpret_cast<const float4*>(coef + 3 * C + c0); }
-    for (int64_t p = (int64_t)blockIdx.x * 16 + slot; gok && p < npix; p += (int64_t)gridDim.x * 16) {
-        const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c0);
+    // one pixel's terms into the running sums — always in ascending pixel order, whatever the number of loads in flight: the same bits
+    auto add = [&](const float4& zv, float4 d, unsigned gm, const float4& mf) {
         if (BWD) {
-            float4 d = *reinterpret_cast<const float4*>(dy + p * C + c0);
             if (MASKM == 1) {
                 const float4 m = rn_fma4(zv, gsc, gsh);
                 d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
             } else if (MASKM == 2) {
-                const unsigned m = reinterpret_cast<const unsigned char*>(mask)[(p * C + c0) >> 2];
-                d = make_float4((m & 1) ? d.x : 0.f, (m & 2) ? d.y : 0.f, (m & 4) ? d.z : 0.f, (m & 8) ? d.w : 0.f);
+                d = make_float4((gm & 1) ? d.x : 0.f, (gm & 2) ? d.y : 0.f, (gm & 4) ? d.z : 0.f, (gm & 8) ? d.w : 0.f);
             } else if (mask) {
-                const float4 m = *reinterpret_cast<const float4*>(mask + p * C + c0);
-                d = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f, m.w > 0.f ? d.w : 0.f);
+                d = make_float4(mf.x > 0.f ? d.x : 0.f, mf.y > 0.f ? d.y : 0.f, mf.z > 0.f ? d.z : 0.f, mf.w > 0.f ? d.w : 0.f);
             }
             s1 = make_float4(s1.x + d.x, s1.y + d.y, s1.z + d.z, s1.w + d.w);
             s2 = make_float4(s2.x + d.x * (zv.x - mu.x) * is.x, s2.y + d.y * (zv.y - mu.y) * is.y, s2.z + d.z * (zv.z - mu.z) * is.z,
@@ -103,6 +100,33 @@ __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict_
             s1 = make_float4(s1.x + zv.x, s1.y + zv.y, s1.z + zv.z, s1.w + zv.w);
             s2 = rn_fma4(zv, zv, s2);
         }
+    };
+    // Four pixels' loads in flight per thread (round 5): with <= 256 workgroups a wave is alone on its SIMD and the one-pixel loop paid a full
+    // memory round trip per pixel (the 19.7 MB tensors: 24 us = 1.6 TB/s).
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t p = (int64_t)blockIdx.x * 16 + slot;
+    for (; gok && p + 3 * stride < npix; p += 4 * stride) {
+        float4 zv[4], d[4], mf[4];
+        unsigned gm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = (p + u * stride) * C + c0;
+            zv[u] = *reinterpret_cast<const float4*>(z + e);
+            d[u] = BWD ? *reinterpret_cast<const float4*>(dy + e) : zero4;
+            gm[u] = (BWD && MASKM == 2) ? reinterpret_cast<const unsigned char*>(mask)[e >> 2] : 0u;
+            mf[u] = (BWD && MASKM == 0 && mask) ? *reinterpret_cast<const float4*>(mask + e) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(zv[u], d[u], gm[u], mf[u]);
+    }
+    for (; gok && p < npix; p += stride) {
+        const int64_t e = p * C + c0;
+        const float4 zv = *reinterpret_cast<const float4*>(z + e);
+        const float4 d = BWD ? *reinterpret_cast<const float4*>(dy + e) : zero4;
+        const unsigned gm = (BWD && MASKM == 2) ? reinterpret_cast<const unsigned char*>(mask)[e >> 2] : 0u;
+        const float4 mf = (BWD && MASKM == 0 && mask) ? *reinterpret_cast<const float4*>(mask + e) : zero4;
+        add(zv, d, gm, mf);
     }
     *reinterpret_cast<float4*>(&red[tid * 8]) = s1;
     *reinterpret_cast<float4*>(&red[tid * 8 + 4]) = s2;

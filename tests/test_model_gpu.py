@@ -804,6 +804,8 @@ def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_c
     assert n_dw == 6, sorted(sep[2])
     both = run({})      # the default: both folds
     for name, a in sep[2].items():
+        if name.startswith("conv") and name.endswith("bias"):
+            continue        # exactly 0 in exact arithmetic (a bias in front of training-mode BatchNorm): rounding noise on both sides
         assert np.abs(a.astype(np.float64) - both[2][name]).max() <= 2e-5 * np.abs(a).max(), name
 
 
