@@ -9,12 +9,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd "$root"
-# bench.py prints the DETAIL record on an earlier line and the compact record LAST: the compact line goes to bench.json, the detail
-# (per-kernel rooflines from the level-2 profile pass, sub-records, peaks read on the box) to bench_detail.json
-timeout -k 10 500 python3 bench.py --detail-out "$out/bench_detail.json" 2> "$out/bench.err" | tail -n 1 > "$out/bench.json"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- \
-    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-inference --no-configs --no-kernel-timing --detail-out "$out/bench_under_rocprof_detail.json" 2> "$out/rocprof_stats.log" | tail -n 1 > "$out/bench_under_rocprof.json"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o pmc -- \
         python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-features --no-inference --no-kernel-timing --no-configs --detail-out /dev/null > /dev/null 2> "$out/rocprof_$c.log"
@@ -33,6 +28,25 @@ ff=$(find "$out/featpmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 fw=$(find "$out/featpmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$root/tools/pmc_traffic.py" "$ff" "$fw" "feature stage: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, build $tag" > "$out/traffic_features.json"
 rm -rf "$out/featpmc_FETCH_SIZE" "$out/featpmc_WRITE_SIZE"
+# the counter passes come FIRST and their figures replace profiles/traffic.json of this copy of the repo, so that the bench line below carries
+# `roofline.traffic` measured on the build it times (bench.py drops a stored figure whose kernel source changed since the pass)
+python3 - "$out/traffic.json" "$out/traffic_features.json" "$root/profiles/traffic.json" <<'PY'
+import json, sys
+a, b = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+assert a["_source_hashes"] == b["_source_hashes"]
+for k, v in b.items():
+    if k == "_provenance": a["_provenance_features"] = v
+    elif k != "_source_hashes": a[k] = v
+json.dump(a, open(sys.argv[3], "w"), indent=1)
+PY
+cp "$root/profiles/traffic.json" "$out/traffic_merged.json"
+cd "$root"
+# bench.py prints the DETAIL record on an earlier line and the compact record LAST: the compact line goes to bench.json, the detail
+# (per-kernel rooflines from the level-2 profile pass, sub-records, peaks read on the box) to bench_detail.json
+timeout -k 10 500 python3 bench.py --detail-out "$out/bench_detail.json" 2> "$out/bench.err" | tail -n 1 > "$out/bench.json"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- \
+    python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-features --no-inference --no-configs --no-kernel-timing --detail-out "$out/bench_under_rocprof_detail.json" 2> "$out/rocprof_stats.log" | tail -n 1 > "$out/bench_under_rocprof.json"
 find "$out/feat_stats" -name '*kernel_trace.csv' -delete
 # seldnet.json in bf16 single-product mode (BASELINE configs[1]'s literal wording): kernel stats
 cd /tmp
