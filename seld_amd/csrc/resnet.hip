@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void rn_reduce_kernel(const float* __restrict_
     const int64_t stride = (int64_t)gridDim.x * 16;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t p = (int64_t)blockIdx.x * 16 + slot;
-    for (; gok && p + 3 * stride < npix; p += 4 * stride) {
+    // (the gate-byte form walks the 78.6 MB block outputs on 512+ workgroups: enough waves per SIMD already, and four pixels in flight cost it 35 -> 43 us)
+    for (; MASKM != 2 && gok && p + 3 * stride < npix; p += 4 * stride) {
         float4 zv[4], d[4], mf[4];
         unsigned gm[4];
 #pragma unroll
