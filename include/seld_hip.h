@@ -369,6 +369,16 @@ int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const floa
  * kernel with transposed LDS reads, gemm_tn_sb.hip, unless seld_k_set_option("gemm_tn_split_bf16", 0)); colsum (may be NULL): [N] = sum_m B[m,:]
  * (the matching bias gradient, produced by the same launch) */
 int seld_k_gemm_tn(const float* A, const float* Bm, float* C, float* colsum, int M, int K1, int N);
+
+/* xception_block's depthwise 3x3 backward on [B,H,16,64] NHWC (xception.hip; spec/XCEPTION_BLOCK.md: the unit is ReLU -> depthwise 3x3 ->
+ * pointwise -> BatchNormalization).  dy: the gradient w.r.t. the depthwise OUTPUT; xin: the unit's input (aff == NULL) or, with aff = [scale 64 |
+ * shift 64], the PREVIOUS unit's pre-BN tensor z (the activation is then relu(z scale + shift)); add (may be NULL): a residual gradient added to dx;
+ * k [3][3][64] (Keras depthwise_kernel [3,3,64,1]).  Outputs: dx [B,H,16,64] = the gradient w.r.t. the (pre-ReLU) input, dk [3][3][64], and — with
+ * bn_mean / bn_invstd [64] (aff required, add NULL) — sums [128] = [sum dx | sum dx xhat], xhat = (z - mean) invstd: the previous
+ * BatchNormalization's backward sums.  fused = 1: one pass (dw3x3_w16_bwd_fused + two-stage combine + partial fold: the default of the model path,
+ * round 5); fused = 0: the separate passes (dw3x3_bwd_data, dw3x3_bwd_w, xc_reduce). */
+int seld_k_xc_dw_bwd(const float* dy, const float* k, const float* xin, const float* add, const float* aff, const float* bn_mean,
+                     const float* bn_invstd, float* dx, float* dk, float* sums, int B, int H, int fused);
 /* Bidirectional(GRU(128, reset_after=True), merge_mode='mul') recurrence (modules.py:311-316).
  * gx_* [B,S,384] = x*kernel + bias[0]; U_* [128,384]; brec_* = bias[1]; h_* [B,S,128]; out = h_f*h_b.
  * saved_* [B,S,128,4] (per unit: z, r, hh, h*U_h+b) may be NULL. */

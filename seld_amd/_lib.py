@@ -137,6 +137,7 @@ SIGNATURES = {
     "seld_k_gemm_pair_n": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "seld_k_gemm_pair_k": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "seld_k_gemm_sb": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "seld_k_xc_dw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "seld_k_gemm_tn": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "seld_k_gru_fwd": (_I, [_P] * 11 + [_I] * 3),
     "seld_k_gru_bwd": (_I, [_P] * 11 + [_I] * 3),

@@ -41,6 +41,8 @@ int seld_k_set_option(const char* key, int value) {
     if (!strcmp(key, "gemm_tn_split_bf16")) { g_gemm_tn_sb = value != 0; return SELD_OK; }
     if (!strcmp(key, "bf16_single")) { g_mfma_one = value != 0; return SELD_OK; }
     if (!strcmp(key, "gsb_dbg")) { g_gsb_dbg = value; return SELD_OK; }
+    if (!strcmp(key, "xc_w16")) { g_xc_w16 = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_xcd_map")) { g_xc_xcd_map = value != 0; return SELD_OK; }
     if (!strcmp(key, "bwd_four_products")) { g_bwd_four = value != 0; return SELD_OK; }
     if (!strcmp(key, "rn_split_bf16")) { g_rn_split_bf16 = value != 0; return SELD_OK; }
     return SELD_ERR_INVALID;
@@ -269,6 +271,42 @@ int seld_k_gemm_sb(const float* A0, const float* A1, const float* B0, const floa
     const int ldb[2] = {transb ? K : N, transb ? K : N}, tb[2] = {transb, transb}, Ks[2] = {K, K}, Ns[2] = {N, N};
     if (launch_gemm_split_b(0, mode ? 2 : 1, src, dst, ldb, tb, Ks, Ns)) return SELD_ERR_INVALID;
     if (launch_gemm_sb(0, A0, A1, K, dst[0], dst[1], bias0, bias1, C0, C1, N, M, N, K, act, mode)) return SELD_ERR_INVALID;
+    return done();
+}
+
+int seld_k_xc_dw_bwd(const float* dy, const float* k, const float* xin, const float* add, const float* aff, const float* bn_mean,
+                     const float* bn_invstd, float* dx, float* dk, float* sums, int B, int H, int fused) {
+    if (!dy || !k || !xin || !dx || !dk || B < 1 || H < 1) return SELD_ERR_INVALID;
+    const bool want_sums = bn_mean != nullptr;
+    if (want_sums && (!bn_invstd || !sums || !aff || add)) return SELD_ERR_INVALID;      // the sums belong to the BatchNormalization folded into the loads
+    const int64_t npix = (int64_t)B * H * 16;
+    Scratch s;
+    int ns = 0, np = 0;
+    if (fused) {
+        const int nb = xc_dw_fused_slabs(B, H);
+        float* slab = s.get((size_t)nb * 576);
+        float* tmp = s.get((size_t)reduce_slabs_groups(nb) * 576);
+        float* part = s.get((size_t)nb * 128);
+        float* folded = s.get((size_t)xc_partial_capacity() * 128);
+        if (!slab || !tmp || !part || !folded) return SELD_ERR_NOMEM;
+        if (launch_dw3x3_bwd_fused(0, dy, k, xin, add, dx, slab, &ns, B, H, 16, aff, bn_mean, bn_invstd, want_sums ? part : nullptr)) return SELD_ERR_UNSUPPORTED;
+        launch_reduce_slabs_2stage(0, slab, ns, 576, dk, 576, tmp);
+        if (want_sums) {
+            launch_xc_fold_partials(0, part, ns, folded, &np);
+            launch_reduce_slabs(0, folded, np, 128, sums, 128, 0);
+        }
+    } else {
+        float* slab = s.get((size_t)xc_partial_capacity() * 576);
+        float* part = s.get((size_t)xc_partial_capacity() * 128);
+        if (!slab || !part) return SELD_ERR_NOMEM;
+        launch_dw3x3_bwd_data(0, dy, k, xin, add, dx, B, H, 16, aff);
+        launch_dw3x3_bwd_w(0, xin, dy, slab, &ns, B, H, 16, aff);
+        launch_reduce_slabs(0, slab, ns, 576, dk, 576, 0);
+        if (want_sums) {
+            launch_xc_bn_bwd_reduce(0, xin, dx, bn_mean, bn_invstd, part, &np, npix);
+            launch_reduce_slabs(0, part, np, 128, sums, 128, 0);
+        }
+    }
     return done();
 }
 

@@ -601,6 +601,60 @@ def _rn_conv_fwd_bwd(seld_lib, B, H, W, Cin, Cout, ksize, stride_f):
     check("rn_conv dx", dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("B,H,aff,with_add,sums", [(2, 37, 1, 0, 1), (3, 8, 1, 0, 0), (1, 1, 0, 1, 0), (2, 50, 0, 0, 0), (2, 3, 0, 1, 0), (5, 13, 1, 0, 1)])
+def test_xc_depthwise_backward(seld_lib, B, H, aff, with_add, sums, fused):
+    """xception_block's depthwise 3x3 backward through seld_k_xc_dw_bwd, in ONE pass (fused = 1: input gradient + kernel-gradient slabs + the
+    previous BatchNormalization's backward sums, dw3x3_w16_bwd_fused; round 5) and as the separate passes (fused = 0), against autograd in fp64:
+    the unit is  a = relu(z scale + shift)  (or relu(x)),  y = DepthwiseConv2D(3, 'same', use_bias=False)(a),  L = sum(y dy):
+    dx = dL/d(pre-ReLU input) (+ add), dk = dL/dk, sums = [sum dx | sum dx xhat].  Ragged sizes: one image row, rows that are not a multiple of the
+    four a workgroup takes, several images (the halo must not cross an image boundary)."""
+    rng = np.random.default_rng(B * 100 + H)
+    shp = (B, H, 16, 64)
+    xin = rng.standard_normal(shp).astype(np.float32)
+    dy = rng.standard_normal(shp).astype(np.float32)
+    k = (rng.standard_normal((3, 3, 64)) * 0.3).astype(np.float32)
+    addv = rng.standard_normal(shp).astype(np.float32) if with_add else None
+    sc = (rng.standard_normal(64) * 0.5 + 1.0).astype(np.float32)
+    sh = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    mean = (rng.standard_normal(64) * 0.2).astype(np.float32)
+    invstd = (rng.random(64) + 0.5).astype(np.float32)
+    # fp64 reference by autograd
+    z = torch.as_tensor(xin, dtype=torch.float64)
+    pre = (z * torch.as_tensor(sc, dtype=torch.float64) + torch.as_tensor(sh, dtype=torch.float64)) if aff else z.clone()
+    pre.requires_grad_(True)
+    kt = torch.as_tensor(k, dtype=torch.float64).permute(2, 0, 1).reshape(64, 1, 3, 3).clone().requires_grad_(True)
+    y = F.conv2d(torch.relu(pre).permute(0, 3, 1, 2), kt, padding=1, groups=64).permute(0, 2, 3, 1)
+    (y * torch.as_tensor(dy, dtype=torch.float64)).sum().backward()
+    dx_ref = pre.grad.numpy() + (addv.astype(np.float64) if with_add else 0.0)
+    dk_ref = kt.grad.reshape(64, 3, 3).permute(1, 2, 0).numpy()
+    xhat = (xin.astype(np.float64) - mean) * invstd
+    sums_ref = np.concatenate([dx_ref.sum((0, 1, 2)), (dx_ref * xhat).sum((0, 1, 2))])
+    d = lambda a: dev(a) if a is not None else None
+    t = {n: d(v) for n, v in dict(dy=dy, k=k, xin=xin, add=addv, aff=np.concatenate([sc, sh]) if aff else None, mean=mean if sums else None,
+                                  invstd=invstd if sums else None).items()}
+    dx, dk, sm = (torch.full(sz, float("nan"), device="cuda") for sz in (shp, (3, 3, 64), (128,)))
+    p = lambda a: ptr(a) if a is not None else None
+    rc = seld_lib.seld_k_xc_dw_bwd(p(t["dy"]), p(t["k"]), p(t["xin"]), p(t["add"]), p(t["aff"]), p(t["mean"]), p(t["invstd"]), ptr(dx), ptr(dk),
+                                   ptr(sm) if sums else None, B, H, fused)
+    assert rc == 0
+    check("xc dw bwd dx", dx.cpu().numpy(), dx_ref)
+    check("xc dw bwd dk", dk.cpu().numpy(), dk_ref)
+    if sums:
+        check("xc dw bwd BatchNorm sums", sm.cpu().numpy(), sums_ref)
+
+
+def test_xc_depthwise_backward_refuses_sums_without_the_folded_batchnorm(seld_lib):
+    """the sums belong to the BatchNormalization folded into the loads: asked for without `aff` (or together with a residual gradient) -> INVALID"""
+    z = torch.zeros(1, 4, 16, 64, device="cuda")
+    k = torch.zeros(3, 3, 64, device="cuda")
+    v = torch.zeros(128, device="cuda")
+    for aff, add in ((None, None), (v, z)):
+        rc = seld_lib.seld_k_xc_dw_bwd(ptr(z), ptr(k), ptr(z), ptr(add) if add is not None else None, ptr(aff) if aff is not None else None, ptr(v), ptr(v),
+                                       ptr(z.clone()), ptr(k.clone()), ptr(v.clone()), 1, 4, 1)
+        assert rc != 0
+
+
 @pytest.mark.parametrize("npix,C,relu,with_res,with_mask", [(960, 32, 1, 0, 1), (480, 256, 1, 0, 1), (480, 1024, 1, 1, 1), (333, 96, 0, 0, 0),
                                                             (7680, 64, 1, 1, 1)])
 def test_rn_bn_fwd_bwd(seld_lib, npix, C, relu, with_res, with_mask):
