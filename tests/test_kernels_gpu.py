@@ -287,6 +287,30 @@ def test_gemm_split_bf16(seld_lib, M, N, K, transb, mode):
         check("gemm_sb second product", C1.cpu().numpy(), A0.astype(np.float64) @ op(B1) + b1)
 
 
+@pytest.mark.parametrize("M,N,mode", [(19200, 384, 1), (1203, 256, 0), (33, 384, 1), (4000, 128, 1)])
+def test_gemm_k128_b_stationary_form_is_bit_identical(seld_lib, M, N, mode):
+    """The opt-in K = 128 form with B stationary in LDS (gemm_sbp_kernel: persistent workgroups, no barrier after the prologue; option gsb_dbg
+    bit 6, round 5) takes the products and k-steps in the tiled kernel's order: the same bits, ragged row counts included."""
+    rng = np.random.default_rng(M + N)
+    A = dev((rng.standard_normal((M, 128)) * np.exp2(rng.integers(-6, 7, size=(M, 128)))).astype(np.float32))
+    B0, B1 = (dev(rng.standard_normal((128, N)).astype(np.float32) / 11.0) for _ in range(2))
+    b0, b1 = (dev(rng.standard_normal(N).astype(np.float32)) for _ in range(2))
+    out = []
+    for dbg in (0, 64):
+        C0, C1 = (torch.full((M, N), float("nan"), device="cuda") for _ in range(2))
+        assert seld_lib.seld_k_set_option(b"gsb_dbg", dbg) == 0
+        try:
+            assert seld_lib.seld_k_gemm_sb(ptr(A), None, ptr(B0), ptr(B1) if mode else None, ptr(b0), ptr(b1) if mode else None, ptr(C0),
+                                           ptr(C1) if mode else None, M, N, 128, 0, 0, mode) == 0
+        finally:
+            seld_lib.seld_k_set_option(b"gsb_dbg", 0)
+        out.append((C0.cpu().numpy(), C1.cpu().numpy()))
+    assert np.isfinite(out[1][0]).all()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    if mode:
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_gemm_split_bf16_refuses_unsupported_shapes(seld_lib):
     t = torch.zeros(256 * 256, device="cuda")
     for N, K in ((100, 64), (128, 40)):
