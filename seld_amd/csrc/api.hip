@@ -117,6 +117,8 @@ struct seld_ctx {
     float *feat_grad = nullptr;       // gradient w.r.t. the last pooled conv output ([B,S,128])
     float *dzbuf = nullptr, *small = nullptr, *stat_partial = nullptr, *bn_partial = nullptr;
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
+    float *wgrad_slab_side = nullptr, *dzbuf_alt = nullptr;      // conv_wgrad_side: the side stream's own slabs, the second dz buffer (allocated when the option is set)
+    int conv_wgrad_side = 1;
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
     unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
@@ -542,6 +544,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     ALLOC(c->stat_partial, (size_t)conv_stat_partial_capacity() * 128);
     ALLOC(c->bn_partial, (size_t)bn_partial_capacity() * 128);
     ALLOC(c->wgrad_slab, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+    if (a->n_conv >= 2 && c->xc.empty() && c->rn.empty()) {      // option conv_wgrad_side (simple_conv_block: the second / third block's kernel gradients beside the main chain)
+        ALLOC(c->wgrad_slab_side, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
+        ALLOC(c->dzbuf_alt, zmax);
+    }
     ALLOC(c->tn_slab, (size_t)tn_slab_capacity());
     ALLOC(c->cs_slab, (size_t)256 * 512);
     ALLOC(c->wflip, 9 * 4096);
@@ -693,6 +699,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
     if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
+    if (!strcmp(key, "conv_wgrad_side")) { c->conv_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_bn_sums")) { c->xc_fused_bn_sums = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_w16")) { c->xc_w16 = value != 0; return SELD_OK; }               // xception.hip
@@ -1813,11 +1820,18 @@ static int backward_impl(seld_ctx* c, const float* x) {
         } else
             launch_bn_bwd_finalize(st, c->bn_partial, np, (double)B * L.H * L.W, c->grads + L.g_off, c->grads + L.be_off, L.c1c2, 64);
         int ns = 0;
+        // conv_wgrad_side (round 5; same box 2.551 -> 2.523 ms): blocks 2 / 3 put their kernel gradient on the side stream (idle in this part of the step); their dz then
+        // alternates between two buffers — the next block's dz is written while the side stream still reads this one's — and the slabs are the side stream's own
+        const bool wside = c->conv_wgrad_side && c->prof < 2 && i >= 1 && c->dzbuf_alt && c->wgrad_slab_side;      // (a level-2 profile pass times every kernel alone)
+        float* dzb = (wside && (i & 1)) ? c->dzbuf_alt : c->dzbuf;
         const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
         if (!fused_first) {
             snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
             PROF2(c, tn);
-            launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, c->dzbuf, B, L.H, L.W, 64, L.pt, L.pf);
+            if (i == 0 && c->conv_wgrad_side && c->dzbuf_alt) {      // the third block's kernel gradient (side stream) read this buffer: not before it is done
+                hipEventRecord(c->ev_join, c->side); hipStreamWaitEvent(st, c->ev_join, 0);
+            }
+            launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, dzb, B, L.H, L.W, 64, L.pt, L.pf);
         }
         if (i == 0 && c->gram_active) {
             PROF(c, "conv1_wgrad");
@@ -1846,21 +1860,24 @@ static int backward_impl(seld_ctx* c, const float* x) {
             snprintf(tn, sizeof tn, "conv%d_wgrad", i + 1);
             {
                 PROF2(c, tn);
+                hipStream_t wst = wside ? c->side : st;
+                float* wsl = wside ? c->wgrad_slab_side : c->wgrad_slab;
+                if (wside) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(c->side, c->ev_fork, 0); }      // dz (and the block's input) are final on the main stream
                 if (c->conv64_split_bf16 && conv64_wgrad_sb_usable(L.W)) {
-                    if (launch_conv64_wgrad_sb(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
+                    if (launch_conv64_wgrad_sb(wst, lin, dzb, wsl, &ns, B, L.H, L.W))
                         return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad_sb");
-                } else if (launch_conv64_wgrad(st, lin, c->dzbuf, c->wgrad_slab, &ns, B, L.H, L.W))
+                } else if (launch_conv64_wgrad(wst, lin, dzb, wsl, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
+                launch_reduce_slabs(wst, wsl, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
             }
-            launch_reduce_slabs(st, c->wgrad_slab, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
                 PROF2(c, tn);
                 if (c->conv64_split_bf16) {   // flipped + split planes were made by the forward's weight pre-pass
-                    launch_conv64_dgrad_sb(st, c->dzbuf, c->wsp_bwd[i], c->conv[i - 1].dp, B, L.H, L.W);
+                    launch_conv64_dgrad_sb(st, dzb, c->wsp_bwd[i], c->conv[i - 1].dp, B, L.H, L.W);
                 } else {
                     launch_flip_weights(st, c->params + L.w_off, c->wflip);
-                    launch_conv64_fwd(st, c->dzbuf, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
+                    launch_conv64_fwd(st, dzb, c->wflip, nullptr, c->conv[i - 1].dp, nullptr, nullptr, B, L.H, L.W);
                 }
             }
             dp = c->conv[i - 1].dp;
