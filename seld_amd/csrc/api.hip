@@ -145,7 +145,8 @@ struct seld_ctx {
     unsigned short *ksp_fwd[SELD_MAX_LAYERS][2] = {}, *ksp_bwd[SELD_MAX_LAYERS][2] = {}, *h0sp_fwd[2] = {}, *h0sp_bwd[2] = {};
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_prep = nullptr;
+    int prep_side = 1;      // option: the step's weight pre-pass on the side stream beside the first block's forward
     hipEvent_t ev_bucket[SELD_MAX_LAYERS] = {};   // side stream: GRU layer n_gru-1-k's (and, k = 0, the heads') gradients are final
     seld_allreduce_fn sync_fn = nullptr;          // synchronised BatchNorm (seld_set_sync_bn)
     void* sync_user = nullptr;
@@ -586,6 +587,7 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         // ev_join and the bucket events cross to a caller's communication stream (RCCL reads the gradients there and writes
         // them to peers): they keep the default system-scope release
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
@@ -649,6 +651,7 @@ void seld_destroy(seld_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_prep) hipEventDestroy(c->ev_prep);
     if (c->ev_gram) hipEventDestroy(c->ev_gram);
     if (c->ev_rn_ready) hipEventDestroy(c->ev_rn_ready);
     for (auto e_ : c->ev_rn_free) if (e_) hipEventDestroy(e_);
@@ -700,6 +703,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
     if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
     if (!strcmp(key, "conv_wgrad_side")) { c->conv_wgrad_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "prep_side")) { c->prep_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_bn_sums")) { c->xc_fused_bn_sums = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_w16")) { c->xc_w16 = value != 0; return SELD_OK; }               // xception.hip
@@ -874,6 +878,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
     hipStream_t st = c->stream;
     const int B = c->B, S = c->S;
     const int rows = B * S;
+    bool prep_on_side = false;
     // every weight-only pre-pass of the step in ONE launch (prep.hip): the split-bf16 planes of the GEMM and 64 -> 64 conv
     // weights (with the gradient orientations / flipped taps when a backward follows) and the folded head weights
     {
@@ -915,7 +920,13 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
                 h.K = L0.in; h.Hd = L0.out;
             }
         if (fits && (!lin || h.K + 1 <= 4 * 144)) {
-            if (launch_weight_prep(st, a, na, b, nb, h, lin ? c->weff : nullptr)) return fail(c, SELD_ERR_UNSUPPORTED, "weight_prep");
+            // prep_side (round 5): none of these planes is read by the FIRST block's forward (it splits its own 7-channel kernel on load), so the pre-pass runs
+            // on the side stream beside it; the main stream takes it back (ev_prep) behind the first block's launch.  The side stream's later work of the step
+            // (the Gram launches, the kernel gradients) is ordered behind it by the stream itself.
+            prep_on_side = c->prep_side && c->ev_prep && c->xc.empty() && c->rn.empty() && c->conv.size() >= 2;
+            if (prep_on_side) fork_side(c);
+            if (launch_weight_prep(prep_on_side ? c->side : st, a, na, b, nb, h, lin ? c->weff : nullptr)) return fail(c, SELD_ERR_UNSUPPORTED, "weight_prep");
+            if (prep_on_side) hipEventRecord(c->ev_prep, c->side);
         } else {      // more jobs than one launch takes (not a seldnet.json shape): the stand-alone kernels
             if (prepare_gemm_splits(c, st, save)) return fail(c, SELD_ERR_UNSUPPORTED, "gemm_split_b");
             if (lin && prepare_heads_weff(c, st)) return fail(c, SELD_ERR_UNSUPPORTED, "heads_weff");
@@ -979,6 +990,7 @@ static int forward_impl(seld_ctx* c, const float* x, float* sed, float* doa, int
             } else if (launch_conv64_fwd(st, in, c->params + L.w_off, c->params + L.b_off, L.z, stat, &npart, B, L.H, L.W))
                 return fail(c, SELD_ERR_UNSUPPORTED, "conv64_fwd");
         }
+        if (i == 0 && prep_on_side) hipStreamWaitEvent(st, c->ev_prep, 0);      // everything behind the first block's convolution may read the pre-split planes
         if (training && c->sync_fn) {
             // synchronised BatchNorm: this rank's [sum z | sum z^2] -> the host's all-reduce -> coefficients of the GLOBAL batch
             launch_bn_partials_to_sums(st, c->stat_partial, npart, c->sync_buf, (double)B * L.H * L.W);
