@@ -548,6 +548,10 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
     if (a->n_conv >= 2 && c->xc.empty() && c->rn.empty()) {      // option conv_wgrad_side (simple_conv_block: the second / third block's kernel gradients beside the main chain)
         ALLOC(c->wgrad_slab_side, (size_t)conv_wgrad_slab_capacity() * (9 * 4096 + 64));
         ALLOC(c->dzbuf_alt, zmax);
+        for (int k_ = 0; k_ < 2; ++k_)      // ev_rn_free[0 / 1]: the side-stream reader of dzbuf / dzbuf_alt is done (the block models create all five for their own slots)
+            if (!c->ev_rn_free[k_] && hipEventCreateWithFlags(&c->ev_rn_free[k_], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+                seld_destroy(c); return fail(nullptr, SELD_ERR_HIP, "event creation failed");
+            }
     }
     ALLOC(c->tn_slab, (size_t)tn_slab_capacity());
     ALLOC(c->cs_slab, (size_t)256 * 512);
@@ -1817,6 +1821,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
             if (busy[k]) hipStreamWaitEvent(st, c->ev_rn_free[k], 0);
         dp = c->conv[0].dp;
     }
+    bool dz_busy[2] = {false, false};      // conv_wgrad_side: a side-stream kernel gradient reads dzbuf / dzbuf_alt (ev_rn_free[0 / 1] marks its end)
     for (int i = (int)c->conv.size() - 1; i >= 0; --i) {
         ConvL& L = c->conv[i];
         int np = 0;
@@ -1844,14 +1849,14 @@ static int backward_impl(seld_ctx* c, const float* x) {
         // conv_wgrad_side (round 5; same box 2.551 -> 2.523 ms): blocks 2 / 3 put their kernel gradient on the side stream (idle in this part of the step); their dz then
         // alternates between two buffers — the next block's dz is written while the side stream still reads this one's — and the slabs are the side stream's own
         const bool wside = c->conv_wgrad_side && c->prof < 2 && i >= 1 && c->dzbuf_alt && c->wgrad_slab_side;      // (a level-2 profile pass times every kernel alone)
-        float* dzb = (wside && (i & 1)) ? c->dzbuf_alt : c->dzbuf;
+        const int dzpar = (wside && (i & 1)) ? 1 : 0;
+        float* dzb = dzpar ? c->dzbuf_alt : c->dzbuf;
         const bool fused_first = (i == 0) && L.pf == 4 && (L.pt == 5 || L.pt == 4 || L.pt == 2 || L.pt == 1);
         if (!fused_first) {
             snprintf(tn, sizeof tn, "pool%d_bwd_dz", i + 1);
             PROF2(c, tn);
-            if (i == 0 && c->conv_wgrad_side && c->dzbuf_alt) {      // the third block's kernel gradient (side stream) read this buffer: not before it is done
-                hipEventRecord(c->ev_join, c->side); hipStreamWaitEvent(st, c->ev_join, 0);
-            }
+            // a kernel gradient on the side stream may still read this buffer (two blocks back, or the third block's when the first block's dz goes here)
+            if (dz_busy[dzpar]) { hipStreamWaitEvent(st, c->ev_rn_free[dzpar], 0); dz_busy[dzpar] = false; }
             launch_bn_pool_bwd_dz(st, L.z, dp, L.mean, L.invstd, L.scale, L.shift, L.c1c2, dzb, B, L.H, L.W, 64, L.pt, L.pf);
         }
         if (i == 0 && c->gram_active) {
@@ -1890,6 +1895,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 } else if (launch_conv64_wgrad(wst, lin, dzb, wsl, &ns, B, L.H, L.W))
                     return fail(c, SELD_ERR_UNSUPPORTED, "conv64_wgrad");
                 launch_reduce_slabs(wst, wsl, ns, 9 * 4096 + 64, c->grads + L.w_off, 9 * 4096 + 64, 0);
+                if (wside) { hipEventRecord(c->ev_rn_free[dzpar], c->side); dz_busy[dzpar] = true; }      // this dz buffer's reader on the side stream
             }
             snprintf(tn, sizeof tn, "conv%d_dgrad", i + 1);
             {
