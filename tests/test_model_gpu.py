@@ -752,6 +752,42 @@ def test_folded_passes_are_bit_identical_to_the_stand_alone_ones(seldnet_config,
             assert np.array_equal(a, b), f"item {i} differs with {opt}: max |d| = {d:.3e}"
 
 
+def test_four_conv_blocks_parity_and_side_stream_kernel_gradients(seldnet_config):
+    """A simple_conv_block of FOUR blocks (pools (5,2) (1,2) (1,2) (1,2): 32 / 16 / 8 frequency bins behind the first): the train step against
+    the fp64 oracle, and `conv_wgrad_side` (the kernel gradients of blocks 2..4 on the side stream, their dz alternating between two buffers: with
+    four blocks a buffer IS written again while the side stream may still read it — the hand-over event of DESIGN.md section 4) bit for bit equal to
+    the main-stream form over two steps."""
+    import copy
+    from oracle import seldnet_oracle as O
+    from seld_amd import losses, models, train
+    cfg = copy.deepcopy(seldnet_config)
+    cfg["FIRST_ARGS"] = {"filters": [64, 64, 64, 64], "pool_size": [[5, 2], [1, 2], [1, 2], [1, 2]], "dropout_rate": 0.0}
+    spec = O.Spec.from_config(cfg)
+    w, st = O.random_weights(spec, 3)
+    B, T = 3, 100
+    x, ys, yd = O.synthetic_batch(B, T, seed=77)
+    ref = O.train_step(spec, w, st, x, ys, yd, doa_loss="MSE", loss_weight=(1.0, 1000.0), lr=1e-3, step=1, dtype=torch.float64)
+    runs = []
+    for side in (1, 0):
+        model = models.seldnet((B, T, 64, 7), cfg)
+        model.set_option("conv_wgrad_side", side)
+        model.set_weights(w, st)
+        opt = train.Adam(1e-3)
+        out = []
+        for it in range(2):
+            y_p, sl, dl = train.trainstep(model, x, (ys, yd), losses.BinaryCrossentropy(), losses.MSE, (1.0, 1000.0), opt)
+            out += [model.get_grads().copy(), y_p[0].cpu().numpy().copy(), y_p[1].cpu().numpy().copy()]
+            if it == 0 and side == 1:
+                check("4 blocks sed", out[1], ref["sed"])
+                check("4 blocks doa", out[2], ref["doa"])
+                _per_var(model, "4 blocks grad", out[0], ref["grad"])
+        out.append(model.get_weights()[0].copy())
+        runs.append(out)
+        model.close()
+    for a, b in zip(runs[0], runs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.gpu
 def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_config):
     """Round 5: a unit's depthwise input-gradient pass also leaves the kernel-gradient slabs (`xc_fused_dw_bwd`) and, for a folded unit, the
