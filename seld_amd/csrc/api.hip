@@ -119,6 +119,7 @@ struct seld_ctx {
     float *wgrad_slab = nullptr, *tn_slab = nullptr, *cs_slab = nullptr, *wflip = nullptr;
     float *wgrad_slab_side = nullptr, *dzbuf_alt = nullptr;      // conv_wgrad_side: the side stream's own slabs, the second dz buffer (allocated when the option is set)
     int conv_wgrad_side = 1;
+    int dgrad_r8 = 1;      // conv_sb.hip g_sbd_dgrad_r8: the W = 16 four-product input gradient on 8-row tiles (round 5: 2.510 -> 2.496 ms same box)
     float *dgx[SELD_MAX_LAYERS][2] = {}, *dgh[SELD_MAX_LAYERS][2] = {};   // per GRU layer: the side stream reads them later
     float* tn_slab_side = nullptr;
     unsigned short* wsplit = nullptr;      // per 64->64 conv layer i: [2 i] forward, [2 i + 1] flipped; each [9][3][64][64] bf16 planes
@@ -707,6 +708,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tn_lds_floor") && value >= 0 && value <= 100) { c->tn_lds_floor = value; return SELD_OK; }   // experiment: gemm_tn_sb.hip
     if (!strcmp(key, "conv64_dbuf")) { c->conv64_dbuf = value != 0; return SELD_OK; }     // conv_sb.hip
     if (!strcmp(key, "conv_wgrad_side")) { c->conv_wgrad_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "dgrad_r8")) { c->dgrad_r8 = value != 0; return SELD_OK; }
     if (!strcmp(key, "prep_side")) { c->prep_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_bn_sums")) { c->xc_fused_bn_sums = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
@@ -871,6 +873,7 @@ static void apply_kernel_choices(const seld_ctx* c) {
     g_gram_bg_blocks = c->gram_bg_blocks;
     g_xc_xcd_map = c->xc_xcd_map;
     g_xc_w16 = c->xc_w16;
+    g_sbd_dgrad_r8 = c->dgrad_r8;
 }
 
 // resnet50_block: this step's pre-split weight planes (16 operands per launch), on `st`.  They depend on the parameters only: with `prep_side` they are made

@@ -101,6 +101,7 @@ int launch_conv_first_wgrad_fused(hipStream_t st, const float* x, const float* z
                                   int Cin, int pt, int pf);
 int conv_gram_dim(int Cin);
 extern int g_gram_bg_blocks;
+extern int g_sbd_dgrad_r8;    // conv_sb.hip (experiment)
 extern int g_xc_w16;          // xception.hip: row-per-workgroup depthwise kernels for W = 16
 extern int g_xc_xcd_map;      // xception.hip: XCD-contiguous row ranges in the depthwise kernels
 int conv_gram_slab_capacity();

@@ -490,13 +490,13 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
     constexpr int NREG4 = NPIX * 16, NPF = (NREG4 + NT - 1) / NT;      // region float4 slots, per thread
     constexpr int NPL = ONE ? 1 : (FOUR ? 2 : 3);                       // bf16 planes in use
     constexpr int NW4 = NPL * 64 * 8, NWF = ONE ? (512 + NT - 1) / NT : (NW4 + NT - 1) / NT;         // weight uint4 slots per tap, per thread
-    constexpr int LD = 64, PLANE = (NPIX + 1) * LD, WBUF = 3 * 64 * LD;
+    constexpr int LD = 64, PLANE = (NPIX + 1) * LD, WBUF = NPL * 64 * LD;      // NPL planes of region and weights: the four-product form's workgroup is a third smaller
     static_assert(TP % 32 == 0, "tile must be whole 32-pixel MFMA row tiles");
     static_assert(ONE || NWF == 4 || NWF == 3 || (FOUR && NWF == 2), "weight staging is two to four named registers");
     static_assert(!ONE || NWF <= 2, "single-product weight staging is one or two named registers");
     extern __shared__ __attribute__((aligned(16))) unsigned short sb_smem[];
-    unsigned short* Rp = sb_smem;                          // [3][NPIX + 1][LD]
-    unsigned short* Wp = sb_smem + 3 * PLANE;              // [2][3][64][LD]
+    unsigned short* Rp = sb_smem;                          // [NPL][NPIX + 1][LD]
+    unsigned short* Wp = sb_smem + NPL * PLANE;            // [2][NPL][64][LD]
     float* red = reinterpret_cast<float*>(sb_smem);        // [NW][128], aliases the region after the last tile
 #define SBD_CH(p_, c_) ((c_) ^ (((p_) >> 1) & 7))          /* where 16-byte chunk c_ of row p_ lives */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
         rrow[u] = idx < NREG4 ? rr : -1;
         roff[u] = ((rr - 1) * W + cc) * 64 + g * 4;
     }
-    for (int i = tid; i < 3 * LD / 2; i += NT) {           // the zero row of every plane (never written again)
+    for (int i = tid; i < NPL * LD / 2; i += NT) {         // the zero row of every plane (never written again)
         const int pl = i / (LD / 2), e = i - pl * (LD / 2);
         reinterpret_cast<unsigned*>(Rp + pl * PLANE + ZROW * LD)[e] = 0u;
     }
@@ -714,6 +714,8 @@ __global__ __launch_bounds__(32 * ((R << WLOG2) / 32) * 2) void conv64_fwd_sbd_k
 
 int g_bwd_four = 1;        // option "bwd_four_products": backward-only products (input / kernel gradients) on four of the six split-bf16 terms
 static thread_local int s_sbd_four = 0; // set around an input-gradient launch (launch_conv64_dgrad_sb); per host thread: two contexts driven by two threads must not see each other's
+int g_sbd_dgrad_r8 = 1;    // option "dgrad_r8": the W = 16 four-product input gradient on 8-row tiles (4 waves, 74 KB of LDS instead of 8 waves, 107 KB: two workgroups per
+                           // CU, or one beside a kernel-gradient workgroup of the side stream; the same taps and k-steps per pixel: the same bits)
 int g_conv64_dbuf = 1;     // 1: conv64_fwd_sbd_kernel (double-buffered weights) for W = 16 / 4; 0: conv64_fwd_sbr_kernel
 
 template <int WLOG2, int R>
@@ -756,10 +758,27 @@ static int launch_sbd(hipStream_t st, const float* x, const unsigned short* wsp,
     if (ext_out) return -3;      // window extremes come with the PRE loader only (the training step's second block)
     if (g_mfma_one) { if (stat_partial) SBD_GO(true, true) else SBD_GO(false, true) }
     else if (s_sbd_four && !stat_partial) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), dim3(grid), dim3(NT), smem, st, x, wsp, bias, z, stat_partial, B, H);
+        // two planes of region and weights: 106 KB at W = 16, 84 KB at W = 4 — at W = 4 a kernel-gradient workgroup of the side stream (70 KB, option
+        // conv_wgrad_side) fits on the same CU beside it
+        const size_t smem4 = (size_t)(2 * (NPIX + 1) * 64 + 2 * 2 * 64 * 64) * sizeof(unsigned short);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
+        hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), dim3(grid), dim3(NT), smem4, st, x, wsp, bias, z, stat_partial, B, H);
     } else { if (stat_partial) SBD_GO(true, false) else SBD_GO(false, false) }
 #undef SBD_GO
+    if (n_partial) *n_partial = grid;
+    return 0;
+}
+
+// the four-product form alone on R-row tiles (option "dgrad_r8", round 5: 2.510 -> 2.496 ms per step same box; W = 16, R = 8 -> 4 waves, 74 KB of LDS: two workgroups per CU, or one beside a
+// kernel-gradient workgroup of the side stream)
+template <int WLOG2, int R>
+static int launch_sbd_four(hipStream_t st, const float* x, const unsigned short* wsp, const float* bias, float* z, int* n_partial, int B, int H) {
+    constexpr int W = 1 << WLOG2, NW = (R * W) / 32, NT = 64 * NW, NPIX = (R + 2) * W;
+    const int ntiles = B * ((H + R - 1) / R);
+    const int grid = ntiles < 512 ? ntiles : 512;
+    const size_t smem4 = (size_t)(2 * (NPIX + 1) * 64 + 2 * 2 * 64 * 64) * sizeof(unsigned short);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
+    hipLaunchKernelGGL((conv64_fwd_sbd_kernel<WLOG2, R, false, false, true>), dim3(grid), dim3(NT), smem4, st, x, wsp, bias, z, nullptr, B, H);
     if (n_partial) *n_partial = grid;
     return 0;
 }
@@ -769,6 +788,8 @@ int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* w
                          float* stat_partial, int* n_partial, int B, int H, int W, const float* pre_scale, const float* pre_shift, float* pre_out,
                          const float* ext_gamma, float* ext_out) {
     if ((pre_scale || ext_out) && !conv64_fwd_sb_takes_pre(W)) return -3;
+    if (W == 16 && g_conv64_dbuf && s_sbd_four && g_sbd_dgrad_r8 && !stat_partial && !pre_scale && !ext_out && !g_mfma_one)
+        return launch_sbd_four<4, 8>(st, x, wsp, bias, z, n_partial, B, H);      // option "dgrad_r8"
     if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out, ext_gamma, ext_out);   // 8 waves, 156 KB
     if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out);    // 6 waves
     if (W == 8 && g_conv64_dbuf) return launch_sbd<3, 32>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves (resnet50_block stage 1)
