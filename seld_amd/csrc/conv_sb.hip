@@ -790,6 +790,7 @@ int launch_conv64_fwd_sb(hipStream_t st, const float* x, const unsigned short* w
     if ((pre_scale || ext_out) && !conv64_fwd_sb_takes_pre(W)) return -3;
     if (W == 16 && g_conv64_dbuf && s_sbd_four && g_sbd_dgrad_r8 && !stat_partial && !pre_scale && !ext_out && !g_mfma_one)
         return launch_sbd_four<4, 8>(st, x, wsp, bias, z, n_partial, B, H);      // option "dgrad_r8"
+    // (W = 4 on 40-row tiles — 76 KB, two per CU, 480 tiles in one round — measured: 2.331 -> 2.346 ms per step, not kept: profiles/r05_gru_experiments.txt)
     if (W == 16 && g_conv64_dbuf) return launch_sbd<4, 16>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out, ext_gamma, ext_out);   // 8 waves, 156 KB
     if (W == 4 && g_conv64_dbuf) return launch_sbd<2, 48>(st, x, wsp, bias, z, stat_partial, n_partial, B, H, pre_scale, pre_shift, pre_out);    // 6 waves
     if (W == 8 && g_conv64_dbuf) return launch_sbd<3, 32>(st, x, wsp, bias, z, stat_partial, n_partial, B, H);    // 8 waves (resnet50_block stage 1)
