@@ -97,6 +97,9 @@ struct seld_ctx {
     std::vector<XcUnit> xc;
     std::vector<float*> xc_x;                // [xc_blocks + 1] module inputs: xc_x[0] = conv[0].p, xc_x[b + 1] = xc_x[b] + y
     float *xc_small = nullptr, *xc_ident = nullptr, *xc_feat = nullptr, *xc_part = nullptr, *xc_slab = nullptr;
+    float* xc_unit_slab = nullptr;    // xc_nowait: per unit [pointwise slabs | depthwise slabs | first-stage sums]
+    size_t xc_unit_slab_per = 0, xc_unit_slab_pw = 0, xc_unit_slab_dw = 0;
+    int xc_nowait = 1;
     float* xc_slab_tmp = nullptr;     // first-stage sums of the fused pass's slabs (launch_reduce_slabs_2stage)
     float* xc_part_dw = nullptr;      // BatchNorm-backward partials left by the fused depthwise input-gradient pass, one [128] per workgroup
     size_t xc_slab_per = 0;      // floats per depthwise-slab buffer (xc_slab holds two)
@@ -506,6 +509,12 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             c->xc_slab_per = per;
             ALLOC(c->xc_part_dw, (size_t)xc_dw_fused_slabs(c->Bmax, c->S) * 128);
             ALLOC(c->xc_slab_tmp, (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576);
+            // xc_nowait (round 5): every unit its OWN slab buffers — [pointwise slabs | depthwise slabs | first-stage sums], ~20 MB per unit — so that no buffer
+            // is written twice in a step and the backward loop needs no hand-over events (each wait costs the main stream ~5-10 us of bubble, 2 per unit)
+            c->xc_unit_slab_pw = (size_t)xc_pw_bwd_slabs() * 4096;
+            c->xc_unit_slab_dw = (size_t)xc_dw_fused_slabs(c->Bmax, c->S) * 576;
+            c->xc_unit_slab_per = c->xc_unit_slab_pw + c->xc_unit_slab_dw + (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576;
+            ALLOC(c->xc_unit_slab, c->xc.size() * c->xc_unit_slab_per);
         }
     }
     if (resn) {
@@ -710,6 +719,7 @@ int seld_set_option(seld_ctx* c, const char* key, int value) {
     if (!strcmp(key, "conv_wgrad_side")) { c->conv_wgrad_side = value != 0; return SELD_OK; }
     if (!strcmp(key, "dgrad_r8")) { c->dgrad_r8 = value != 0; return SELD_OK; }
     if (!strcmp(key, "prep_side")) { c->prep_side = value != 0; return SELD_OK; }
+    if (!strcmp(key, "xc_nowait")) { c->xc_nowait = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_bn_sums")) { c->xc_fused_bn_sums = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_fused_dw_bwd")) { c->xc_fused_dw_bwd = value != 0; return SELD_OK; }
     if (!strcmp(key, "xc_w16")) { c->xc_w16 = value != 0; return SELD_OK; }               // xception.hip
@@ -1753,7 +1763,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 const bool fold = c->xc_fused_fwd && u > 0;       // the forward applied the previous unit's BatchNormalization on load
                 const float* uin = u == 0 ? c->xc_x[b] : (fold ? c->xc[(size_t)b * 3 + u - 1].z : c->xc[(size_t)b * 3 + u - 1].a);
                 const float* aff = fold ? c->xc[(size_t)b * 3 + u - 1].scale : nullptr;
-                int np = 0, ns = 0;
+                int np = 0, ns = 0, ns_pw = 0;
                 const bool fpw = c->xc_fused_pw_bwd != 0;
                 int sd = -1;
                 float* dz = nullptr;
@@ -1773,9 +1783,16 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         launch_bn_bwd_finalize(st, c->xc_part, np, (double)npix, c->grads + U.g_off, c->grads + U.be_off, U.c1c2, 64);
                     if (!fpw) launch_xc_bn_bwd_dz(st, U.z, gY, U.mean, U.invstd, U.scale, U.c1c2, dz, npix);
                 }
-                const int sf = take(2, fi);
+                // xc_nowait: the default path's side-stream work reads slab buffers only, and every unit has its own: no slot to take back
+                const bool nowait = fpw && c->xc_fused_dw_bwd && c->xc_nowait && c->xc_unit_slab;
+                float* uslab = nowait ? c->xc_unit_slab + ((size_t)b * 3 + u) * c->xc_unit_slab_per : nullptr;
+                int sf = -1;
+                if (nowait) fi ^= 1; else sf = take(2, fi);
                 float* F1c = f1b[fi];
-                if (fpw) {
+                if (nowait) {
+                    PROF2(c, "xc_pointwise_bwd");
+                    launch_xc_pw_bwd(st, U.z, gY, U.dwo, c->params + U.pw_off, U.mean, U.invstd, U.scale, U.c1c2, F1c, uslab, &ns_pw, npix);
+                } else if (fpw) {
                     PROF2(c, "xc_pointwise_bwd");
                     // dz formed on load; F1 = dz W^T and the slabs of dW = dwo^T dz from one pass (xc_pw_bwd); the combine goes to the side stream
                     if (busy[0]) { hipStreamWaitEvent(st, c->ev_rn_free[0], 0); busy[0] = false; }      // slot 0 = the slab buffer here
@@ -1797,7 +1814,7 @@ static int backward_impl(seld_ctx* c, const float* x) {
                 float* gin = (u == 0 && b == 0) ? c->conv[0].dp : F2;
                 if (c->xc_fused_dw_bwd) {
                     // ... and the kernel-gradient slabs from the same pass (slab buffer fi: slot `sf` was taken above, i.e. its last combine is done)
-                    float* sl = c->xc_slab + (size_t)fi * c->xc_slab_per;
+                    float* sl = nowait ? uslab + c->xc_unit_slab_pw : c->xc_slab + (size_t)fi * c->xc_slab_per;
                     // a folded unit's input is the previous unit's pre-BN tensor and gin that BatchNormalization's output gradient: its backward sums ride along
                     const bool sums = fold && c->xc_fused_bn_sums;
                     const XcUnit* Pv = sums ? &c->xc[(size_t)b * 3 + u - 1] : nullptr;
@@ -1806,8 +1823,13 @@ static int backward_impl(seld_ctx* c, const float* x) {
                         return fail(c, SELD_ERR_UNSUPPORTED, "dw3x3_bwd_fused");
                     if (sums) { have_sums = true; n_dw_part = ns; }
                     fork();
-                    launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, c->xc_slab_tmp);      // side stream: its launches are ordered, one tmp
-                    done(sf);
+                    if (nowait) {      // one hand-over per unit: both combines behind it, each buffer its own
+                        launch_reduce_slabs(ws, uslab, ns_pw, 4096, c->grads + U.pw_off, 4096, 0);
+                        launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, uslab + c->xc_unit_slab_pw + c->xc_unit_slab_dw);
+                    } else {
+                        launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, c->xc_slab_tmp);      // side stream: its launches are ordered, one tmp
+                        done(sf);
+                    }
                 } else {
                     fork();
                     launch_dw3x3_bwd_w(ws, uin, F1c, c->xc_slab, &ns, B, S, 16, aff);
