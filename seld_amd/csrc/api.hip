@@ -513,7 +513,8 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
             // is written twice in a step and the backward loop needs no hand-over events (each wait costs the main stream ~5-10 us of bubble, 2 per unit)
             c->xc_unit_slab_pw = (size_t)xc_pw_bwd_slabs() * 4096;
             c->xc_unit_slab_dw = (size_t)xc_dw_fused_slabs(c->Bmax, c->S) * 576;
-            c->xc_unit_slab_per = c->xc_unit_slab_pw + c->xc_unit_slab_dw + (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576;
+            c->xc_unit_slab_per = c->xc_unit_slab_pw + c->xc_unit_slab_dw + (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576 +
+                                  (size_t)reduce_slabs_groups(xc_pw_bwd_slabs()) * 4096;      // + the two combines' first-stage sums
             ALLOC(c->xc_unit_slab, c->xc.size() * c->xc_unit_slab_per);
         }
     }
@@ -1756,6 +1757,8 @@ static int backward_impl(seld_ctx* c, const float* x) {
         auto done = [&](int slot) { if (aside) { hipEventRecord(c->ev_rn_free[slot], c->side); busy[slot] = true; } };
         bool have_sums = false;      // the running unit's BatchNorm-backward partials are in xc_part_dw (n_dw_part rows)
         int n_dw_part = 0;
+        struct { float* slab; int ns_pw, ns_dw; int64_t pw_off, dw_off; } pend[3];      // xc_nowait: a module's combines, launched behind its last unit
+        int npend = 0;
         for (int b = (int)c->arch.xc_blocks - 1; b >= 0; --b) {
             const float* gY = X;
             for (int u = 2; u >= 0; --u) {
@@ -1822,11 +1825,21 @@ static int backward_impl(seld_ctx* c, const float* x) {
                                                sums ? Pv->mean : nullptr, sums ? Pv->invstd : nullptr, sums ? c->xc_part_dw : nullptr))
                         return fail(c, SELD_ERR_UNSUPPORTED, "dw3x3_bwd_fused");
                     if (sums) { have_sums = true; n_dw_part = ns; }
-                    fork();
-                    if (nowait) {      // one hand-over per unit: both combines behind it, each buffer its own
-                        launch_reduce_slabs(ws, uslab, ns_pw, 4096, c->grads + U.pw_off, 4096, 0);
-                        launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, uslab + c->xc_unit_slab_pw + c->xc_unit_slab_dw);
+                    if (nowait) {
+                        // ONE hand-over per module (an event record costs the main stream ~5 us): the three units' combines go to the side stream behind the
+                        // module's last unit, each on buffers of its own
+                        pend[npend++] = {uslab, ns_pw, ns, U.pw_off, U.dw_off};
+                        if (u == 0) {
+                            fork();
+                            for (int q = 0; q < npend; ++q) {
+                                float* tmp_ = pend[q].slab + c->xc_unit_slab_pw + c->xc_unit_slab_dw;
+                                launch_reduce_slabs_2stage(ws, pend[q].slab, pend[q].ns_pw, 4096, c->grads + pend[q].pw_off, 4096, tmp_ + (size_t)reduce_slabs_groups(xc_dw_fused_slabs(c->Bmax, c->S)) * 576);
+                                launch_reduce_slabs_2stage(ws, pend[q].slab + c->xc_unit_slab_pw, pend[q].ns_dw, 576, c->grads + pend[q].dw_off, 576, tmp_);
+                            }
+                            npend = 0;
+                        }
                     } else {
+                        fork();
                         launch_reduce_slabs_2stage(ws, sl, ns, 576, c->grads + U.dw_off, 576, c->xc_slab_tmp);      // side stream: its launches are ordered, one tmp
                         done(sf);
                     }

@@ -798,6 +798,8 @@ def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_c
     * `xc_fused_dw_bwd` = 1 with `xc_fused_bn_sums` = 0 forms every input gradient with the same taps in the same order — every gradient
       EXCEPT the depthwise kernels' is bit-identical to the separate passes — and sums the depthwise kernel gradients in another association:
       held to 2e-6 of each tensor's maximum;
+    * `xc_nowait` = 1 (every unit its own slab buffers, no hand-over events inside the loop, both slab combines in two stages): the units' kernel
+      gradients within 2e-6, everything else bit for bit;
     * `xc_fused_bn_sums` = 1 sums [sum dy | sum dy xhat] per workgroup of four image rows instead of per strided pixel set: every gradient
       within 2e-5 of its maximum (a BatchNorm backward's c1 / c2 feed everything upstream)."""
     import copy
@@ -828,7 +830,8 @@ def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_c
         np.testing.assert_array_equal(got[0], sep[0])
         for name in sep[2]:
             np.testing.assert_array_equal(got[2][name], sep[2][name], err_msg=f"{name} with {alt}")
-    fused = run({"xc_fused_dw_bwd": 1, "xc_fused_bn_sums": 0})
+    # (xc_nowait = 0: the hand-over-free schedule of the default combines the pointwise slabs in two stages — another association of the same sums)
+    fused = run({"xc_fused_dw_bwd": 1, "xc_fused_bn_sums": 0, "xc_nowait": 0})
     np.testing.assert_array_equal(fused[1], sep[1])
     n_dw = 0
     for name, a in sep[2].items():
@@ -839,6 +842,12 @@ def test_xception_fused_depthwise_backward_equals_the_separate_passes(xception_c
         else:
             np.testing.assert_array_equal(b, a, err_msg=name)
     assert n_dw == 6, sorted(sep[2])
+    nw = run({"xc_fused_dw_bwd": 1, "xc_fused_bn_sums": 0, "xc_nowait": 1})      # + per-unit slab buffers, one hand-over per module, two-stage combines
+    for name, a in fused[2].items():
+        if name.endswith("_kernel") and name.startswith("xc"):
+            assert np.abs(a.astype(np.float64) - nw[2][name]).max() <= 2e-6 * np.abs(a).max(), name
+        else:
+            np.testing.assert_array_equal(nw[2][name], a, err_msg=name)
     both = run({})      # the default: both folds
     for name, a in sep[2].items():
         if name.startswith("conv") and name.endswith("bias"):
