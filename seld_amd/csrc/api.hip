@@ -150,7 +150,7 @@ struct seld_ctx {
     int conv64_split_bf16 = 1;             // 1: conv2/conv3 forward + input gradient on bf16 MFMA with exact 3-way split operands
     hipStream_t side = nullptr;            // weight-gradient GEMMs run here, under the BPTT chain of the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_prep = nullptr;
-    int prep_side = 1;      // option: the step's weight pre-pass on the side stream beside the first block's forward
+    int prep_side = 0;      // option (off by default): the step's weight pre-pass on the side stream beside the first block's forward
     hipEvent_t ev_bucket[SELD_MAX_LAYERS] = {};   // side stream: GRU layer n_gru-1-k's (and, k = 0, the heads') gradients are final
     seld_allreduce_fn sync_fn = nullptr;          // synchronised BatchNorm (seld_set_sync_bn)
     void* sync_user = nullptr;

@@ -710,7 +710,7 @@ def test_bitwise_reproducible(seldnet_config):
 
 @pytest.mark.parametrize("B,T", [(3, 100), (4, 600)])
 @pytest.mark.parametrize("opt", [{"conv2_pre_fused": 0}, {"conv3_pre_fused": 0}, {"conv2_pre_fused": 0, "conv3_pre_fused": 0}, {"gram_parts": 1},
-                                 {"conv2_pre_fused": 0, "conv3_pre_fused": 0, "gram_parts": 1}, {"conv_wgrad_side": 0}, {"conv_wgrad_side": 0, "conv1_gram": 0}, {"prep_side": 0}, {"dgrad_r8": 0}])
+                                 {"conv2_pre_fused": 0, "conv3_pre_fused": 0, "gram_parts": 1}, {"conv_wgrad_side": 0}, {"conv_wgrad_side": 0, "conv1_gram": 0}, {"prep_side": 1}, {"dgrad_r8": 0}])
 def test_folded_passes_are_bit_identical_to_the_stand_alone_ones(seldnet_config, B, T, opt):
     """The default step folds the first / second block's BatchNorm + ReLU (+ pooling) passes into the next block's loader
     (`conv2_pre_fused`, `conv3_pre_fused`: bn_relu_ext and bn_relu_pool_fwd<1,4> no longer run) and splits the first block's Gram product over
