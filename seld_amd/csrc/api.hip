@@ -602,7 +602,9 @@ int seld_create(const seld_arch* a, int B, int T, int dtype, int device, seld_ct
         // ev_join and the bucket events cross to a caller's communication stream (RCCL reads the gradients there and writes
         // them to peers): they keep the default system-scope release
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        // ev_prep carries DATA from the side stream to the main stream and is waited for microseconds after its record: it keeps the default release, to be on
+        // the safe side of DESIGN.md section 6 item 8 (ev_gram, the other side -> main data event, is waited for a millisecond after its record)
+        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_gram, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         seld_destroy(c);
         return fail(nullptr, SELD_ERR_HIP, "side stream / event creation failed");
